@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py -- F5-TTS 335M flow-matching sampling throughput on MI355X (BASELINE.json metric).
+
+A "step" = one `F5TTS.sample()` call (32-point Euler = 31 updates = 62 DiT forwards with CFG) over a
+batch of synthetic 10 s utterances (N = 937 mel frames, SURVEY.md §8(d) inputs), inputs resident in
+HBM, output = final mel on device.  value = mel frames produced per second, whole job.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|bf16x3]
+
+Multi-GPU (utterances are independent): one process per GPU under torch.distributed.run,
+weights generated on rank 0 and replicated with ONE RCCL broadcast of the weights arena, every rank
+samples its own B utterances, no data-path collective ("scaling": "weak").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from f5_tts_mlx_amd.audio import log_mel_spectrogram  # noqa: E402
+from f5_tts_mlx_amd.cfm import F5TTS, time_grid  # noqa: E402
+from f5_tts_mlx_amd.dit import DiT  # noqa: E402
+from f5_tts_mlx_amd.weights import F5TTS_335M, synthetic_weights  # noqa: E402
+
+N_FRAMES = 937            # int(10.0 * 93.75), generate.py:23,163
+REF_SAMPLES = 72_000      # 3.0 s reference audio -> 281 mel frames
+NT = 160
+ODE_POINTS = 32
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def flops_forward(N: int, hoisted: bool) -> float:
+    """Algorithmic flops of one DiT utterance-forward, SURVEY.md §8(d).  hoisted=True drops the work the engine
+    runs once per sample instead of once per forward (text path, adaLN/time linears, cond/text input proj)."""
+    blocks = 22 * (N * 2 * (4 * 1024 ** 2 + 2 * 1024 * 2048) + 4 * N ** 2 * 1024)
+    conv = 2 * N * 2 * 31 * 64 * 1024
+    out = N * 2 * 1024 * 100
+    if hoisted:
+        return blocks + conv + out + N * 2 * 128 * 1024
+    ada = 22 * 2 * 1024 * 6144 + 2 * 1024 * 2048 + 2 * (256 * 1024 + 1024 ** 2)
+    text = 4 * N * (2 * 2 * 512 * 1024 + 2 * 7 * 512)
+    return blocks + conv + out + N * 2 * 712 * 1024 + ada + text
+
+
+def synth_batch(B: int, first: int, device):
+    conds, texts, y0s = [], [], []
+    for i in range(first, first + B):
+        wave = (np.random.default_rng(1234 + i).standard_normal(REF_SAMPLES).astype(np.float32) * np.float32(0.1))
+        conds.append(log_mel_spectrogram(torch.from_numpy(wave).to(device))[0])
+        texts.append(np.random.default_rng(2345 + i).integers(0, 2545, NT).astype(np.int32))
+        y0s.append(np.random.default_rng(3456 + i).standard_normal((100, N_FRAMES)).astype(np.float32).T)
+    cond = torch.stack(conds)                                            # (B, 281, 100) on device
+    text = torch.from_numpy(np.stack(texts)).to(device)
+    y0 = torch.from_numpy(np.ascontiguousarray(np.stack(y0s))).to(device)
+    return cond, text, y0
+
+
+def gemm_roofline(model: DiT, B: int, iters: int = 20):
+    """Live HIP-event timing of the dominant kernel (QKV projection GEMM, f5_gemm_kernel<EPI_QKV_ROPE>) at the
+    bench shape: M = 2*B*N rows (cond + null), K = 1024, N = 3072."""
+    import ctypes as C
+    from f5_tts_mlx_amd import engine as E
+    lib, dev = E.load_library(), model.device
+    M, D, H = 2 * B * N_FRAMES, 1024, 16
+    npad = (N_FRAMES + 63) // 64 * 64
+    nseg = 3 if model.precision == "bf16x3" else 1
+    g = torch.Generator(device="cpu").manual_seed(0)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dev).to(torch.bfloat16)
+    a_hi, a_lo, w_hi, w_lo = mk(M, D), mk(M, D), mk(3 * D, D), mk(3 * D, D)
+    bias = torch.zeros(3 * D, device=dev)
+    cos_t, sin_t = torch.ones(N_FRAMES, 32, device=dev), torch.zeros(N_FRAMES, 32, device=dev)
+    qk = [torch.empty(M, 2 * D, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    vt = [torch.zeros(2 * B * H, 64, npad, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    def run():
+        E.check(lib.f5_op_qkv_rope(E.ptr(a_hi), E.ptr(a_lo), E.ptr(w_hi), E.ptr(w_lo), E.ptr(bias), E.ptr(cos_t), E.ptr(sin_t),
+                                   E.ptr(qk[0]), E.ptr(qk[1]), E.ptr(vt[0]), E.ptr(vt[1]), 2 * B, N_FRAMES, npad, H, D, nseg,
+                                   E.stream_ptr(dev)))
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * D * 3 * D                      # algorithmic: one (hi*hi) pass, whatever the precision mode
+    achieved = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", kernel="f5_gemm_kernel<EPI_QKV_ROPE>", shape=f"M={M} N={3 * D} K={D}", avg_launch_ms=ms,
+                achieved=achieved, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / BF16_PEAK_TFLOPS, traffic=None)
+
+
+def cpu_baseline(weights, budget_forwards: int = 2):
+    """The oracle (CPU restatement of the reference, kind="port") timed on the host cores on a bounded sample:
+    `budget_forwards` full-size DiT forwards at N=937 (one CFG function evaluation), extrapolated to the
+    62 forwards of a 32-point Euler solve."""
+    from oracle import f5_oracle as O   # checker / baseline leg only
+    cores = torch.get_num_threads()
+    orc = O.DiTOracle(F5TTS_335M, weights)
+    r = np.random.default_rng(0)
+    x = torch.from_numpy(r.standard_normal((1, N_FRAMES, 100)).astype(np.float32))
+    cond = torch.zeros((1, N_FRAMES, 100))
+    cond[:, :281] = torch.from_numpy(r.standard_normal((1, 281, 100)).astype(np.float32))
+    text = torch.from_numpy(r.integers(0, 2545, (1, NT)).astype(np.int32))
+    t0 = time.perf_counter()
+    for i in range(budget_forwards):
+        orc.forward(x, cond, text, torch.tensor(0.3), bool(i % 2), bool(i % 2), None)
+    dt = (time.perf_counter() - t0) / budget_forwards
+    n_fwd = 2 * (ODE_POINTS - 1)
+    return dict(value=N_FRAMES / (n_fwd * dt), unit="mel-frames/s", cores=cores, kind="port",
+                sample=f"{budget_forwards} full-size fp32 DiT forwards (B=1, N={N_FRAMES}) of the oracle on torch-CPU, "
+                       f"{dt:.2f} s each, extrapolated x{n_fwd} forwards per utterance",
+                rtf=10.0 / (n_fwd * dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU (BASELINE configs[1] = 1, configs[2] = 32)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--method", default="euler")
+    ap.add_argument("--ode-points", type=int, default=ODE_POINTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    B = args.batch
+
+    model = DiT.from_config(F5TTS_335M, precision=args.precision, device=device)
+    weights = None
+    t_w = time.perf_counter()
+    if rank == 0:
+        weights = synthetic_weights(F5TTS_335M, seed=42)
+        model.load_weights(weights)
+    if dist_on:
+        from f5_tts_mlx_amd.dist import broadcast_weights
+        bcast_ms = broadcast_weights(model.engine, src=0)
+    else:
+        bcast_ms = None
+    load_s = time.perf_counter() - t_w
+
+    f5 = F5TTS(transformer=model)
+    cond, text, y0 = synth_batch(B, first=rank * B, device=device)
+    kw = dict(duration=N_FRAMES, steps=args.ode_points, method=args.method, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0,
+              use_graph=not args.no_graph)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out, _ = f5.sample(cond, text, **kw)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, _ = f5.sample(cond, text, **kw)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        frames = world * B * N_FRAMES
+        value = frames / (ms_per_step * 1e-3)
+        per = {"euler": 1, "midpoint": 2, "rk4": 4}[args.method]
+        n_fwd = 2 * per * (args.ode_points - 1)
+        exec_tflop = world * B * n_fwd * flops_forward(N_FRAMES, hoisted=True) / 1e12
+        ref_tflop = world * B * n_fwd * flops_forward(N_FRAMES, hoisted=False) / 1e12
+        roof = gemm_roofline(model, B)
+        rec = {
+            "metric": "mel_frames_per_sec", "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (split-bf16 operands, fp32-class)",
+            "data": "synthetic (seeded random-init 335M weights, white-noise reference audio, random token ids)",
+            "config": {"workload": f"F5-TTS 335M, {args.ode_points}-point {args.method} (={n_fwd} DiT forwards, CFG), "
+                                   f"batch {B}/GPU x 10 s (N=937) utterances, hipGraph={not args.no_graph}",
+                       "global_batch": world * B, "seq_len": N_FRAMES, "parallelism": f"dp{world} (utterance sharding)"},
+            "rtf": world * B * 10.0 / (ms_per_step * 1e-3),
+            "per_gpu_value": value / world,
+            "executed_tflop_per_step": exec_tflop, "reference_tflop_per_step": ref_tflop,
+            "whole_path_tflops": exec_tflop / (ms_per_step * 1e-3),
+            "whole_path_frac_of_bf16_peak": exec_tflop / (ms_per_step * 1e-3) / (world * BF16_PEAK_TFLOPS),
+            "weights_load_s": load_s, "weights_broadcast_ms": bcast_ms,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(weights)
+        print(json.dumps(rec))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

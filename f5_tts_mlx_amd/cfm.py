@@ -1,0 +1,243 @@
+"""Flow-matching sampler (reference: f5_tts_mlx/cfm.py).
+
+ein notation: b - batch, n - sequence, nt - text sequence, nw - raw wave length, d - dimension.
+
+`F5TTS.sample` keeps the reference's signature, defaults, return tuple and error behaviour; the host
+side reproduces the reference's scalar logic (text -> ids, lens/duration clamp, time grid), and the
+GPU side — masks, noise splice, the ODE loop with classifier-free guidance, 2 x NFE DiT forwards —
+runs inside one C-ABI call (`f5_sample`, hipGraph captured).  Tensors are torch (ROCm) tensors
+instead of `mx.array`.
+"""
+from __future__ import annotations
+
+import math
+from pathlib import Path
+from typing import Callable, Dict, List, Literal, Optional, Union
+
+import numpy as np
+import torch
+
+from .audio import MelSpec
+from .dit import DiT
+from .rng import mlx_like_normal
+from .utils import default, exists, fetch_from_hub, lens_to_mask, list_str_to_idx, list_str_to_tensor
+from .weights import F5TTS_335M, convert_upstream_weights
+
+# ode solvers -- generic host versions with the reference's semantics (cfm.py:38-122); the engine has
+# the same three schemes fused with the CFG combine (csrc/rowops.hip: ode_stage_kernel)
+
+
+def odeint_euler(func, y0, t):
+    ys = [y0]
+    y_current = y0
+    for i in range(len(t) - 1):
+        t_current = t[i]
+        dt = t[i + 1] - t_current
+        k = func(t_current, y_current)
+        y_next = y_current + dt * k
+        ys.append(y_next)
+        y_current = y_next
+    return torch.stack(ys)
+
+
+def odeint_midpoint(func, y0, t):
+    ys = [y0]
+    y_current = y0
+    for i in range(len(t) - 1):
+        t_current = t[i]
+        dt = t[i + 1] - t_current
+        k1 = func(t_current, y_current)
+        mid = y_current + 0.5 * dt * k1
+        k2 = func(t_current + 0.5 * dt, mid)
+        y_next = y_current + dt * k2
+        ys.append(y_next)
+        y_current = y_next
+    return torch.stack(ys)
+
+
+def odeint_rk4(func, y0, t):
+    ys = [y0]
+    y_current = y0
+    for i in range(len(t) - 1):
+        t_current = t[i]
+        dt = t[i + 1] - t_current
+        k1 = func(t_current, y_current)
+        k2 = func(t_current + 0.5 * dt, y_current + 0.5 * dt * k1)
+        k3 = func(t_current + 0.5 * dt, y_current + 0.5 * dt * k2)
+        k4 = func(t_current + dt, y_current + dt * k3)
+        y_next = y_current + (dt / 6) * (k1 + 2 * k2 + 2 * k3 + k4)
+        ys.append(y_next)
+        y_current = y_next
+    return torch.stack(ys)
+
+
+def time_grid(steps: int, sway_sampling_coef: Optional[float]) -> np.ndarray:
+    """cfm.py:377-381 in float32: `steps` grid POINTS on [0, 1], optionally sway-warped."""
+    t = np.linspace(0, 1, steps, dtype=np.float32)
+    if exists(sway_sampling_coef):
+        t = (t + np.float32(sway_sampling_coef) * (np.cos(np.float32(math.pi / 2) * t) - np.float32(1) + t)).astype(np.float32)
+    return t
+
+
+class F5TTS:
+    """Conditional flow matching wrapper (cfm.py:128-167).  Training (`__call__` loss) is out of scope."""
+
+    def __init__(
+        self,
+        transformer: DiT,
+        audio_drop_prob=0.3,
+        cond_drop_prob=0.2,
+        num_channels=None,
+        mel_spec_module=None,
+        mel_spec_kwargs: dict = dict(),
+        frac_lengths_mask: tuple[float, float] = (0.7, 1.0),
+        vocab_char_map: dict[str, int] | None = None,
+        vocoder: Callable | None = None,
+        duration_predictor=None,
+    ):
+        self.frac_lengths_mask = frac_lengths_mask
+        self._mel_spec = default(mel_spec_module, MelSpec(**mel_spec_kwargs))
+        num_channels = default(num_channels, self._mel_spec.n_mels)
+        self.num_channels = num_channels
+        self.audio_drop_prob = audio_drop_prob
+        self.cond_drop_prob = cond_drop_prob
+        self.transformer = transformer
+        self.dim = transformer.dim
+        self._vocab_char_map = vocab_char_map
+        self._vocoder = vocoder
+        self._duration_predictor = duration_predictor
+
+    def eval(self):
+        return self
+
+    def __call__(self, inp, text, *, lens=None):
+        raise NotImplementedError("training loss (cfm.py:169-251) is outside the inference engine's scope")
+
+    def predict_duration(self, cond, text, speed: float = 1.0):
+        """cfm.py:253-262."""
+        duration_in_sec = self._duration_predictor(cond, text)
+        frame_rate = self._mel_spec.sample_rate // self._mel_spec.hop_length
+        return (duration_in_sec * frame_rate / speed).to(torch.int32)
+
+    def sample(
+        self,
+        cond: torch.Tensor,                      # b n d  |  b nw
+        text: Union[torch.Tensor, List[str], List[List[str]]],
+        duration: Union[int, torch.Tensor, None] = None,
+        *,
+        lens: Optional[torch.Tensor] = None,
+        steps=8,
+        method: Literal["euler", "midpoint", "rk4"] = "rk4",
+        cfg_strength=2.0,
+        speed=1.0,
+        sway_sampling_coef=-1.0,
+        seed: Optional[int] = None,
+        max_duration=4096,
+        y0: Optional[torch.Tensor] = None,       # extension: inject the initial noise (b, n, d)
+        use_graph: bool = True,
+    ) -> tuple[torch.Tensor, torch.Tensor]:
+        self.eval()
+        device = self.transformer.device
+        cond = torch.as_tensor(cond)
+
+        # raw wave (cfm.py:283-286): batch 1 only, like the reference's `rearrange("1 n -> n")`
+        if cond.ndim == 2:
+            assert cond.shape[0] == 1, "raw-wave conditioning supports batch 1 (cfm.py:284)"
+            cond = self._mel_spec(cond[0])
+            assert cond.shape[-1] == self.num_channels
+        cond = cond.to(device, torch.float32)
+
+        batch, cond_seq_len = cond.shape[:2]
+        if not exists(lens):
+            lens = torch.full((batch,), cond_seq_len, dtype=torch.int64)
+        lens = torch.as_tensor(lens).to("cpu", torch.int64)
+
+        # text (cfm.py:294-303)
+        if isinstance(text, list):
+            if exists(self._vocab_char_map):
+                text = list_str_to_idx(text, self._vocab_char_map)
+            else:
+                text = list_str_to_tensor(text)
+            assert text.shape[0] == batch
+        text = torch.as_tensor(text).to("cpu", torch.int32)
+        if exists(text):
+            text_lens = (text != -1).sum(dim=-1)
+            lens = torch.maximum(text_lens, lens)
+
+        # duration (cfm.py:307-319)
+        if duration is None and self._duration_predictor is not None:
+            duration = self.predict_duration(cond, text, speed)
+        elif duration is None:
+            raise ValueError("Duration must be provided or a duration predictor must be set.")
+        if isinstance(duration, int):
+            duration = torch.full((batch,), duration, dtype=torch.int64)
+        duration = torch.as_tensor(duration).to("cpu", torch.int64)
+        duration = torch.maximum(lens + 1, duration)
+        duration = torch.clip(duration, 0, max_duration)
+        max_duration = int(duration.max().item())
+
+        if method not in ("midpoint", "euler", "rk4"):
+            raise ValueError(f"Unknown method: {method}")
+
+        # pad the conditioning mel to max_duration (cfm.py:321); masks are built on the GPU from lens/durations
+        if max_duration >= cond_seq_len:
+            cond_p = torch.zeros((batch, max_duration, self.num_channels), dtype=torch.float32, device=device)
+            cond_p[:, :cond_seq_len] = cond
+        else:  # mx.pad with a negative width raises in the reference
+            raise ValueError("duration shorter than the conditioning audio")
+
+        # noise input (cfm.py:369-375): channel-major draw per element, zero padded, "b d n -> b n d"
+        if y0 is None:
+            rows = []
+            for dur in duration.tolist():
+                s = seed if exists(seed) else int(np.random.SeedSequence().entropy % (1 << 63))
+                z = mlx_like_normal(s, (self.num_channels, int(dur)))
+                rows.append(np.pad(z, ((0, 0), (0, max_duration - int(dur)))))
+            y0 = torch.from_numpy(np.ascontiguousarray(np.stack(rows).transpose(0, 2, 1)))
+        y0 = torch.as_tensor(y0).to(device, torch.float32).contiguous()
+        assert y0.shape == (batch, max_duration, self.num_channels)
+
+        t = time_grid(steps, sway_sampling_coef)
+
+        out, trajectory = self.transformer.engine.sample(
+            text.to(device).contiguous(), cond_p, lens.tolist(), duration.tolist(), y0, t, method=method,
+            cfg_strength=float(cfg_strength), use_mask=batch > 1, use_graph=use_graph, return_trajectory=True)
+
+        if exists(self._vocoder):
+            out = self._vocoder(out)
+        return out, trajectory
+
+    # ------------------------------------------------------------------------------------------
+    def load_weights(self, weights) -> None:
+        """`weights`: dict or list of (name, array) with reference (MLX-layout) names (cfm.py:517)."""
+        self.transformer.load_weights(dict(weights))
+
+    @classmethod
+    def from_pretrained(cls, hf_model_name_or_path: str, convert_weights=None, quantization_bits: int | None = None,
+                        precision: str = "bf16", device: str = "cuda:0") -> "F5TTS":
+        """cfm.py:404-520.  Loads `model_v1.safetensors` + `vocab.txt` from a local directory or the HF hub
+        (network required).  MLX int4/int8 checkpoints (`quantization_bits`) are MLX-specific and not
+        loadable here."""
+        if exists(quantization_bits):
+            raise NotImplementedError("MLX group-quantized checkpoints (model_v1_{4,8}b) are not supported")
+        path = fetch_from_hub(hf_model_name_or_path, quantization_bits=quantization_bits)
+        if path is None:
+            raise ValueError(f"Could not find model {hf_model_name_or_path}")
+        vocab_path = Path(path) / "vocab.txt"
+        vocab = {v: i for i, v in enumerate(Path(vocab_path).read_text().split("\n"))}
+        if len(vocab) == 0:
+            raise ValueError(f"Could not load vocab from {vocab_path}")
+        convert_weights = default(convert_weights, True)
+        model_path = Path(path) / "model_v1.safetensors"
+        from safetensors.numpy import load_file
+        weights = load_file(str(model_path))
+        if convert_weights:
+            weights = convert_upstream_weights(weights)
+        weights = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
+        f5tts = cls(
+            transformer=DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4,
+                            text_num_embeds=len(vocab) - 1, text_mask_padding=True, precision=precision, device=device),
+            vocab_char_map=vocab,
+        )
+        f5tts.load_weights(weights)
+        return f5tts

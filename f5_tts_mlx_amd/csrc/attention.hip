@@ -1,0 +1,226 @@
+// Flash attention (non-causal, key-padding by per-batch prefix length) for gfx950, head_dim = 64.
+// Reference semantics: mx.fast.scaled_dot_product_attention(q, k, v, scale, mask) at dit.py:166.
+//
+// Layout trick (all softmax state stays lane-local, no LDS round trip for P):
+//   S^T = K * Q^T  via v_mfma_f32_32x32x16_bf16 with A = K tile rows (keys), B = Q rows (queries);
+//         C layout => lane (l&31) owns ONE query column, its 16 accumulators are 16 of the 32 keys
+//         of the block (the other 16 live in lane l^32).  Row max / row sum = in-lane reduction +
+//         one exchange with lane^32.
+//   O^T = V^T * P^T with A = V^T rows (dims) and B = P^T: the MFMA "k" index only has to be the SAME
+//         key for A and B, so P is fed straight from the S accumulators (keys {0-3,8-11}+4*hi per
+//         16-key step) and V^T is read from LDS with the matching key permutation.  V is kept
+//         transposed in HBM ([b*h][64][npad], written by the QKV GEMM epilogue).
+//   O^T's C layout again has query = lane&31, so the online-softmax rescale is a per-lane multiply.
+//
+// Block = 4 waves x 32 queries = 128 queries; KV tile = 64 keys, double-buffered in LDS (padded rows:
+// K 144 B, V^T 136 B => conflict-free ds_read_b128 / ds_read_b64).  bf16x3 mode (HP) carries hi/lo
+// for Q, K, V and splits P in registers: 3 MFMAs per product.
+#include "attention.hpp"
+
+#define KLD 72   // K  tile row stride in elements (144 B)
+#define VLD 68   // V^T tile row stride in elements (136 B)
+
+template <bool HP>
+__global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
+    constexpr int NP = HP ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][NP][64 * KLD];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[2][NP][64 * VLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, lq = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
+    const int ntile = (kvlen + 63) >> 6;
+    const size_t rowbase = (size_t)b * p.seq_len;
+
+    // Q fragments (B operand): query row lq, dims ks*16 + hi*8 .. +8
+    bf16x8 qf[NP][4];
+    {
+        int qr = q0 + lq;
+        if (qr > p.seq_len - 1) qr = p.seq_len - 1;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                qf[pp][ks] = *reinterpret_cast<const bf16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+    }
+
+    // staging: 2 chunks of K and 2 chunks of V^T per thread (per precision part)
+    u32x4 rk[NP][2], rv[NP][2];
+    auto load_tile = [&](int j) {
+        const int key0 = j * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qd = tid + 256 * i;
+            const int r = qd >> 3, c = qd & 7;
+            int key = key0 + r;
+            if (key > p.seq_len - 1) key = p.seq_len - 1;
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                rk[pp][i] = *reinterpret_cast<const u32x4*>(p.qk[pp] + (rowbase + key) * p.ldqk + p.dmodel + h * 64 + c * 8);
+                rv[pp][i] = *reinterpret_cast<const u32x4*>(p.vt[pp] + ((size_t)bh * 64 + r) * p.npad + key0 + c * 8);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qd = tid + 256 * i;
+            const int r = qd >> 3, c = qd & 7;
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                *reinterpret_cast<u32x4*>(&sK[buf][pp][r * KLD + c * 8]) = rk[pp][i];
+                u32x2 lo2, hi2;
+                lo2[0] = rv[pp][i][0]; lo2[1] = rv[pp][i][1];
+                hi2[0] = rv[pp][i][2]; hi2[1] = rv[pp][i][3];
+                *reinterpret_cast<u32x2*>(&sV[buf][pp][r * VLD + c * 8]) = lo2;
+                *reinterpret_cast<u32x2*>(&sV[buf][pp][r * VLD + c * 8 + 4]) = hi2;
+            }
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        o[0][e] = 0.0f;
+        o[1][e] = 0.0f;
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int j = 0; j < ntile; ++j) {
+        const int cur = j & 1;
+        if (j + 1 < ntile) load_tile(j + 1);
+
+        // ---- S^T = K Q^T -------------------------------------------------------------------
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kb][e] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = (kb * 32 + lq) * KLD + ks * 16 + hi * 8;
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sK[cur][0][off]);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[kb], 0, 0, 0);
+                if (HP) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sK[cur][NP - 1][off]);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[0][ks], s[kb], 0, 0, 0);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- online softmax (per query column = per lane) ---------------------------------
+        const int key0 = j * 64;
+        if (key0 + 64 > kvlen) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= kvlen) s[kb][r] = -INFINITY;
+                }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+        const float mc = m_new * c2;
+        m_run = m_new;
+        float psum = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
+                s[kb][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            o[0][e] *= alpha;
+            o[1][e] *= alpha;
+        }
+
+        // ---- O^T += V^T P^T ----------------------------------------------------------------
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ++ks4) {
+            const int kb = ks4 >> 1, sp = ks4 & 1;
+            uint32_t pw[4], pwl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p0 = s[kb][8 * sp + 2 * e], p1 = s[kb][8 * sp + 2 * e + 1];
+                pw[e] = f5_pack2(p0, p1);
+                if (HP) pwl[e] = f5_pack2_lo(p0, p1);
+            }
+            const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+            bf16x8 pbl = pb;
+            if (HP) pbl = __builtin_bit_cast(bf16x8, u32x4{pwl[0], pwl[1], pwl[2], pwl[3]});
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int off = (db * 32 + lq) * VLD + ks4 * 16 + 4 * hi;
+                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&sV[cur][0][off]);
+                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&sV[cur][0][off + 8]);
+                const bf16x8 a = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                if (HP) {
+                    const bf16x4 w0 = *reinterpret_cast<const bf16x4*>(&sV[cur][NP - 1][off]);
+                    const bf16x4 w1 = *reinterpret_cast<const bf16x4*>(&sV[cur][NP - 1][off + 8]);
+                    const bf16x8 al = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pb, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pbl, o[db], 0, 0, 0);
+                }
+            }
+        }
+
+        if (j + 1 < ntile) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store O[token][h*64 + d] ---------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + lq;
+    if (qr < p.seq_len) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = db * 32 + 8 * rg + 4 * hi;
+                const float v0 = o[db][rg * 4 + 0] * inv, v1 = o[db][rg * 4 + 1] * inv;
+                const float v2 = o[db][rg * 4 + 2] * inv, v3 = o[db][rg * 4 + 3] * inv;
+                const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
+                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+                if (HP && p.out[1])
+                    *reinterpret_cast<u32x2*>(p.out[1] + off) = u32x2{f5_pack2_lo(v0, v1), f5_pack2_lo(v2, v3)};
+            }
+    }
+}
+
+int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
+    F5_REQUIRE(a.B > 0 && a.H > 0 && a.seq_len > 0, "attention: bad shape");
+    F5_REQUIRE(a.npad % 64 == 0 && a.npad >= a.seq_len, "attention: npad must be a multiple of 64 and >= seq_len");
+    F5_REQUIRE(a.ldqk % 8 == 0 && a.ldo % 4 == 0, "attention: bad leading dims");
+    F5_REQUIRE(a.qk[0] && a.vt[0] && a.out[0], "attention: null pointer");
+    dim3 grid(f5_cdiv(a.seq_len, 128), a.B * a.H);
+    if (a.hp) {
+        F5_REQUIRE(a.qk[1] && a.vt[1] && a.out[1], "attention: bf16x3 needs lo buffers");
+        hipLaunchKernelGGL((f5_attn_kernel<true>), grid, dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((f5_attn_kernel<false>), grid, dim3(256), 0, stream, a);
+    }
+    F5_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,98 @@
+// Shared device/host helpers for the gfx950 F5-TTS sampling engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define F5_WAVE 64
+
+// ---- error handling (never throw across the C ABI) -------------------------------------------
+void f5_set_error(const char* fmt, ...);
+#define F5_HIP_CHECK(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            f5_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+#define F5_LAUNCH_CHECK() F5_HIP_CHECK(hipGetLastError())
+#define F5_REQUIRE(cond, ...)                                                                     \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            f5_set_error(__VA_ARGS__);                                                            \
+            return 2;                                                                             \
+        }                                                                                         \
+    } while (0)
+
+// ---- bf16 helpers ----------------------------------------------------------------------------
+// float -> bf16 round-to-nearest-even (same rounding as torch's .to(bfloat16)); hi/lo split for the
+// 3-pass "bf16x3" precision mode: x ~= hi + lo with |x - hi - lo| <= 2^-17 |x|.
+__host__ __device__ inline u16 f5_f2bf_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // NaN
+    uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(r >> 16);
+}
+__host__ __device__ inline float f5_bf_bits2f(u16 h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__device__ inline bf16_t f5_f2bf(float f) { return static_cast<bf16_t>(f); }
+__device__ inline float f5_bf2f(bf16_t h) { return static_cast<float>(h); }
+__device__ inline void f5_split(float f, bf16_t& hi, bf16_t& lo) {
+    hi = static_cast<bf16_t>(f);
+    lo = static_cast<bf16_t>(f - static_cast<float>(hi));
+}
+
+// pack two floats to bf16 pairs (element 0 in the low half); *_lo packs the rounding residuals
+__device__ inline uint32_t f5_pack2(float a, float b) {
+    const u16 x = __builtin_bit_cast(u16, static_cast<bf16_t>(a));
+    const u16 y = __builtin_bit_cast(u16, static_cast<bf16_t>(b));
+    return (uint32_t)x | ((uint32_t)y << 16);
+}
+__device__ inline uint32_t f5_pack2_lo(float a, float b) {
+    const float ra = a - static_cast<float>(static_cast<bf16_t>(a));
+    const float rb = b - static_cast<float>(static_cast<bf16_t>(b));
+    return f5_pack2(ra, rb);
+}
+
+// ---- activations (MLX semantics, see oracle/f5_oracle.py) ------------------------------------
+__device__ inline float f5_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ inline float f5_gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ inline float f5_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ inline float f5_mish(float x) {
+    float sp = (x > 20.0f) ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+
+// ---- wave helpers ----------------------------------------------------------------------------
+__device__ inline float f5_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float f5_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int f5_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

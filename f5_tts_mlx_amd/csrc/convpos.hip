@@ -1,0 +1,139 @@
+// ConvPositionEmbedding conv (dit.py:29-50): grouped Conv1d(C, C, k=31, groups=C/64, pad=15) + Mish on
+// channels-last (b, n, c) input, as an implicit GEMM per group on v_mfma_f32_32x32x16_bf16:
+//   out[n][co] = sum_{tap, ci} x[n + tap - 15][ci] * w[co][tap][ci]      (M = tokens, N = 64, K = taps*64)
+// The A operand is a sliding window over ONE LDS-resident halo tile of x ((128 + taps - 1) rows x 64 ci),
+// so x is read from HBM once per block; the per-tap weight slab [64 co][64 ci] is double-buffered.
+// Sequence edges are zero padded per batch element (Conv1d padding); no mask (dit.py:251 passes none).
+#include "convpos.hpp"
+
+#define XLD 72  // LDS row stride (elements) for both tiles: 144 B rows => conflict-free ds_read_b128
+#define CP_ROWS 128
+#define CP_MAXTAPS 31
+
+template <bool HP>
+__global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
+    constexpr int NP = HP ? 2 : 1;
+    constexpr int HALO = CP_ROWS + CP_MAXTAPS - 1;
+    __shared__ __attribute__((aligned(16))) bf16_t sX[NP][HALO * XLD];
+    __shared__ __attribute__((aligned(16))) bf16_t sW[2][NP][64 * XLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, lr = lane & 31;
+    const int n0 = blockIdx.x * CP_ROWS;
+    const int g = blockIdx.y;
+    const int b = blockIdx.z;
+    const int taps = p.taps;
+    const int pad = taps >> 1;
+    const int halo = CP_ROWS + taps - 1;
+    const size_t rowbase = (size_t)b * p.seq_len;
+    const int kdim = taps * 64;
+
+    // ---- stage the x halo tile (zero outside [0, seq_len)) --------------------------------------
+    for (int qd = tid; qd < halo * 8; qd += 256) {
+        const int r = qd >> 3, c = qd & 7;
+        const int n = n0 - pad + r;
+        const bool ok = (n >= 0) && (n < p.seq_len);
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(p.in[pp] + (rowbase + n) * p.ld + g * 64 + c * 8);
+            *reinterpret_cast<u32x4*>(&sX[pp][r * XLD + c * 8]) = v;
+        }
+    }
+
+    // ---- weight slab staging: 2 chunks per thread per part ---------------------------------------
+    u32x4 rw[NP][2];
+#define CP_LOADW(t_)                                                                                    \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+            const int qd_ = tid + 256 * i;                                                              \
+            const int r_ = qd_ >> 3, c_ = qd_ & 7;                                                      \
+            _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) rw[pp][i] =                               \
+                *reinterpret_cast<const u32x4*>(p.W[pp] + (size_t)(g * 64 + r_) * kdim + (t_) * 64 + c_ * 8); \
+        }                                                                                               \
+    }
+#define CP_STOREW(buf_)                                                                                 \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+            const int qd_ = tid + 256 * i;                                                              \
+            const int r_ = qd_ >> 3, c_ = qd_ & 7;                                                      \
+            _Pragma("unroll") for (int pp = 0; pp < NP; ++pp)                                           \
+                *reinterpret_cast<u32x4*>(&sW[buf_][pp][r_ * XLD + c_ * 8]) = rw[pp][i];               \
+        }                                                                                               \
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        acc[0][e] = 0.0f;
+        acc[1][e] = 0.0f;
+    }
+
+    CP_LOADW(0);
+    CP_STOREW(0);
+    __syncthreads();
+
+    for (int t = 0; t < taps; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < taps) CP_LOADW(t + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int aoff = (wave * 32 + lr + t) * XLD + ks * 16 + hi * 8;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sX[0][aoff]);
+            bf16x8 al = a;
+            if (HP) al = *reinterpret_cast<const bf16x8*>(&sX[NP - 1][aoff]);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int boff = (nb * 32 + lr) * XLD + ks * 16 + hi * 8;
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(&sW[cur][0][boff]);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[nb], 0, 0, 0);
+                if (HP) {
+                    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&sW[cur][NP - 1][boff]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, w, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wl, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < taps) CP_STOREW(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias, Mish, store ----------------------------------------------------------
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int co = g * 64 + nb * 32 + lr;
+        const float bias = p.bias[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (n < p.seq_len) {
+                const float v = f5_mish(acc[nb][r] + bias);
+                const size_t off = (rowbase + n) * p.ldo + co;
+                if (p.mode == 0) {
+                    bf16_t h, l;
+                    f5_split(v, h, l);
+                    p.out_bf[0][off] = h;
+                    if (p.out_bf[1]) p.out_bf[1][off] = l;
+                } else {
+                    p.out_f32[off] += v;
+                }
+            }
+        }
+    }
+}
+
+int f5_launch_convpos(const F5ConvPosArgs& a, hipStream_t stream) {
+    F5_REQUIRE(a.B > 0 && a.seq_len > 0 && a.groups > 0, "convpos: bad shape");
+    F5_REQUIRE(a.C == a.groups * 64, "convpos: channels per group must be 64 (C=%d groups=%d)", a.C, a.groups);
+    F5_REQUIRE(a.taps >= 1 && a.taps <= CP_MAXTAPS && (a.taps & 1), "convpos: taps must be odd and <= %d", CP_MAXTAPS);
+    F5_REQUIRE(a.ld % 8 == 0, "convpos: ld must be a multiple of 8");
+    dim3 grid(f5_cdiv(a.seq_len, CP_ROWS), a.groups, a.B);
+    if (a.nseg == 3) {
+        F5_REQUIRE(a.in[1] && a.W[1], "convpos: bf16x3 needs lo operands");
+        hipLaunchKernelGGL((f5_convpos_kernel<true>), grid, dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((f5_convpos_kernel<false>), grid, dim3(256), 0, stream, a);
+    }
+    F5_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,1011 @@
+// Engine: weights arena, workspace plan, F5TTS.sample orchestration (eager or hipGraph) and the C ABI.
+// Reference path: F5TTS.sample (cfm.py:312-397) -> fn/CFG (cfm.py:340-365) -> DiT.__call__ (dit.py:374-401).
+//
+// What is hoisted out of the ODE loop (numerically identical up to summation order):
+//   * time MLP + all 22 adaLN linears + final adaLN for every function evaluation time (t only),
+//   * the text path (TextEmbedding + ConvNeXtV2 blocks) for the cond and null branches (text only),
+//   * the cond/text part of the input projection  W_c*cond + W_t*text + b  (dit.py:250).
+// Per function evaluation the cond and null branches run as one batch of 2*B*N rows.
+#include <stdarg.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/f5tts_hip.h"
+#include "attention.hpp"
+#include "convpos.hpp"
+#include "gemm.hpp"
+#include "rowops.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// error string
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void f5_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* f5_last_error(void) { return g_err; }
+extern "C" int f5_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// arena / workspace bump allocator
+// ------------------------------------------------------------------------------------------------
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+struct MatBF {          // bf16 matrix in the arena (hi + optional lo)
+    size_t hi = 0, lo = 0;
+    int rows = 0, ld = 0;
+};
+
+struct TensorDst {      // where (part of) a reference tensor goes
+    int kind;           // 0: fp32 copy at off (count elements); 1: bf16 matrix placement
+    size_t off = 0;     // kind 0
+    MatBF mat;          // kind 1
+    int row0 = 0;       // first destination row
+    int src_rows = 0, src_cols = 0;
+    int c0 = 0, c1 = 0, dst_c0 = 0;  // source column range -> destination column offset
+    std::vector<int64_t> shape;
+    bool loaded = false;
+};
+
+struct BlockW {
+    MatBF qkv, o, ff1, ff2;
+    size_t bqkv, bo, bff1, bff2;  // fp32
+};
+struct TextBlockW {
+    size_t dw_w, dw_b, ln_w, ln_b, b1, gamma, beta, b2;
+    MatBF pw1, pw2;
+};
+
+struct Workspace {
+    size_t total = 0;
+    size_t lens, dur2, text, ids, keep, rowkeep;
+    size_t tgrid, dt, sinus, th, temb, mod;
+    size_t rope_cos, rope_sin;
+    size_t cond, traj, ytmp, kst, vel;
+    size_t xin[2];
+    size_t te[2], tg, grn_partial, grn_nx;
+    size_t tln[2], tg2[2], ct[2];
+    size_t hc, x;
+    size_t xb[2], c1[2], h[2], qk[2], vt[2], ao[2], ffh[2];
+    size_t vt_bytes;
+};
+
+struct GraphEntry {
+    std::string key;
+    hipGraphExec_t exec;
+};
+
+struct f5_engine {
+    f5_config cfg;
+    int prec;
+    int np;  // precision parts (1 or 2)
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    size_t arena_need = 0;
+    bool finalized = false;
+    std::unordered_map<std::string, std::vector<TensorDst>> tmap;
+    // arena offsets
+    size_t time_w0, time_b0, time_w2, time_b2;
+    size_t ada_w, ada_b;  // [(6*depth+2)*D][D], [(6*depth+2)*D]
+    size_t text_table, text_pos;
+    std::vector<TextBlockW> tblocks;
+    MatBF wx, wct;
+    size_t bproj;
+    MatBF conv_w[2];
+    size_t conv_b[2];
+    std::vector<BlockW> blocks;
+    MatBF wout;
+    size_t bout;
+    std::vector<GraphEntry> graphs;
+};
+
+static int nfe_per_step(int method) { return method == F5_EULER ? 1 : (method == F5_MIDPOINT ? 2 : 4); }
+
+static MatBF alloc_mat(Bump& b, int rows, int ld, int np) {
+    MatBF m;
+    m.rows = rows;
+    m.ld = ld;
+    const int rows_pad = (rows + 127) / 128 * 128;  // GEMM reads whole 128-row weight tiles
+    m.hi = b.take((size_t)rows_pad * ld * 2);
+    m.lo = np == 2 ? b.take((size_t)rows_pad * ld * 2) : 0;
+    return m;
+}
+
+static void add_f32(f5_engine* e, const std::string& name, size_t off, std::vector<int64_t> shape) {
+    TensorDst d;
+    d.kind = 0;
+    d.off = off;
+    d.shape = shape;
+    e->tmap[name].push_back(d);
+}
+static void add_mat(f5_engine* e, const std::string& name, const MatBF& m, int row0, int src_rows, int src_cols, int c0, int c1,
+                    int dst_c0, std::vector<int64_t> shape) {
+    TensorDst d;
+    d.kind = 1;
+    d.mat = m;
+    d.row0 = row0;
+    d.src_rows = src_rows;
+    d.src_cols = src_cols;
+    d.c0 = c0;
+    d.c1 = c1;
+    d.dst_c0 = dst_c0;
+    d.shape = shape;
+    e->tmap[name].push_back(d);
+}
+
+static int build_arena_plan(f5_engine* e) {
+    const f5_config& c = e->cfg;
+    const int D = c.dim, Dt = c.text_dim, FF = c.ff_dim, TF = c.text_ff_dim, L = c.depth, np = e->np;
+    Bump b;
+    const std::string p = "transformer.";
+    // time MLP (fp32)
+    e->time_w0 = b.take((size_t)D * c.freq_embed_dim * 4);
+    e->time_b0 = b.take((size_t)D * 4);
+    e->time_w2 = b.take((size_t)D * D * 4);
+    e->time_b2 = b.take((size_t)D * 4);
+    add_f32(e, p + "time_embed.time_mlp.layers.0.weight", e->time_w0, {D, c.freq_embed_dim});
+    add_f32(e, p + "time_embed.time_mlp.layers.0.bias", e->time_b0, {D});
+    add_f32(e, p + "time_embed.time_mlp.layers.2.weight", e->time_w2, {D, D});
+    add_f32(e, p + "time_embed.time_mlp.layers.2.bias", e->time_b2, {D});
+    // adaLN (fp32): all blocks + final stacked so one skinny GEMM builds the whole modulation table
+    const size_t ada_rows = (size_t)(6 * L + 2) * D;
+    e->ada_w = b.take(ada_rows * D * 4);
+    e->ada_b = b.take(ada_rows * 4);
+    // text embedding
+    e->text_table = b.take((size_t)(c.text_num_embeds + 1) * Dt * 4);
+    e->text_pos = b.take((size_t)c.text_max_pos * Dt * 4);
+    add_f32(e, p + "text_embed.text_embed.weight", e->text_table, {c.text_num_embeds + 1, Dt});
+    e->tblocks.resize(c.conv_layers);
+    for (int i = 0; i < c.conv_layers; ++i) {
+        TextBlockW& t = e->tblocks[i];
+        const std::string q = p + "text_embed.text_blocks.layers." + std::to_string(i) + ".";
+        t.dw_w = b.take((size_t)Dt * 7 * 4);
+        t.dw_b = b.take((size_t)Dt * 4);
+        t.ln_w = b.take((size_t)Dt * 4);
+        t.ln_b = b.take((size_t)Dt * 4);
+        t.b1 = b.take((size_t)TF * 4);
+        t.gamma = b.take((size_t)TF * 4);
+        t.beta = b.take((size_t)TF * 4);
+        t.b2 = b.take((size_t)Dt * 4);
+        t.pw1 = alloc_mat(b, TF, Dt, np);
+        t.pw2 = alloc_mat(b, Dt, TF, np);
+        add_f32(e, q + "dwconv.weight", t.dw_w, {Dt, 7, 1});
+        add_f32(e, q + "dwconv.bias", t.dw_b, {Dt});
+        add_f32(e, q + "norm.weight", t.ln_w, {Dt});
+        add_f32(e, q + "norm.bias", t.ln_b, {Dt});
+        add_mat(e, q + "pwconv1.weight", t.pw1, 0, TF, Dt, 0, Dt, 0, {TF, Dt});
+        add_f32(e, q + "pwconv1.bias", t.b1, {TF});
+        add_f32(e, q + "grn.gamma", t.gamma, {1, 1, TF});
+        add_f32(e, q + "grn.beta", t.beta, {1, 1, TF});
+        add_mat(e, q + "pwconv2.weight", t.pw2, 0, Dt, TF, 0, TF, 0, {Dt, TF});
+        add_f32(e, q + "pwconv2.bias", t.b2, {Dt});
+    }
+    // input projection, split by input segment (x | cond | text), dit.py:250
+    const int M = c.mel_dim, IN = 2 * M + Dt;
+    e->wx = alloc_mat(b, D, 128, np);
+    e->wct = alloc_mat(b, D, 128 + Dt, np);
+    e->bproj = b.take((size_t)D * 4);
+    add_mat(e, p + "input_embed.proj.weight", e->wx, 0, D, IN, 0, M, 0, {D, IN});
+    add_mat(e, p + "input_embed.proj.weight", e->wct, 0, D, IN, M, 2 * M, 0, {D, IN});
+    add_mat(e, p + "input_embed.proj.weight", e->wct, 0, D, IN, 2 * M, IN, 128, {D, IN});
+    add_f32(e, p + "input_embed.proj.bias", e->bproj, {D});
+    const int kc = c.conv_pos_kernel, gin = D / c.conv_pos_groups;
+    for (int j = 0; j < 2; ++j) {
+        e->conv_w[j] = alloc_mat(b, D, kc * gin, np);
+        e->conv_b[j] = b.take((size_t)D * 4);
+        const std::string q = p + "input_embed.conv_pos_embed.conv1d.layers." + std::to_string(j * 2) + ".";
+        add_mat(e, q + "weight", e->conv_w[j], 0, D, kc * gin, 0, kc * gin, 0, {D, kc, gin});
+        add_f32(e, q + "bias", e->conv_b[j], {D});
+    }
+    e->blocks.resize(L);
+    for (int i = 0; i < L; ++i) {
+        BlockW& w = e->blocks[i];
+        const std::string q = p + "transformer_blocks." + std::to_string(i) + ".";
+        w.qkv = alloc_mat(b, 3 * D, D, np);
+        w.o = alloc_mat(b, D, D, np);
+        w.ff1 = alloc_mat(b, FF, D, np);
+        w.ff2 = alloc_mat(b, D, FF, np);
+        w.bqkv = b.take((size_t)3 * D * 4);
+        w.bo = b.take((size_t)D * 4);
+        w.bff1 = b.take((size_t)FF * 4);
+        w.bff2 = b.take((size_t)D * 4);
+        add_f32(e, q + "attn_norm.linear.weight", e->ada_w + (size_t)i * 6 * D * D * 4, {6 * D, D});
+        add_f32(e, q + "attn_norm.linear.bias", e->ada_b + (size_t)i * 6 * D * 4, {6 * D});
+        const char* nm[3] = {"to_q", "to_k", "to_v"};
+        for (int k = 0; k < 3; ++k) {
+            add_mat(e, q + "attn." + nm[k] + ".weight", w.qkv, k * D, D, D, 0, D, 0, {D, D});
+            add_f32(e, q + "attn." + nm[k] + ".bias", w.bqkv + (size_t)k * D * 4, {D});
+        }
+        add_mat(e, q + "attn.to_out.layers.0.weight", w.o, 0, D, D, 0, D, 0, {D, D});
+        add_f32(e, q + "attn.to_out.layers.0.bias", w.bo, {D});
+        add_mat(e, q + "ff.ff.layers.0.layers.0.weight", w.ff1, 0, FF, D, 0, D, 0, {FF, D});
+        add_f32(e, q + "ff.ff.layers.0.layers.0.bias", w.bff1, {FF});
+        add_mat(e, q + "ff.ff.layers.2.weight", w.ff2, 0, D, FF, 0, FF, 0, {D, FF});
+        add_f32(e, q + "ff.ff.layers.2.bias", w.bff2, {D});
+    }
+    add_f32(e, p + "norm_out.linear.weight", e->ada_w + (size_t)L * 6 * D * D * 4, {2 * D, D});
+    add_f32(e, p + "norm_out.linear.bias", e->ada_b + (size_t)L * 6 * D * 4, {2 * D});
+    e->wout = alloc_mat(b, M, D, np);
+    e->bout = b.take((size_t)M * 4);
+    add_mat(e, p + "proj_out.weight", e->wout, 0, M, D, 0, D, 0, {M, D});
+    add_f32(e, p + "proj_out.bias", e->bout, {M});
+    e->arena_need = b.off;
+    return 0;
+}
+
+extern "C" int f5_engine_create(const f5_config* cfg, int precision, f5_engine** out) {
+    F5_REQUIRE(cfg && out, "f5_engine_create: null argument");
+    const f5_config& c = *cfg;
+    F5_REQUIRE(precision == F5_PREC_BF16 || precision == F5_PREC_BF16X3, "unknown precision %d", precision);
+    F5_REQUIRE(c.dim_head == 64, "dim_head must be 64 (got %d)", c.dim_head);
+    F5_REQUIRE(c.heads * c.dim_head == c.dim, "heads * dim_head must equal dim (%d * %d != %d)", c.heads, c.dim_head, c.dim);
+    F5_REQUIRE(c.dim % 256 == 0 && c.dim <= 1024, "dim must be a multiple of 256 and <= 1024 (got %d)", c.dim);
+    F5_REQUIRE(c.dim / c.conv_pos_groups == 64, "dim / conv_pos_groups must be 64");
+    F5_REQUIRE(c.conv_pos_kernel % 2 == 1 && c.conv_pos_kernel <= 31, "conv_pos_kernel must be odd and <= 31");
+    F5_REQUIRE(c.text_dim % 256 == 0 && c.text_dim <= 1024, "text_dim must be a multiple of 256 and <= 1024 (got %d)", c.text_dim);
+    F5_REQUIRE(c.ff_dim % 128 == 0 && c.text_ff_dim % 128 == 0, "ff dims must be multiples of 128");
+    F5_REQUIRE(c.mel_dim >= 1 && c.mel_dim <= 128, "mel_dim must be in [1,128]");
+    F5_REQUIRE(c.freq_embed_dim % 256 == 0 && c.freq_embed_dim <= 1024, "freq_embed_dim must be a multiple of 256");
+    F5_REQUIRE(c.depth >= 1 && c.conv_layers >= 1, "depth and conv_layers must be >= 1");
+    f5_engine* e = new f5_engine();
+    e->cfg = c;
+    e->prec = precision;
+    e->np = precision == F5_PREC_BF16X3 ? 2 : 1;
+    build_arena_plan(e);
+    *out = e;
+    return 0;
+}
+
+extern "C" void f5_engine_destroy(f5_engine* e) {
+    if (!e) return;
+    for (auto& g : e->graphs) hipGraphExecDestroy(g.exec);
+    delete e;
+}
+
+extern "C" int f5_weights_bytes(f5_engine* e, size_t* bytes) {
+    F5_REQUIRE(e && bytes, "null argument");
+    *bytes = e->arena_need;
+    return 0;
+}
+
+extern "C" int f5_set_weights_arena(f5_engine* e, void* dev_arena, size_t bytes, void* stream) {
+    F5_REQUIRE(e && dev_arena, "null argument");
+    F5_REQUIRE(bytes >= e->arena_need, "weights arena too small: %zu < %zu", bytes, e->arena_need);
+    F5_REQUIRE(((uintptr_t)dev_arena & 255) == 0, "weights arena must be 256-byte aligned");
+    e->arena = (char*)dev_arena;
+    e->arena_bytes = bytes;
+    F5_HIP_CHECK(hipMemsetAsync(dev_arena, 0, e->arena_need, (hipStream_t)stream));  // zero pads
+    F5_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int f5_load_tensor(f5_engine* e, const char* name, const float* host, int ndim, const int64_t* shape) {
+    F5_REQUIRE(e && name && host && shape, "null argument");
+    F5_REQUIRE(e->arena, "f5_set_weights_arena must be called first");
+    auto it = e->tmap.find(name);
+    F5_REQUIRE(it != e->tmap.end(), "unknown tensor name '%s'", name);
+    for (TensorDst& d : it->second) {
+        F5_REQUIRE((int)d.shape.size() == ndim, "tensor '%s': expected %zu dims, got %d", name, d.shape.size(), ndim);
+        size_t count = 1;
+        for (int i = 0; i < ndim; ++i) {
+            F5_REQUIRE(d.shape[i] == shape[i], "tensor '%s': dim %d is %lld, expected %lld", name, i, (long long)shape[i],
+                       (long long)d.shape[i]);
+            count *= (size_t)shape[i];
+        }
+        if (d.kind == 0) {
+            F5_HIP_CHECK(hipMemcpy(e->arena + d.off, host, count * 4, hipMemcpyHostToDevice));
+        } else {
+            const int ncol = d.c1 - d.c0;
+            std::vector<u16> hi((size_t)d.src_rows * ncol), lo;
+            if (e->np == 2) lo.resize(hi.size());
+            for (int r = 0; r < d.src_rows; ++r)
+                for (int cc = 0; cc < ncol; ++cc) {
+                    const float v = host[(size_t)r * d.src_cols + d.c0 + cc];
+                    const u16 h = f5_f2bf_bits(v);
+                    hi[(size_t)r * ncol + cc] = h;
+                    if (e->np == 2) lo[(size_t)r * ncol + cc] = f5_f2bf_bits(v - f5_bf_bits2f(h));
+                }
+            const size_t dst_off = ((size_t)d.row0 * d.mat.ld + d.dst_c0) * 2;
+            F5_HIP_CHECK(hipMemcpy2D(e->arena + d.mat.hi + dst_off, (size_t)d.mat.ld * 2, hi.data(), (size_t)ncol * 2,
+                                     (size_t)ncol * 2, d.src_rows, hipMemcpyHostToDevice));
+            if (e->np == 2)
+                F5_HIP_CHECK(hipMemcpy2D(e->arena + d.mat.lo + dst_off, (size_t)d.mat.ld * 2, lo.data(), (size_t)ncol * 2,
+                                         (size_t)ncol * 2, d.src_rows, hipMemcpyHostToDevice));
+        }
+        d.loaded = true;
+    }
+    return 0;
+}
+
+extern "C" int f5_mark_weights_loaded(f5_engine* e) {
+    F5_REQUIRE(e, "null argument");
+    for (auto& kv : e->tmap)
+        for (auto& d : kv.second) d.loaded = true;
+    return 0;
+}
+
+extern "C" int f5_finalize_weights(f5_engine* e, void* stream) {
+    F5_REQUIRE(e && e->arena, "arena not set");
+    for (auto& kv : e->tmap)
+        for (auto& d : kv.second) F5_REQUIRE(d.loaded, "tensor '%s' was never loaded", kv.first.c_str());
+    int rc = f5_launch_text_pos_table((float*)(e->arena + e->text_pos), e->cfg.text_max_pos, e->cfg.text_dim, (hipStream_t)stream);
+    if (rc) return rc;
+    F5_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    e->finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace plan
+// ------------------------------------------------------------------------------------------------
+static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int steps, int method) {
+    const f5_config& c = e->cfg;
+    const int D = c.dim, Dt = c.text_dim, FF = c.ff_dim, TF = c.text_ff_dim, L = c.depth, np = e->np, mel = c.mel_dim;
+    const size_t M1 = (size_t)B * N, M2 = 2 * M1;
+    const int nfe = (steps - 1) * nfe_per_step(method);
+    const int npad = (N + 63) / 64 * 64;
+    Bump b;
+    Workspace w;
+    w.lens = b.take((size_t)B * 4);
+    w.dur2 = b.take((size_t)2 * B * 4);
+    w.text = b.take((size_t)B * (nt > 0 ? nt : 1) * 4);
+    w.ids = b.take(M2 * 4);
+    w.keep = b.take(M2);
+    w.rowkeep = b.take(M2);
+    w.tgrid = b.take((size_t)(nfe > 0 ? nfe : 1) * 4);
+    w.dt = b.take((size_t)steps * 4);
+    w.sinus = b.take((size_t)(nfe + 1) * c.freq_embed_dim * 4);
+    w.th = b.take((size_t)(nfe + 1) * D * 4);
+    w.temb = b.take((size_t)(nfe + 1) * D * 4);
+    w.mod = b.take((size_t)(nfe + 1) * (6 * L + 2) * D * 4);
+    w.rope_cos = b.take((size_t)N * 32 * 4);
+    w.rope_sin = b.take((size_t)N * 32 * 4);
+    w.cond = b.take(M1 * mel * 4);
+    w.traj = b.take((size_t)steps * M1 * mel * 4);
+    w.ytmp = b.take(M1 * mel * 4);
+    w.kst = b.take(3 * M1 * mel * 4);
+    w.vel = b.take(M2 * mel * 4);
+    for (int p = 0; p < 2; ++p) w.xin[p] = p < np ? b.take(M1 * 128 * 2) : 0;
+    w.te[0] = b.take(M2 * Dt * 4);
+    w.te[1] = b.take(M2 * Dt * 4);
+    w.tg = b.take(M2 * TF * 4);
+    w.grn_partial = b.take(f5_grn_partial_floats(2 * B, N, TF) * 4);
+    w.grn_nx = b.take((size_t)2 * B * TF * 4);
+    for (int p = 0; p < 2; ++p) {
+        w.tln[p] = p < np ? b.take(M2 * Dt * 2) : 0;
+        w.tg2[p] = p < np ? b.take(M2 * TF * 2) : 0;
+        w.ct[p] = p < np ? b.take(M2 * (128 + Dt) * 2) : 0;
+    }
+    w.hc = b.take(M2 * D * 4);
+    w.x = b.take(M2 * D * 4);
+    w.vt_bytes = (size_t)2 * B * c.heads * 64 * npad * 2;
+    for (int p = 0; p < 2; ++p) {
+        w.xb[p] = p < np ? b.take(M2 * D * 2) : 0;
+        w.c1[p] = p < np ? b.take(M2 * D * 2) : 0;
+        w.h[p] = p < np ? b.take(M2 * D * 2) : 0;
+        w.qk[p] = p < np ? b.take(M2 * 2 * D * 2) : 0;
+        w.vt[p] = p < np ? b.take(w.vt_bytes) : 0;
+        w.ao[p] = p < np ? b.take(M2 * D * 2) : 0;
+        w.ffh[p] = p < np ? b.take(M2 * FF * 2) : 0;
+    }
+    w.total = b.off;
+    return w;
+}
+
+extern "C" int f5_workspace_bytes(f5_engine* e, int B, int N, int nt, int steps, int method, size_t* bytes) {
+    F5_REQUIRE(e && bytes, "null argument");
+    F5_REQUIRE(B >= 1 && N >= 1 && steps >= 1, "bad sizes B=%d N=%d steps=%d", B, N, steps);
+    F5_REQUIRE(method >= F5_EULER && method <= F5_RK4, "Unknown method: %d", method);
+    *bytes = plan_workspace(e, B, N, nt, steps, method).total;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch context
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+    f5_engine* e;
+    Workspace w;
+    char* ws;
+    hipStream_t s;
+    int B, N, nt, nb;   // nb = branches evaluated per function evaluation (1 or 2)
+    int npad;
+    bool use_mask;
+    template <typename T>
+    T* p(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+    template <typename T>
+    T* a(size_t off) const { return reinterpret_cast<T*>(e->arena + off); }
+    bf16_t* pb(const size_t (&offs)[2], int part) const {
+        return (part < e->np) ? reinterpret_cast<bf16_t*>(ws + offs[part]) : nullptr;
+    }
+    const bf16_t* wm(const MatBF& m, int part) const {
+        if (part == 0) return reinterpret_cast<const bf16_t*>(e->arena + m.hi);
+        return e->np == 2 ? reinterpret_cast<const bf16_t*>(e->arena + m.lo) : nullptr;
+    }
+    int nseg() const { return e->np == 2 ? 3 : 1; }
+};
+
+#define RC(expr)            \
+    do {                    \
+        int _rc = (expr);   \
+        if (_rc) return _rc; \
+    } while (0)
+
+static F5GemmArgs gemm_base(const Ctx& c, const bf16_t* a_hi, const bf16_t* a_lo, int lda, const MatBF& w, int M, int N, int K,
+                            const float* bias) {
+    F5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = a_hi;
+    g.A[1] = a_lo;
+    g.W[0] = c.wm(w, 0);
+    g.W[1] = c.wm(w, 1);
+    g.lda = lda;
+    g.ldw = w.ld;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.nseg = c.nseg();
+    g.bias = bias;
+    return g;
+}
+
+// loop-invariant preparation: time/adaLN tables, text path, hoisted input projection, masks, rope
+static int run_prep(const Ctx& c, int nfe) {
+    const f5_engine* e = c.e;
+    const f5_config& cf = e->cfg;
+    const Workspace& w = c.w;
+    const int D = cf.dim, Dt = cf.text_dim, TF = cf.text_ff_dim, L = cf.depth;
+    const int M1 = c.B * c.N, M2 = 2 * M1;
+    hipStream_t s = c.s;
+
+    // --- t-only tables (dit.py:61-82, 267, 286)
+    if (nfe > 0) {
+        RC(f5_launch_time_sinus(c.p<float>(w.tgrid), c.p<float>(w.sinus), nfe, cf.freq_embed_dim, s));
+        RC(f5_launch_skinny_gemm(c.p<float>(w.sinus), c.a<float>(e->time_w0), c.a<float>(e->time_b0), c.p<float>(w.th), nfe, D,
+                                 cf.freq_embed_dim, 0, 1, s));
+        RC(f5_launch_skinny_gemm(c.p<float>(w.th), c.a<float>(e->time_w2), c.a<float>(e->time_b2), c.p<float>(w.temb), nfe, D, D,
+                                 0, 0, s));
+        RC(f5_launch_skinny_gemm(c.p<float>(w.temb), c.a<float>(e->ada_w), c.a<float>(e->ada_b), c.p<float>(w.mod), nfe,
+                                 (6 * L + 2) * D, D, 1, 0, s));
+    }
+    RC(f5_launch_rope_table(c.p<float>(w.rope_cos), c.p<float>(w.rope_sin), c.N, cf.dim_head, s));
+    RC(f5_launch_rowkeep(c.p<int>(w.dur2), c.p<uint8_t>(w.rowkeep), 2 * c.B, c.N, s));
+    for (int p = 0; p < e->np; ++p) F5_HIP_CHECK(hipMemsetAsync(c.ws + w.vt[p], 0, w.vt_bytes, s));
+
+    // --- text path for both branches (dit.py:196-229, convnext_v2.py:46-54)
+    RC(f5_launch_text_embed(c.p<int>(w.text), c.nt, c.a<float>(e->text_table), c.a<float>(e->text_pos), cf.text_max_pos,
+                            c.p<float>(w.te[0]), c.p<int>(w.ids), c.p<uint8_t>(w.keep), c.B, c.N, Dt, s));
+    int cur = 0;
+    for (int i = 0; i < cf.conv_layers; ++i) {
+        const TextBlockW& t = e->tblocks[i];
+        RC(f5_launch_dwconv_ln(c.p<float>(w.te[cur]), c.a<float>(t.dw_w), c.a<float>(t.dw_b), c.a<float>(t.ln_w),
+                               c.a<float>(t.ln_b), c.pb(w.tln, 0), c.pb(w.tln, 1), 2 * c.B, c.N, Dt, 1e-6f, s));
+        F5GemmArgs g1 = gemm_base(c, c.pb(w.tln, 0), c.pb(w.tln, 1), Dt, t.pw1, M2, TF, Dt, c.a<float>(t.b1));
+        g1.out_f32 = c.p<float>(w.tg);
+        g1.ldo = TF;
+        RC(f5_launch_gemm(g1, EPI_GELU_ERF, s));
+        RC(f5_launch_grn(c.p<float>(w.tg), c.a<float>(t.gamma), c.a<float>(t.beta), c.p<float>(w.grn_partial),
+                         c.p<float>(w.grn_nx), c.pb(w.tg2, 0), c.pb(w.tg2, 1), 2 * c.B, c.N, TF, s));
+        F5GemmArgs g2 = gemm_base(c, c.pb(w.tg2, 0), c.pb(w.tg2, 1), TF, t.pw2, M2, Dt, TF, c.a<float>(t.b2));
+        g2.out_f32 = c.p<float>(w.te[cur ^ 1]);
+        g2.ldo = Dt;
+        g2.resid = c.p<float>(w.te[cur]);
+        g2.ldres = Dt;
+        g2.rowkeep = c.p<uint8_t>(w.keep);
+        RC(f5_launch_gemm(g2, EPI_RESID_KEEP, s));
+        cur ^= 1;
+    }
+    // --- hoisted part of the input projection: Hc = [cond | text] * Wct^T + b   (dit.py:249-250)
+    RC(f5_launch_pack_cond_text(c.p<float>(w.cond), c.p<int>(w.lens), c.p<float>(w.te[cur]), c.pb(w.ct, 0), c.pb(w.ct, 1), c.B,
+                                c.N, cf.mel_dim, Dt, s));
+    F5GemmArgs gh = gemm_base(c, c.pb(w.ct, 0), c.pb(w.ct, 1), 128 + Dt, e->wct, M2, D, 128 + Dt, c.a<float>(e->bproj));
+    gh.out_f32 = c.p<float>(w.hc);
+    gh.ldo = D;
+    RC(f5_launch_gemm(gh, EPI_F32, s));
+    return 0;
+}
+
+// one batched (cond + null) DiT forward; input = xin (bf16 padded state), modulation row `j`
+static int run_dit(const Ctx& c, int j) {
+    const f5_engine* e = c.e;
+    const f5_config& cf = e->cfg;
+    const Workspace& w = c.w;
+    const int D = cf.dim, FF = cf.ff_dim, L = cf.depth, H = cf.heads;
+    const int M1 = c.B * c.N, M = c.nb * M1;
+    hipStream_t s = c.s;
+    const float* mod = c.p<float>(w.mod) + (size_t)j * (6 * L + 2) * D;
+    const uint8_t* rowkeep = c.use_mask ? c.p<uint8_t>(w.rowkeep) : nullptr;
+    const int* kvlen = c.use_mask ? c.p<int>(w.dur2) : nullptr;
+
+    // x = Wx * x_t + Hc  (dit.py:250), both branches share x_t
+    F5GemmArgs g0 = gemm_base(c, c.pb(w.xin, 0), c.pb(w.xin, 1), 128, e->wx, M, D, 128, nullptr);
+    g0.a_row_mod = M1;
+    g0.addrows = c.p<float>(w.hc);
+    g0.ldadd = D;
+    g0.out_f32 = c.p<float>(w.x);
+    g0.ldo = D;
+    g0.out_bf[0] = c.pb(w.xb, 0);
+    g0.out_bf[1] = c.pb(w.xb, 1);
+    g0.ldob = D;
+    RC(f5_launch_gemm(g0, EPI_ADDROWS, s));
+
+    // x += conv_pos_embed(x)  (dit.py:251)
+    F5ConvPosArgs cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.B = c.nb * c.B;
+    cp.seq_len = c.N;
+    cp.C = D;
+    cp.groups = cf.conv_pos_groups;
+    cp.taps = cf.conv_pos_kernel;
+    cp.ld = D;
+    cp.ldo = D;
+    cp.nseg = c.nseg();
+    cp.in[0] = c.pb(w.xb, 0);
+    cp.in[1] = c.pb(w.xb, 1);
+    cp.W[0] = c.wm(e->conv_w[0], 0);
+    cp.W[1] = c.wm(e->conv_w[0], 1);
+    cp.bias = c.a<float>(e->conv_b[0]);
+    cp.mode = 0;
+    cp.out_bf[0] = c.pb(w.c1, 0);
+    cp.out_bf[1] = c.pb(w.c1, 1);
+    RC(f5_launch_convpos(cp, s));
+    cp.in[0] = c.pb(w.c1, 0);
+    cp.in[1] = c.pb(w.c1, 1);
+    cp.W[0] = c.wm(e->conv_w[1], 0);
+    cp.W[1] = c.wm(e->conv_w[1], 1);
+    cp.bias = c.a<float>(e->conv_b[1]);
+    cp.mode = 1;
+    cp.out_bf[0] = cp.out_bf[1] = nullptr;
+    cp.out_f32 = c.p<float>(w.x);
+    RC(f5_launch_convpos(cp, s));
+
+    for (int i = 0; i < L; ++i) {
+        const BlockW& bw = e->blocks[i];
+        const float* m6 = mod + (size_t)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        RC(f5_launch_ln_modulate(c.p<float>(w.x), m6 + D, m6, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+        F5GemmArgs gq = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.qkv, M, 3 * D, D, c.a<float>(bw.bqkv));
+        gq.out_bf[0] = c.pb(w.qk, 0);
+        gq.out_bf[1] = c.pb(w.qk, 1);
+        gq.ldob = 2 * D;
+        gq.rope_cos = c.p<float>(w.rope_cos);
+        gq.rope_sin = c.p<float>(w.rope_sin);
+        gq.seq_len = c.N;
+        gq.npad = c.npad;
+        gq.heads = H;
+        gq.dmodel = D;
+        gq.vt[0] = c.pb(w.vt, 0);
+        gq.vt[1] = c.pb(w.vt, 1);
+        RC(f5_launch_gemm(gq, EPI_QKV_ROPE, s));
+
+        F5AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        for (int p = 0; p < 2; ++p) {
+            at.qk[p] = c.pb(w.qk, p);
+            at.vt[p] = c.pb(w.vt, p);
+            at.out[p] = c.pb(w.ao, p);
+        }
+        at.kv_len = kvlen;
+        at.B = c.nb * c.B;
+        at.H = H;
+        at.seq_len = c.N;
+        at.npad = c.npad;
+        at.ldqk = 2 * D;
+        at.ldo = D;
+        at.dmodel = D;
+        at.hp = e->np == 2;
+        at.scale = 1.0f / sqrtf((float)cf.dim_head);
+        RC(f5_launch_attention(at, s));
+
+        F5GemmArgs go = gemm_base(c, c.pb(w.ao, 0), c.pb(w.ao, 1), D, bw.o, M, D, D, c.a<float>(bw.bo));
+        go.out_f32 = c.p<float>(w.x);
+        go.ldo = D;
+        go.gate = m6 + 2 * D;
+        go.rowkeep = rowkeep;
+        RC(f5_launch_gemm(go, EPI_RESID_GATE, s));
+
+        RC(f5_launch_ln_modulate(c.p<float>(w.x), m6 + 4 * D, m6 + 3 * D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+        F5GemmArgs g1 = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.ff1, M, FF, D, c.a<float>(bw.bff1));
+        g1.out_bf[0] = c.pb(w.ffh, 0);
+        g1.out_bf[1] = c.pb(w.ffh, 1);
+        g1.ldob = FF;
+        RC(f5_launch_gemm(g1, EPI_GELU_TANH, s));
+        F5GemmArgs g2 = gemm_base(c, c.pb(w.ffh, 0), c.pb(w.ffh, 1), FF, bw.ff2, M, D, FF, c.a<float>(bw.bff2));
+        g2.out_f32 = c.p<float>(w.x);
+        g2.ldo = D;
+        g2.gate = m6 + 5 * D;
+        RC(f5_launch_gemm(g2, EPI_RESID_GATE, s));
+    }
+    const float* mf = mod + (size_t)L * 6 * D;  // (scale, shift) order, dit.py:287
+    RC(f5_launch_ln_modulate(c.p<float>(w.x), mf, mf + D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+    F5GemmArgs gf = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, e->wout, M, cf.mel_dim, D, c.a<float>(e->bout));
+    gf.out_f32 = c.p<float>(w.vel);
+    gf.ldo = cf.mel_dim;
+    RC(f5_launch_gemm(gf, EPI_F32, s));
+    return 0;
+}
+
+static int run_sample_body(const Ctx& c, const f5_sample_args* a) {
+    const f5_config& cf = c.e->cfg;
+    const Workspace& w = c.w;
+    const int mel = cf.mel_dim;
+    const size_t M1 = (size_t)c.B * c.N;
+    const int per = nfe_per_step(a->method);
+    const int nfe = (a->steps - 1) * per;
+    hipStream_t s = c.s;
+    RC(run_prep(c, nfe));
+    float* traj = c.p<float>(w.traj);
+    RC(f5_launch_pack_x(traj, c.pb(w.xin, 0), c.pb(w.xin, 1), (int)M1, mel, s));
+    const float* pred = c.p<float>(w.vel);
+    const float* nullp = c.nb == 2 ? pred + M1 * mel : nullptr;
+    float* kst = c.p<float>(w.kst);
+    float* ytmp = c.p<float>(w.ytmp);
+    for (int i = 0; i + 1 < a->steps; ++i) {
+        float* y = traj + (size_t)i * M1 * mel;
+        float* ynext = traj + (size_t)(i + 1) * M1 * mel;
+        F5OdeArgs o;
+        memset(&o, 0, sizeof(o));
+        o.pred = pred;
+        o.null_pred = nullp;
+        o.cfg = a->cfg_strength;
+        o.base = y;
+        o.dt_ptr = c.p<float>(w.dt) + i;
+        o.divisor = 1.0f;
+        o.rows = (int)M1;
+        o.mel_dim = mel;
+        o.xin_hi = c.pb(w.xin, 0);
+        o.xin_lo = c.pb(w.xin, 1);
+        if (a->method == F5_EULER) {
+            RC(run_dit(c, i));
+            o.coef = 1.0f;
+            o.out = ynext;
+            RC(f5_launch_ode_stage(o, s));
+        } else if (a->method == F5_MIDPOINT) {
+            RC(run_dit(c, 2 * i));
+            o.coef = 0.5f;
+            o.out = ytmp;
+            RC(f5_launch_ode_stage(o, s));
+            RC(run_dit(c, 2 * i + 1));
+            o.coef = 1.0f;
+            o.out = ynext;
+            RC(f5_launch_ode_stage(o, s));
+        } else {
+            RC(run_dit(c, 4 * i));
+            o.coef = 0.5f;
+            o.out = ytmp;
+            o.kstore = kst;
+            RC(f5_launch_ode_stage(o, s));
+            RC(run_dit(c, 4 * i + 1));
+            o.kstore = kst + M1 * mel;
+            RC(f5_launch_ode_stage(o, s));
+            RC(run_dit(c, 4 * i + 2));
+            o.coef = 1.0f;
+            o.kstore = kst + 2 * M1 * mel;
+            RC(f5_launch_ode_stage(o, s));
+            RC(run_dit(c, 4 * i + 3));
+            o.kstore = nullptr;
+            o.mode = 1;
+            o.divisor = 6.0f;
+            o.k1 = kst;
+            o.k2 = kst + M1 * mel;
+            o.k3 = kst + 2 * M1 * mel;
+            o.out = ynext;
+            RC(f5_launch_ode_stage(o, s));
+        }
+    }
+    return 0;
+}
+
+static int check_args(const f5_engine* e, const f5_sample_args* a) {
+    F5_REQUIRE(e && a, "null argument");
+    F5_REQUIRE(e->finalized, "weights are not finalized");
+    F5_REQUIRE(a->B >= 1 && a->N >= 1 && a->nt >= 1 && a->steps >= 1, "bad sizes B=%d N=%d nt=%d steps=%d", a->B, a->N, a->nt,
+               a->steps);
+    F5_REQUIRE(a->method >= F5_EULER && a->method <= F5_RK4, "Unknown method: %d", a->method);
+    F5_REQUIRE(a->text && a->cond && a->lens && a->durations && a->workspace, "null pointer in f5_sample_args");
+    F5_REQUIRE(((uintptr_t)a->workspace & 255) == 0, "workspace must be 256-byte aligned");
+    for (int b = 0; b < a->B; ++b) {
+        F5_REQUIRE(a->durations[b] >= 1 && a->durations[b] <= a->N, "durations[%d]=%d out of range [1,%d]", b, a->durations[b],
+                   a->N);
+        F5_REQUIRE(a->lens[b] >= 0 && a->lens[b] <= a->N, "lens[%d]=%d out of range", b, a->lens[b]);
+    }
+    return 0;
+}
+
+// stage the call's inputs into the workspace (outside any graph: source pointers are caller owned)
+static int stage_inputs(Ctx& c, const f5_sample_args* a, const float* x_override, const std::vector<float>& tnfe,
+                        const std::vector<float>& dts) {
+    const Workspace& w = c.w;
+    const size_t M1 = (size_t)c.B * c.N;
+    const int mel = c.e->cfg.mel_dim;
+    hipStream_t s = c.s;
+    std::vector<int> dur2(2 * c.B);
+    for (int b = 0; b < c.B; ++b) dur2[b] = dur2[c.B + b] = a->durations[b];
+    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.lens, a->lens, (size_t)c.B * 4, hipMemcpyHostToDevice, s));
+    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.dur2, dur2.data(), (size_t)2 * c.B * 4, hipMemcpyHostToDevice, s));
+    if (!tnfe.empty()) F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.tgrid, tnfe.data(), tnfe.size() * 4, hipMemcpyHostToDevice, s));
+    if (!dts.empty()) F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.dt, dts.data(), dts.size() * 4, hipMemcpyHostToDevice, s));
+    F5_HIP_CHECK(hipStreamSynchronize(s));  // host staging vectors die at scope exit
+    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.text, a->text, (size_t)c.B * c.nt * 4, hipMemcpyDeviceToDevice, s));
+    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.cond, a->cond, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
+    const float* x0 = x_override ? x_override : a->y0;
+    F5_REQUIRE(x0 != nullptr, "initial state (y0) is null");
+    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.traj, x0, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+static Ctx make_ctx(f5_engine* e, const f5_sample_args* a, hipStream_t s) {
+    Ctx c;
+    c.e = e;
+    c.w = plan_workspace(e, a->B, a->N, a->nt, a->steps, a->method);
+    c.ws = (char*)a->workspace;
+    c.s = s;
+    c.B = a->B;
+    c.N = a->N;
+    c.nt = a->nt;
+    c.nb = a->cfg_strength < 1e-5f ? 1 : 2;
+    c.npad = (a->N + 63) / 64 * 64;
+    c.use_mask = a->use_mask != 0;
+    return c;
+}
+
+extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
+    RC(check_args(e, a));
+    F5_REQUIRE(a->y0 && a->t && a->out, "null pointer in f5_sample_args (y0/t/out)");
+    hipStream_t s = (hipStream_t)stream;
+    Ctx c = make_ctx(e, a, s);
+    F5_REQUIRE(a->workspace_bytes >= c.w.total, "workspace too small: %zu < %zu", a->workspace_bytes, c.w.total);
+    const int mel = e->cfg.mel_dim;
+    const size_t M1 = (size_t)c.B * c.N;
+
+    // function-evaluation times and step sizes in fp32, as the solvers compute them (cfm.py:50-56,76-86,106-114)
+    std::vector<float> tnfe, dts;
+    for (int i = 0; i + 1 < a->steps; ++i) {
+        const float t0 = a->t[i];
+        const float dt = a->t[i + 1] - t0;
+        dts.push_back(dt);
+        if (a->method == F5_EULER) {
+            tnfe.push_back(t0);
+        } else if (a->method == F5_MIDPOINT) {
+            tnfe.push_back(t0);
+            tnfe.push_back(t0 + 0.5f * dt);
+        } else {
+            tnfe.push_back(t0);
+            tnfe.push_back(t0 + 0.5f * dt);
+            tnfe.push_back(t0 + 0.5f * dt);
+            tnfe.push_back(t0 + dt);
+        }
+    }
+    RC(stage_inputs(c, a, nullptr, tnfe, dts));
+
+    if (a->use_graph) {
+        char key[256];
+        snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+                 (int)c.use_mask, a->workspace);
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : e->graphs)
+            if (g.key == key) exec = g.exec;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            F5_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int rc = run_sample_body(c, a);
+            const hipError_t ec = hipStreamEndCapture(s, &graph);
+            if (rc) {
+                if (graph) hipGraphDestroy(graph);
+                return rc;
+            }
+            F5_HIP_CHECK(ec);
+            F5_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+            e->graphs.push_back({key, exec});
+        }
+        F5_HIP_CHECK(hipGraphLaunch(exec, s));
+    } else {
+        RC(run_sample_body(c, a));
+    }
+    const float* ylast = c.p<float>(c.w.traj) + (size_t)(a->steps - 1) * M1 * mel;
+    RC(f5_launch_splice(c.p<float>(c.w.cond), ylast, c.p<int>(c.w.lens), a->out, c.B, c.N, mel, s));
+    if (a->trajectory)
+        F5_HIP_CHECK(hipMemcpyAsync(a->trajectory, c.ws + c.w.traj, (size_t)a->steps * M1 * mel * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float* x, float t, float* pred, float* null_pred,
+                              void* stream) {
+    RC(check_args(e, a));
+    F5_REQUIRE(x && pred, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    f5_sample_args a2 = *a;
+    a2.steps = 2;
+    a2.method = F5_EULER;
+    Ctx c = make_ctx(e, &a2, s);
+    F5_REQUIRE(a->workspace_bytes >= c.w.total, "workspace too small: %zu < %zu", a->workspace_bytes, c.w.total);
+    const int mel = e->cfg.mel_dim;
+    const size_t M1 = (size_t)c.B * c.N;
+    std::vector<float> tnfe(1, t), dts(1, 0.0f);
+    RC(stage_inputs(c, &a2, x, tnfe, dts));
+    RC(run_prep(c, 1));
+    RC(f5_launch_pack_x(c.p<float>(c.w.traj), c.pb(c.w.xin, 0), c.pb(c.w.xin, 1), (int)M1, mel, s));
+    RC(run_dit(c, 0));
+    F5_HIP_CHECK(hipMemcpyAsync(pred, c.ws + c.w.vel, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
+    if (null_pred && c.nb == 2)
+        F5_HIP_CHECK(hipMemcpyAsync(null_pred, c.ws + c.w.vel + M1 * mel * 4, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-op entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                          float* out_f32, void* out_bf_hi, void* out_bf_lo, int M, int N, int K, int lda, int ldw, int ldo,
+                          int nseg, int epi, void* stream) {
+    F5_REQUIRE(epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU_TANH || epi == EPI_GELU_ERF,
+               "f5_op_gemm supports epilogues 0-3 only");
+    F5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = (const bf16_t*)a_hi;
+    g.A[1] = (const bf16_t*)a_lo;
+    g.W[0] = (const bf16_t*)w_hi;
+    g.W[1] = (const bf16_t*)w_lo;
+    g.lda = lda;
+    g.ldw = ldw;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.nseg = nseg;
+    g.bias = bias;
+    g.out_f32 = out_f32;
+    g.ldo = ldo;
+    g.out_bf[0] = (bf16_t*)out_bf_hi;
+    g.out_bf[1] = (bf16_t*)out_bf_lo;
+    g.ldob = ldo;
+    return f5_launch_gemm(g, epi, (hipStream_t)stream);
+}
+
+extern "C" int f5_op_attention(const void* qk_hi, const void* qk_lo, const void* vt_hi, const void* vt_lo, void* out_hi,
+                               void* out_lo, const int32_t* kv_len, int B, int H, int seq_len, int npad, int dmodel, float scale,
+                               int hp, void* stream) {
+    F5AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.qk[0] = (const bf16_t*)qk_hi;
+    at.qk[1] = (const bf16_t*)qk_lo;
+    at.vt[0] = (const bf16_t*)vt_hi;
+    at.vt[1] = (const bf16_t*)vt_lo;
+    at.out[0] = (bf16_t*)out_hi;
+    at.out[1] = (bf16_t*)out_lo;
+    at.kv_len = kv_len;
+    at.B = B;
+    at.H = H;
+    at.seq_len = seq_len;
+    at.npad = npad;
+    at.ldqk = 2 * dmodel;
+    at.ldo = dmodel;
+    at.dmodel = dmodel;
+    at.hp = hp;
+    at.scale = scale;
+    return f5_launch_attention(at, (hipStream_t)stream);
+}
+
+extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                              const float* rope_cos, const float* rope_sin, void* qk_hi, void* qk_lo, void* vt_hi, void* vt_lo,
+                              int B, int seq_len, int npad, int heads, int dmodel, int nseg, void* stream) {
+    F5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = (const bf16_t*)a_hi;
+    g.A[1] = (const bf16_t*)a_lo;
+    g.W[0] = (const bf16_t*)w_hi;
+    g.W[1] = (const bf16_t*)w_lo;
+    g.lda = dmodel;
+    g.ldw = dmodel;
+    g.M = B * seq_len;
+    g.N = 3 * dmodel;
+    g.K = dmodel;
+    g.nseg = nseg;
+    g.bias = bias;
+    g.out_bf[0] = (bf16_t*)qk_hi;
+    g.out_bf[1] = (bf16_t*)qk_lo;
+    g.ldob = 2 * dmodel;
+    g.rope_cos = rope_cos;
+    g.rope_sin = rope_sin;
+    g.seq_len = seq_len;
+    g.npad = npad;
+    g.heads = heads;
+    g.dmodel = dmodel;
+    g.vt[0] = (bf16_t*)vt_hi;
+    g.vt[1] = (bf16_t*)vt_lo;
+    return f5_launch_gemm(g, EPI_QKV_ROPE, (hipStream_t)stream);
+}
+
+extern "C" int f5_op_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, void* stream) {
+    return f5_launch_rope_table(cos_t, sin_t, seq_len, dim_head, (hipStream_t)stream);
+}
+
+extern "C" int f5_op_convpos(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias,
+                             void* out_hi, void* out_lo, float* out_f32, int B, int seq_len, int C, int groups, int taps,
+                             int nseg, int mode, void* stream) {
+    F5ConvPosArgs cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.in[0] = (const bf16_t*)in_hi;
+    cp.in[1] = (const bf16_t*)in_lo;
+    cp.W[0] = (const bf16_t*)w_hi;
+    cp.W[1] = (const bf16_t*)w_lo;
+    cp.bias = bias;
+    cp.B = B;
+    cp.seq_len = seq_len;
+    cp.C = C;
+    cp.groups = groups;
+    cp.taps = taps;
+    cp.ld = C;
+    cp.ldo = C;
+    cp.nseg = nseg;
+    cp.mode = mode;
+    cp.out_bf[0] = (bf16_t*)out_hi;
+    cp.out_bf[1] = (bf16_t*)out_lo;
+    cp.out_f32 = out_f32;
+    return f5_launch_convpos(cp, (hipStream_t)stream);
+}
+
+extern "C" int f5_op_ln_modulate(const float* x, const float* scale, const float* shift, void* out_hi, void* out_lo, int rows,
+                                 int dim, void* stream) {
+    return f5_launch_ln_modulate(x, scale, shift, (bf16_t*)out_hi, (bf16_t*)out_lo, rows, dim, 1e-6f, (hipStream_t)stream);
+}
+
+extern "C" int f5_op_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                               void* out_hi, void* out_lo, int nbatch, int seq_len, int dim, void* stream) {
+    return f5_launch_dwconv_ln(x, dw_w, dw_b, ln_w, ln_b, (bf16_t*)out_hi, (bf16_t*)out_lo, nbatch, seq_len, dim, 1e-6f,
+                               (hipStream_t)stream);
+}
+
+extern "C" size_t f5_op_grn_scratch_floats(int nbatch, int seq_len, int dim) {
+    return f5_grn_partial_floats(nbatch, seq_len, dim) + (size_t)nbatch * dim;
+}
+extern "C" int f5_op_grn(const float* g, const float* gamma, const float* beta, float* scratch, void* out_hi, void* out_lo,
+                         int nbatch, int seq_len, int dim, void* stream) {
+    float* nx = scratch + f5_grn_partial_floats(nbatch, seq_len, dim);
+    return f5_launch_grn(g, gamma, beta, scratch, nx, (bf16_t*)out_hi, (bf16_t*)out_lo, nbatch, seq_len, dim, (hipStream_t)stream);
+}
+
+extern "C" int f5_op_text_embed(const int32_t* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
+                                int32_t* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, void* stream) {
+    return f5_launch_text_embed(text, nt, table, pos_table, max_pos, out, ids_out, keep_out, B, seq_len, dim, (hipStream_t)stream);
+}
+extern "C" int f5_op_text_pos_table(float* table, int max_pos, int dim, void* stream) {
+    return f5_launch_text_pos_table(table, max_pos, dim, (hipStream_t)stream);
+}
+extern "C" int f5_op_time_sinus(const float* t, float* out, int n, int dim, void* stream) {
+    return f5_launch_time_sinus(t, out, n, dim, (hipStream_t)stream);
+}
+extern "C" int f5_op_skinny_gemm(const float* a, const float* w, const float* b, float* out, int M, int N, int K, int silu_in,
+                                 int silu_out, void* stream) {
+    return f5_launch_skinny_gemm(a, w, b, out, M, N, K, silu_in, silu_out, (hipStream_t)stream);
+}
+extern "C" int f5_op_cfg_axpy(const float* pred, const float* null_pred, float cfg, const float* base, const float* dt_dev,
+                              float coef, float divisor, float* out, void* xin_hi, void* xin_lo, int rows, int mel_dim,
+                              void* stream) {
+    F5OdeArgs o;
+    memset(&o, 0, sizeof(o));
+    o.pred = pred;
+    o.null_pred = null_pred;
+    o.cfg = cfg;
+    o.base = base;
+    o.dt_ptr = dt_dev;
+    o.coef = coef;
+    o.divisor = divisor;
+    o.out = out;
+    o.xin_hi = (bf16_t*)xin_hi;
+    o.xin_lo = (bf16_t*)xin_lo;
+    o.rows = rows;
+    o.mel_dim = mel_dim;
+    return f5_launch_ode_stage(o, (hipStream_t)stream);
+}

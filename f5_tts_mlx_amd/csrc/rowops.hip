@@ -1,0 +1,471 @@
+// HBM-bound row / elementwise kernels of the F5-TTS sampling path (gfx950, wave64).
+// Everything here is fp32 arithmetic; bf16 only appears as the (hi, lo) operand encoding handed to
+// the MFMA kernels.  Loads/stores are 16 B per lane wherever the layout allows it.
+#include "rowops.hpp"
+
+// =================================================================================================
+// LayerNorm (no affine) + adaLN modulation: one wave per row, NV float4 per lane (dim = NV*256)
+// =================================================================================================
+template <int NV>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, bf16_t* __restrict__ out_hi,
+                                                          bf16_t* __restrict__ out_lo, int rows, float eps) {
+    constexpr int DIM = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * DIM;
+    f32x4 v[NV];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = f5_wave_sum(sum) * (1.0f / DIM);
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            sq += d * d;
+        }
+    const float var = f5_wave_sum(sq) * (1.0f / DIM);
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
+        *reinterpret_cast<u32x2*>(out_hi + (size_t)row * DIM + c) = u32x2{f5_pack2(y[0], y[1]), f5_pack2(y[2], y[3])};
+        if (out_lo)
+            *reinterpret_cast<u32x2*>(out_lo + (size_t)row * DIM + c) =
+                u32x2{f5_pack2_lo(y[0], y[1]), f5_pack2_lo(y[2], y[3])};
+    }
+}
+
+int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, bf16_t* out_hi, bf16_t* out_lo,
+                          int rows, int dim, float eps, hipStream_t s) {
+    F5_REQUIRE(dim % 256 == 0 && dim >= 256 && dim <= 1024, "ln_modulate: dim must be 256/512/768/1024 (got %d)", dim);
+    const dim3 grid(f5_cdiv(rows, 4)), block(256);
+    switch (dim / 256) {
+        case 1: hipLaunchKernelGGL((ln_modulate_kernel<1>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps); break;
+        case 2: hipLaunchKernelGGL((ln_modulate_kernel<2>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps); break;
+        case 3: hipLaunchKernelGGL((ln_modulate_kernel<3>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps); break;
+        default: hipLaunchKernelGGL((ln_modulate_kernel<4>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps); break;
+    }
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// depthwise conv (k=7, pad=3, per batch element zero padding) + bias + LayerNorm(affine)
+// one wave per token; lane owns dim/64 channels as float4 chunks (dim = NV*256)
+// =================================================================================================
+template <int NV>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
+                                                        const float* __restrict__ dw_b, const float* __restrict__ ln_w,
+                                                        const float* __restrict__ ln_b, bf16_t* __restrict__ out_hi,
+                                                        bf16_t* __restrict__ out_lo, int rows, int seq_len, float eps) {
+    constexpr int DIM = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / seq_len, n = row - b * seq_len;
+    float y[NV][4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[i][e] = dw_b[c + e];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int nn = n + t - 3;
+            if (nn >= 0 && nn < seq_len) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((size_t)b * seq_len + nn) * DIM + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[i][e] += xv[e] * dw_w[(c + e) * 7 + t];
+            }
+        }
+        sum += (y[i][0] + y[i][1]) + (y[i][2] + y[i][3]);
+    }
+    const float mean = f5_wave_sum(sum) * (1.0f / DIM);
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = y[i][e] - mean;
+            sq += d * d;
+        }
+    const float rstd = rsqrtf(f5_wave_sum(sq) * (1.0f / DIM) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        float z[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = (y[i][e] - mean) * rstd * ln_w[c + e] + ln_b[c + e];
+        *reinterpret_cast<u32x2*>(out_hi + (size_t)row * DIM + c) = u32x2{f5_pack2(z[0], z[1]), f5_pack2(z[2], z[3])};
+        if (out_lo)
+            *reinterpret_cast<u32x2*>(out_lo + (size_t)row * DIM + c) =
+                u32x2{f5_pack2_lo(z[0], z[1]), f5_pack2_lo(z[2], z[3])};
+    }
+}
+
+int f5_launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                        bf16_t* out_hi, bf16_t* out_lo, int nbatch, int seq_len, int dim, float eps, hipStream_t s) {
+    F5_REQUIRE(dim % 256 == 0 && dim >= 256 && dim <= 1024, "dwconv_ln: dim must be 256/512/768/1024 (got %d)", dim);
+    const int rows = nbatch * seq_len;
+    const dim3 grid(f5_cdiv(rows, 4)), block(256);
+#define DW_ARGS x, dw_w, dw_b, ln_w, ln_b, out_hi, out_lo, rows, seq_len, eps
+    switch (dim / 256) {
+        case 1: hipLaunchKernelGGL((dwconv_ln_kernel<1>), grid, block, 0, s, DW_ARGS); break;
+        case 2: hipLaunchKernelGGL((dwconv_ln_kernel<2>), grid, block, 0, s, DW_ARGS); break;
+        case 3: hipLaunchKernelGGL((dwconv_ln_kernel<3>), grid, block, 0, s, DW_ARGS); break;
+        default: hipLaunchKernelGGL((dwconv_ln_kernel<4>), grid, block, 0, s, DW_ARGS); break;
+    }
+#undef DW_ARGS
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// GRN: Gx[b][c] = ||g[b,:,c]||_2 over the sequence; Nx = Gx / (mean_c Gx + 1e-6);
+//      out = gamma * (g * Nx) + beta + g.   Deterministic: per-chunk partial sums, fixed-order finish.
+// =================================================================================================
+#define GRN_CHUNK 32
+size_t f5_grn_partial_floats(int nbatch, int seq_len, int dim) {
+    return (size_t)nbatch * f5_cdiv(seq_len, GRN_CHUNK) * dim;
+}
+
+__global__ __launch_bounds__(256) void grn_partial_kernel(const float* __restrict__ g, float* __restrict__ partial,
+                                                          int seq_len, int dim, int nchunk) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y, b = blockIdx.z;
+    if (c >= dim) return;
+    const int n0 = ch * GRN_CHUNK;
+    const int n1 = min(n0 + GRN_CHUNK, seq_len);
+    float acc = 0.0f;
+    for (int n = n0; n < n1; ++n) {
+        const float v = g[((size_t)b * seq_len + n) * dim + c];
+        acc += v * v;
+    }
+    partial[((size_t)b * nchunk + ch) * dim + c] = acc;
+}
+
+// one block per batch element: Gx (fixed summation order) -> mean over channels -> Nx
+__global__ __launch_bounds__(256) void grn_finish_kernel(const float* __restrict__ partial, float* __restrict__ nx, int dim,
+                                                         int nchunk) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float local = 0.0f;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        float ss = 0.0f;
+        for (int ch = 0; ch < nchunk; ++ch) ss += partial[((size_t)b * nchunk + ch) * dim + c];
+        const float gx = sqrtf(ss);
+        nx[(size_t)b * dim + c] = gx;
+        local += gx;
+    }
+    local = f5_wave_sum(local);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)dim;
+    const float inv = 1.0f / (mean + 1e-6f);
+    for (int c = threadIdx.x; c < dim; c += 256) nx[(size_t)b * dim + c] *= inv;
+}
+
+__global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict__ g, const float* __restrict__ nx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int seq_len,
+                                                        int dim, size_t total4) {
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= total4) return;
+    const size_t idx = i4 * 4;
+    const int c = (int)(idx % dim);
+    const size_t row = idx / dim;
+    const int b = (int)(row / seq_len);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + idx);
+    const f32x4 nv = *reinterpret_cast<const f32x4*>(nx + (size_t)b * dim + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = ga[e] * (gv[e] * nv[e]) + be[e] + gv[e];
+    *reinterpret_cast<u32x2*>(out_hi + idx) = u32x2{f5_pack2(y[0], y[1]), f5_pack2(y[2], y[3])};
+    if (out_lo) *reinterpret_cast<u32x2*>(out_lo + idx) = u32x2{f5_pack2_lo(y[0], y[1]), f5_pack2_lo(y[2], y[3])};
+}
+
+int f5_launch_grn(const float* g, const float* gamma, const float* beta, float* partial, float* nx, bf16_t* out_hi,
+                  bf16_t* out_lo, int nbatch, int seq_len, int dim, hipStream_t s) {
+    F5_REQUIRE(dim % 4 == 0, "grn: dim must be a multiple of 4");
+    const int nchunk = f5_cdiv(seq_len, GRN_CHUNK);
+    hipLaunchKernelGGL(grn_partial_kernel, dim3(f5_cdiv(dim, 256), nchunk, nbatch), dim3(256), 0, s, g, partial, seq_len, dim,
+                       nchunk);
+    hipLaunchKernelGGL(grn_finish_kernel, dim3(nbatch), dim3(256), 0, s, partial, nx, dim, nchunk);
+    const size_t total4 = (size_t)nbatch * seq_len * dim / 4;
+    hipLaunchKernelGGL(grn_apply_kernel, dim3(f5_cdiv((long)total4, 256)), dim3(256), 0, s, g, nx, gamma, beta, out_hi, out_lo,
+                       seq_len, dim, total4);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// TextEmbedding index path + gather.  out layout [2 branches][B][seq][dim]; ids_out [2][B][seq];
+// keep_out [2][B][seq] (1 where the ORIGINAL id != 0, i.e. not filler; same for both branches) -- bit exact.
+// =================================================================================================
+__global__ __launch_bounds__(128) void text_embed_kernel(const int* __restrict__ text, int nt, const float* __restrict__ table,
+                                                         const float* __restrict__ pos_table, int max_pos,
+                                                         float* __restrict__ out, int* __restrict__ ids_out,
+                                                         uint8_t* __restrict__ keep_out, int B, int seq_len, int dim) {
+    const int n = blockIdx.x, b = blockIdx.y, br = blockIdx.z;
+    int id = 0;
+    if (n < nt) id = text[(size_t)b * nt + n] + 1;   // text + 1, curtailed to seq_len, right-padded with 0
+    const bool keep = id != 0;                        // text_mask = (text == 0), taken BEFORE the drop
+    const int emb_id = (br == 1) ? 0 : id;            // drop_text -> all-zero ids
+    const int pos = n < max_pos ? n : max_pos - 1;
+    if (threadIdx.x == 0) {
+        ids_out[((size_t)br * B + b) * seq_len + n] = emb_id;
+        keep_out[((size_t)br * B + b) * seq_len + n] = keep ? 1 : 0;
+    }
+    float* o = out + (((size_t)br * B + b) * seq_len + n) * dim;
+    for (int c = threadIdx.x * 4; c < dim; c += 128 * 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (keep) {
+            const f32x4 e = *reinterpret_cast<const f32x4*>(table + (size_t)emb_id * dim + c);
+            const f32x4 pe = *reinterpret_cast<const f32x4*>(pos_table + (size_t)pos * dim + c);
+            v = e + pe;
+        }
+        *reinterpret_cast<f32x4*>(o + c) = v;
+    }
+}
+
+int f5_launch_text_embed(const int* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
+                         int* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, hipStream_t s) {
+    F5_REQUIRE(dim % 4 == 0, "text_embed: dim must be a multiple of 4");
+    hipLaunchKernelGGL(text_embed_kernel, dim3(seq_len, B, 2), dim3(128), 0, s, text, nt, table, pos_table, max_pos, out,
+                       ids_out, keep_out, B, seq_len, dim);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// A operand of the hoisted input projection: rows [2][B*seq], cols [cond padded to 128 | text dt]
+// branch 0: cond masked by n < lens[b] (step_cond, cfm.py:331); branch 1: cond dropped (dit.py:249)
+// =================================================================================================
+__global__ __launch_bounds__(256) void pack_cond_text_kernel(const float* __restrict__ cond, const int* __restrict__ lens,
+                                                             const float* __restrict__ text_emb, bf16_t* __restrict__ out_hi,
+                                                             bf16_t* __restrict__ out_lo, int B, int seq_len, int mel_dim,
+                                                             int dt) {
+    const int n = blockIdx.x, b = blockIdx.y, br = blockIdx.z;
+    const int ld = 128 + dt;
+    const size_t orow = (((size_t)br * B + b) * seq_len + n) * ld;
+    const bool use_cond = (br == 0) && (n < lens[b]);
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        float v = 0.0f;
+        if (c < 128) {
+            if (use_cond && c < mel_dim) v = cond[((size_t)b * seq_len + n) * mel_dim + c];
+        } else {
+            v = text_emb[(((size_t)br * B + b) * seq_len + n) * dt + (c - 128)];
+        }
+        bf16_t h, l;
+        f5_split(v, h, l);
+        out_hi[orow + c] = h;
+        if (out_lo) out_lo[orow + c] = l;
+    }
+}
+
+int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, bf16_t* out_hi, bf16_t* out_lo,
+                             int B, int seq_len, int mel_dim, int dt, hipStream_t s) {
+    F5_REQUIRE(mel_dim <= 128, "pack_cond_text: mel_dim must be <= 128");
+    hipLaunchKernelGGL(pack_cond_text_kernel, dim3(seq_len, B, 2), dim3(256), 0, s, cond, lens, text_emb, out_hi, out_lo, B,
+                       seq_len, mel_dim, dt);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// time embedding pieces
+// =================================================================================================
+__global__ void time_sinus_kernel(const float* __restrict__ t, float* __restrict__ out, int n, int dim) {
+    const int i = blockIdx.x;
+    const int half = dim / 2;
+    const float step = logf(10000.0f) / (float)(half - 1);
+    for (int j = threadIdx.x; j < half; j += blockDim.x) {
+        const float e = expf((float)j * -step);
+        const float a = (1000.0f * t[i]) * e;
+        out[(size_t)i * dim + j] = sinf(a);
+        out[(size_t)i * dim + half + j] = cosf(a);
+    }
+}
+int f5_launch_time_sinus(const float* t, float* out, int n, int dim, hipStream_t s) {
+    hipLaunchKernelGGL(time_sinus_kernel, dim3(n), dim3(128), 0, s, t, out, n, dim);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// one wave per output column; K % 256 == 0; a is small and L2 resident
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int M, int N,
+                                                          int K, int silu_in, int silu_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int kc = K >> 8;  // float4 chunks per lane (<= 4)
+    f32x4 wv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < kc) wv[i] = *reinterpret_cast<const f32x4*>(w + (size_t)n * K + i * 256 + lane * 4);
+    const float bn = bias ? bias[n] : 0.0f;
+    for (int m = 0; m < M; ++m) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < kc) {
+                f32x4 av = *reinterpret_cast<const f32x4*>(a + (size_t)m * K + i * 256 + lane * 4);
+                if (silu_in) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = f5_silu(av[e]);
+                }
+                acc += (av[0] * wv[i][0] + av[1] * wv[i][1]) + (av[2] * wv[i][2] + av[3] * wv[i][3]);
+            }
+        acc = f5_wave_sum(acc);
+        if (lane == 0) {
+            float r = acc + bn;
+            if (silu_out) r = f5_silu(r);
+            out[(size_t)m * N + n] = r;
+        }
+    }
+}
+int f5_launch_skinny_gemm(const float* a, const float* w, const float* b, float* out, int M, int N, int K, int silu_in,
+                          int silu_out, hipStream_t s) {
+    F5_REQUIRE(K % 256 == 0 && K <= 1024, "skinny_gemm: K must be a multiple of 256 and <= 1024 (got %d)", K);
+    hipLaunchKernelGGL(skinny_gemm_kernel, dim3(f5_cdiv(N, 4)), dim3(256), 0, s, a, w, b, out, M, N, K, silu_in, silu_out);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// positional tables
+// =================================================================================================
+__global__ void rope_table_kernel(float* __restrict__ cos_t, float* __restrict__ sin_t, int seq_len, int dim_head) {
+    const int n = blockIdx.x;
+    const int half = dim_head / 2;
+    for (int j = threadIdx.x; j < half; j += blockDim.x) {
+        const float inv = 1.0f / powf(10000.0f, (float)(2 * j) / (float)dim_head);  // rope.py:23
+        const float a = (float)n * inv;                                              // fp32 product, rope.py:45
+        cos_t[(size_t)n * half + j] = cosf(a);
+        sin_t[(size_t)n * half + j] = sinf(a);
+    }
+}
+int f5_launch_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, hipStream_t s) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3(seq_len), dim3(64), 0, s, cos_t, sin_t, seq_len, dim_head);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void text_pos_table_kernel(float* __restrict__ table, int max_pos, int dim) {
+    const int n = blockIdx.x;
+    const int half = dim / 2;
+    for (int j = threadIdx.x; j < half; j += blockDim.x) {
+        const float f = 1.0f / powf(10000.0f, (float)(2 * j) / (float)dim);  // rope.py:66-68
+        const float a = (float)n * f;                                        // rope.py:70
+        table[(size_t)n * dim + j] = cosf(a);                                // [cos | sin], rope.py:71-73
+        table[(size_t)n * dim + half + j] = sinf(a);
+    }
+}
+int f5_launch_text_pos_table(float* table, int max_pos, int dim, hipStream_t s) {
+    hipLaunchKernelGGL(text_pos_table_kernel, dim3(max_pos), dim3(256), 0, s, table, max_pos, dim);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// ODE state plumbing
+// =================================================================================================
+__global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ y, bf16_t* __restrict__ out_hi,
+                                                     bf16_t* __restrict__ out_lo, int rows, int mel_dim) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * 128) return;
+    const size_t row = i >> 7;
+    const int c = (int)(i & 127);
+    const float v = (c < mel_dim) ? y[row * mel_dim + c] : 0.0f;
+    bf16_t h, l;
+    f5_split(v, h, l);
+    out_hi[i] = h;
+    if (out_lo) out_lo[i] = l;
+}
+int f5_launch_pack_x(const float* y, bf16_t* out_hi, bf16_t* out_lo, int rows, int mel_dim, hipStream_t s) {
+    hipLaunchKernelGGL(pack_x_kernel, dim3(f5_cdiv((long)rows * 128, 256)), dim3(256), 0, s, y, out_hi, out_lo, rows, mel_dim);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void ode_stage_kernel(F5OdeArgs p) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over rows * 128 (padded columns)
+    if (i >= (size_t)p.rows * 128) return;
+    const size_t row = i >> 7;
+    const int c = (int)(i & 127);
+    float o = 0.0f;
+    if (c < p.mel_dim) {
+        const size_t idx = row * p.mel_dim + c;
+        const float pr = p.pred[idx];
+        float k = pr;
+        if (p.null_pred) k = pr + (pr - p.null_pred[idx]) * p.cfg;     // cfm.py:364
+        if (p.kstore) p.kstore[idx] = k;
+        const float a = (p.coef * p.dt_ptr[0]) / p.divisor;
+        float upd = k;
+        if (p.mode == 1) upd = ((p.k1[idx] + 2.0f * p.k2[idx]) + 2.0f * p.k3[idx]) + k;  // cfm.py:117
+        o = p.base[idx] + a * upd;
+        p.out[idx] = o;
+    }
+    if (p.xin_hi) {
+        bf16_t h, l;
+        f5_split(o, h, l);
+        p.xin_hi[i] = h;
+        if (p.xin_lo) p.xin_lo[i] = l;
+    }
+}
+int f5_launch_ode_stage(const F5OdeArgs& a, hipStream_t s) {
+    F5_REQUIRE(a.mel_dim <= 128, "ode_stage: mel_dim must be <= 128");
+    hipLaunchKernelGGL(ode_stage_kernel, dim3(f5_cdiv((long)a.rows * 128, 256)), dim3(256), 0, s, a);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void splice_kernel(const float* __restrict__ cond, const float* __restrict__ y,
+                                                     const int* __restrict__ lens, float* __restrict__ out, int seq_len,
+                                                     int mel_dim, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t row = i / mel_dim;
+    const int b = (int)(row / seq_len);
+    const int n = (int)(row - (size_t)b * seq_len);
+    out[i] = (n < lens[b]) ? cond[i] : y[i];
+}
+int f5_launch_splice(const float* cond, const float* y, const int* lens, float* out, int B, int seq_len, int mel_dim,
+                     hipStream_t s) {
+    const size_t total = (size_t)B * seq_len * mel_dim;
+    hipLaunchKernelGGL(splice_kernel, dim3(f5_cdiv((long)total, 256)), dim3(256), 0, s, cond, y, lens, out, seq_len, mel_dim,
+                       total);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void rowkeep_kernel(const int* __restrict__ dur, uint8_t* __restrict__ keep, int seq_len, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / seq_len);
+    const int n = (int)(i - (size_t)b * seq_len);
+    keep[i] = n < dur[b] ? 1 : 0;
+}
+int f5_launch_rowkeep(const int* dur, uint8_t* keep, int nbatch, int seq_len, hipStream_t s) {
+    const size_t total = (size_t)nbatch * seq_len;
+    hipLaunchKernelGGL(rowkeep_kernel, dim3(f5_cdiv((long)total, 256)), dim3(256), 0, s, dur, keep, seq_len, total);
+    F5_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,69 @@
+// HBM-bound row / elementwise kernels of the sampling path (declarations).
+#pragma once
+#include "common.hpp"
+
+// y = LN(x) * (1 + scale) + shift, LN without affine, eps (dit.py:270,289,321). One wave per row.
+int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, bf16_t* out_hi, bf16_t* out_lo,
+                          int rows, int dim, float eps, hipStream_t s);
+
+// ConvNeXtV2 front half (convnext_v2.py:46-48): depthwise Conv1d(k=7,pad=3)+bias -> LayerNorm(affine).
+int f5_launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                        bf16_t* out_hi, bf16_t* out_lo, int nbatch, int seq_len, int dim, float eps, hipStream_t s);
+
+// GRN (convnext_v2.py:15-18) over the SEQUENCE axis: three deterministic passes.
+int f5_launch_grn(const float* g, const float* gamma, const float* beta, float* partial, float* nx, bf16_t* out_hi,
+                  bf16_t* out_lo, int nbatch, int seq_len, int dim, hipStream_t s);
+size_t f5_grn_partial_floats(int nbatch, int seq_len, int dim);
+
+// TextEmbedding index path + gather (dit.py:196-222): ids (+1, pad 0, mask, drop) -> emb + pos.
+int f5_launch_text_embed(const int* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
+                         int* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, hipStream_t s);
+
+// pack A operand of the hoisted input projection: [cond(128, zero padded) | text_embed(dt)] for both branches
+int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, bf16_t* out_hi, bf16_t* out_lo,
+                             int B, int seq_len, int mel_dim, int dt, hipStream_t s);
+
+// sinusoidal time embedding (dit.py:61-67)
+int f5_launch_time_sinus(const float* t, float* out, int n, int dim, hipStream_t s);
+
+// out[m][n] = act_out(sum_k act_in(a[m][k]) * w[n][k] + b[n]) in fp32 for small M (time MLP, adaLN tables)
+int f5_launch_skinny_gemm(const float* a, const float* w, const float* b, float* out, int M, int N, int K, int silu_in,
+                          int silu_out, hipStream_t s);
+
+// rotary cos/sin table [seq_len][dim_head/2] (rope.py:38-60) and text positional table (rope.py:63-73)
+int f5_launch_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, hipStream_t s);
+int f5_launch_text_pos_table(float* table, int max_pos, int dim, hipStream_t s);
+
+// y (fp32 [rows][mel]) -> bf16 [rows][128] zero padded (A operand of the per-step x projection)
+int f5_launch_pack_x(const float* y, bf16_t* out_hi, bf16_t* out_lo, int rows, int mel_dim, hipStream_t s);
+
+// CFG combine + ODE stage (cfm.py:38-122, :364).  k = pred + (pred - null) * cfg  (pred only when !has_null)
+//   mode 0: out = base + a * k                         (optionally k -> kstore)
+//   mode 1: out = base + a * (k1 + 2*k2 + 2*k3 + k)    (RK4 final)
+// also writes the bf16 padded copy of `out` (next DiT input) when xin_hi != null.
+struct F5OdeArgs {
+    const float* pred;
+    const float* null_pred;  // may be null
+    float cfg;
+    const float* base;
+    const float* dt_ptr;     // device scalar dt of this step
+    float coef;
+    float divisor;           // a = (coef * dt) / divisor
+    int mode;
+    float* kstore;
+    const float* k1;
+    const float* k2;
+    const float* k3;
+    float* out;
+    bf16_t* xin_hi;
+    bf16_t* xin_lo;
+    int rows, mel_dim;
+};
+int f5_launch_ode_stage(const F5OdeArgs& a, hipStream_t s);
+
+// out = where(n < lens[b], cond, y)  (cfm.py:395-397)
+int f5_launch_splice(const float* cond, const float* y, const int* lens, float* out, int B, int seq_len, int mel_dim,
+                     hipStream_t s);
+
+// rowkeep[b*seq+n] = n < dur[b]  for 2 branches ([nb][seq])
+int f5_launch_rowkeep(const int* dur, uint8_t* keep, int nbatch, int seq_len, hipStream_t s);

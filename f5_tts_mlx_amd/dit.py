@@ -1,0 +1,75 @@
+"""DiT backbone handle (reference: f5_tts_mlx/dit.py:331-401).
+
+The reference `DiT` is an nn.Module tree evaluated op by op; here it is a configuration + weight set
+bound to one HIP `Engine`.  `DiT.__call__` keeps the reference signature for single forwards (tests,
+diagnostics); `F5TTS.sample` drives the whole ODE solve through `Engine.sample` instead of calling
+the model 2 x NFE times from Python.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .engine import Engine
+from .weights import DiTConfig
+
+
+class DiT:
+    def __init__(self, *, dim, depth=8, heads=8, dim_head=64, dropout=0.0, ff_mult=4, mel_dim=100, text_num_embeds=256,
+                 text_dim=None, text_mask_padding=True, conv_layers=0, precision: str = "bf16",
+                 device: str | torch.device = "cuda:0"):
+        if text_dim is None:
+            text_dim = mel_dim
+        if not text_mask_padding:
+            raise NotImplementedError("text_mask_padding=False is not used by the sampling path (cfm.py:468)")
+        if dropout != 0.0:
+            raise NotImplementedError("dropout is training-only")
+        if conv_layers <= 0:
+            raise NotImplementedError("the engine implements the ConvNeXt text path (conv_layers > 0, cfm.py:466)")
+        self.cfg = DiTConfig(dim=dim, depth=depth, heads=heads, dim_head=dim_head, ff_mult=ff_mult, mel_dim=mel_dim,
+                             text_num_embeds=text_num_embeds, text_dim=text_dim, conv_layers=conv_layers,
+                             conv_pos_groups=dim // 64)
+        self.dim = dim
+        self.depth = depth
+        self.precision = precision
+        self.device = torch.device(device)
+        self._engine: Optional[Engine] = None
+
+    @classmethod
+    def from_config(cls, cfg: DiTConfig, precision="bf16", device="cuda:0") -> "DiT":
+        m = cls(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, dim_head=cfg.dim_head, ff_mult=cfg.ff_mult, mel_dim=cfg.mel_dim,
+                text_num_embeds=cfg.text_num_embeds, text_dim=cfg.text_dim, conv_layers=cfg.conv_layers, precision=precision,
+                device=device)
+        m.cfg = cfg
+        return m
+
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            self._engine = Engine(self.cfg, precision=self.precision, device=self.device)
+        return self._engine
+
+    def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        """weights: reference (MLX-layout) names -> fp32 arrays (weights.param_specs)."""
+        self.engine.load_weights({k: np.asarray(v) for k, v in weights.items()})
+
+    def __call__(self, x, cond, text, time, drop_audio_cond, drop_text, mask=None) -> torch.Tensor:
+        """dit.py:374-401 — one forward.  Only the two flag combinations the sampler uses exist in the
+        engine: (False, False) = conditional, (True, True) = null branch."""
+        if bool(drop_audio_cond) != bool(drop_text):
+            raise NotImplementedError("engine evaluates (drop_audio_cond, drop_text) = (False, False) or (True, True)")
+        B, N, _ = x.shape
+        x = x.to(self.device, torch.float32).contiguous()
+        cond = cond.to(self.device, torch.float32).contiguous()
+        text = text.to(self.device, torch.int32).contiguous()
+        t = float(time if not torch.is_tensor(time) else time.reshape(-1)[0])
+        if mask is not None:
+            durations = mask.sum(dim=-1).to(torch.int32).tolist()
+        else:
+            durations = [N] * B
+        # `cond` arrives already masked (step_cond), so the conditioning length is the full sequence
+        pred, null = self.engine.dit_forward(x, text, cond, [N] * B, durations, t, cfg_strength=2.0,
+                                             use_mask=mask is not None)
+        return null if drop_text else pred

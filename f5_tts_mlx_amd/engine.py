@@ -1,0 +1,227 @@
+"""ctypes binding of the C-ABI library (include/f5tts_hip.h) + a thin Engine object.
+
+PyTorch is used for device memory, streams and torch.distributed only; every FLOP of the sampling
+path runs in the hand-written HIP kernels of `csrc/`.  There is NO fallback: if the shared library
+is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .weights import DiTConfig, check_weights
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libf5tts_hip.so"
+_lib = None
+
+METHODS = {"euler": 0, "midpoint": 1, "rk4": 2}
+PRECISIONS = {"bf16": 0, "bf16x3": 1}
+
+
+class F5Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dim", "depth", "heads", "dim_head", "ff_dim", "mel_dim", "text_num_embeds", "text_dim", "text_ff_dim",
+        "conv_layers", "conv_pos_kernel", "conv_pos_groups", "freq_embed_dim", "text_max_pos")]
+
+
+class F5SampleArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("N", C.c_int32), ("nt", C.c_int32),
+        ("text", C.c_void_p), ("cond", C.c_void_p), ("lens", C.c_void_p), ("durations", C.c_void_p),
+        ("y0", C.c_void_p), ("t", C.c_void_p),
+        ("steps", C.c_int32), ("method", C.c_int32), ("cfg_strength", C.c_float),
+        ("use_mask", C.c_int32), ("use_graph", C.c_int32),
+        ("out", C.c_void_p), ("trajectory", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """Load libf5tts_hip.so (built by `__graft_entry__.build()` / csrc/build.sh). Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RuntimeError(
+            f"HIP extension not built: {_LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or f5_tts_mlx_amd/csrc/build.sh). There is no CPU fallback.")
+    lib = C.CDLL(str(_LIB_PATH))
+    lib.f5_last_error.restype = C.c_char_p
+    lib.f5_version.restype = C.c_int
+    lib.f5_op_grn_scratch_floats.restype = C.c_size_t
+    lib.f5_engine_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load_library().f5_last_error().decode("utf-8", "replace")
+        if msg.startswith("Unknown method"):
+            raise ValueError(msg)
+        raise RuntimeError(f"{what or 'f5 call'} failed (rc={rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_ptr(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def to_c_config(cfg: DiTConfig) -> F5Config:
+    return F5Config(cfg.dim, cfg.depth, cfg.heads, cfg.dim_head, cfg.ff_dim, cfg.mel_dim, cfg.text_num_embeds, cfg.text_dim,
+                    cfg.text_ff_dim, cfg.conv_layers, cfg.conv_pos_kernel, cfg.conv_pos_groups, cfg.freq_embed_dim,
+                    cfg.text_max_pos)
+
+
+def _aligned_bytes(nbytes: int, device: torch.device) -> torch.Tensor:
+    """uint8 device buffer, 256-byte aligned (torch's caching allocator aligns to 512 B)."""
+    t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+    off = (-t.data_ptr()) % 256
+    return t[off:off + int(nbytes)]
+
+
+class Engine:
+    """One engine handle per device.  Not re-entrant (same contract as the C ABI)."""
+
+    def __init__(self, cfg: DiTConfig, precision: str = "bf16", device: str | torch.device = "cuda:0"):
+        if precision not in PRECISIONS:
+            raise ValueError(f"unknown precision {precision!r}; expected one of {sorted(PRECISIONS)}")
+        self.lib = load_library()
+        self.cfg = cfg
+        self.precision = precision
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the HIP engine needs a GPU device (cuda:N); there is no CPU path")
+        torch.cuda.set_device(self.device)
+        self._h = C.c_void_p()
+        ccfg = to_c_config(cfg)
+        check(self.lib.f5_engine_create(C.byref(ccfg), PRECISIONS[precision], C.byref(self._h)), "f5_engine_create")
+        nbytes = C.c_size_t()
+        check(self.lib.f5_weights_bytes(self._h, C.byref(nbytes)), "f5_weights_bytes")
+        self.arena = _aligned_bytes(nbytes.value, self.device)
+        check(self.lib.f5_set_weights_arena(self._h, ptr(self.arena), C.c_size_t(self.arena.numel()), stream_ptr(self.device)),
+              "f5_set_weights_arena")
+        self._workspace: Optional[torch.Tensor] = None
+        self.weights_ready = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.lib.f5_engine_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------
+    def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        """Upload reference-named fp32 tensors (weights.param_specs) into the arena."""
+        check_weights(self.cfg, weights)
+        for name, arr in weights.items():
+            if name == "transformer.rotary_embed.inv_freq":
+                continue
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            check(self.lib.f5_load_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.ndim, shape),
+                  f"f5_load_tensor({name})")
+        self.finalize()
+
+    def finalize(self) -> None:
+        check(self.lib.f5_finalize_weights(self._h, stream_ptr(self.device)), "f5_finalize_weights")
+        self.weights_ready = True
+
+    def mark_loaded_from_broadcast(self) -> None:
+        """Arena content arrived by a collective (dist.broadcast_weights) instead of load_weights."""
+        check(self.lib.f5_mark_weights_loaded(self._h), "f5_mark_weights_loaded")
+        self.finalize()
+
+    # ---- workspace -------------------------------------------------------------------------
+    def workspace(self, B: int, N: int, nt: int, steps: int, method: str) -> torch.Tensor:
+        if method not in METHODS:
+            raise ValueError(f"Unknown method: {method}")
+        nbytes = C.c_size_t()
+        check(self.lib.f5_workspace_bytes(self._h, B, N, nt, steps, METHODS[method], C.byref(nbytes)), "f5_workspace_bytes")
+        if self._workspace is None or self._workspace.numel() < nbytes.value:
+            self._workspace = None
+            self._workspace = _aligned_bytes(nbytes.value, self.device)
+        return self._workspace
+
+    # ---- hot path --------------------------------------------------------------------------
+    def _args(self, text, cond, lens, durations, y0, t, steps, method, cfg_strength, use_mask, use_graph, out, traj, ws):
+        B, N, _ = cond.shape
+        keep = dict(lens=np.ascontiguousarray(lens, dtype=np.int32), dur=np.ascontiguousarray(durations, dtype=np.int32),
+                    t=np.ascontiguousarray(t, dtype=np.float32))
+        a = F5SampleArgs()
+        a.B, a.N, a.nt = B, N, text.shape[1]
+        a.text, a.cond = text.data_ptr(), cond.data_ptr()
+        a.lens, a.durations = keep["lens"].ctypes.data, keep["dur"].ctypes.data
+        a.y0 = 0 if y0 is None else y0.data_ptr()
+        a.t = keep["t"].ctypes.data
+        a.steps, a.method, a.cfg_strength = steps, METHODS[method], float(cfg_strength)
+        a.use_mask, a.use_graph = int(use_mask), int(use_graph)
+        a.out = 0 if out is None else out.data_ptr()
+        a.trajectory = 0 if traj is None else traj.data_ptr()
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        return a, keep
+
+    def _check_inputs(self, text, cond, lens, durations):
+        assert cond.is_cuda and cond.dtype == torch.float32 and cond.is_contiguous() and cond.ndim == 3
+        assert cond.shape[2] == self.cfg.mel_dim
+        assert text.is_cuda and text.dtype == torch.int32 and text.is_contiguous() and text.ndim == 2
+        assert text.shape[0] == cond.shape[0]
+        assert len(lens) == cond.shape[0] and len(durations) == cond.shape[0]
+        if not self.weights_ready:
+            raise RuntimeError("weights not loaded")
+
+    def sample(self, text: torch.Tensor, cond: torch.Tensor, lens: Sequence[int], durations: Sequence[int], y0: torch.Tensor,
+               t: np.ndarray, method: str = "euler", cfg_strength: float = 2.0, use_mask: Optional[bool] = None,
+               use_graph: bool = True, return_trajectory: bool = True, out: Optional[torch.Tensor] = None,
+               trajectory: Optional[torch.Tensor] = None):
+        """ODE solve on the GPU. cond (B,N,mel) fp32 zero-padded to N=max(durations); text (B,nt) int32
+        (-1 padded); y0 (B,N,mel).  Returns (out (B,N,mel), trajectory (steps,B,N,mel) or None)."""
+        if method not in METHODS:
+            raise ValueError(f"Unknown method: {method}")
+        self._check_inputs(text, cond, lens, durations)
+        B, N, mel = cond.shape
+        steps = int(len(t))
+        assert y0.shape == cond.shape and y0.dtype == torch.float32 and y0.is_contiguous() and y0.is_cuda
+        if use_mask is None:
+            use_mask = B > 1                       # cfm.py:333-336
+        ws = self.workspace(B, N, text.shape[1], steps, method)
+        if out is None:
+            out = torch.empty_like(cond)
+        if return_trajectory and trajectory is None:
+            trajectory = torch.empty((steps, B, N, mel), dtype=torch.float32, device=self.device)
+        a, keep = self._args(text, cond, lens, durations, y0, t, steps, method, cfg_strength, use_mask, use_graph, out,
+                             trajectory if return_trajectory else None, ws)
+        check(self.lib.f5_sample(self._h, C.byref(a), stream_ptr(self.device)), "f5_sample")
+        del keep
+        return out, (trajectory if return_trajectory else None)
+
+    def dit_forward(self, x: torch.Tensor, text: torch.Tensor, cond: torch.Tensor, lens, durations, t: float,
+                    cfg_strength: float = 2.0, use_mask: Optional[bool] = None):
+        """One DiT evaluation (cond branch and, when cfg_strength >= 1e-5, null branch)."""
+        self._check_inputs(text, cond, lens, durations)
+        B, N, mel = cond.shape
+        if use_mask is None:
+            use_mask = B > 1
+        ws = self.workspace(B, N, text.shape[1], 2, "euler")
+        pred = torch.empty_like(cond)
+        null = torch.empty_like(cond) if cfg_strength >= 1e-5 else None
+        a, keep = self._args(text, cond, lens, durations, None, np.zeros(2, np.float32), 2, "euler", cfg_strength, use_mask,
+                             False, None, None, ws)
+        check(self.lib.f5_dit_forward(self._h, C.byref(a), ptr(x), C.c_float(t), ptr(pred), ptr(null), stream_ptr(self.device)),
+              "f5_dit_forward")
+        del keep
+        return pred, null

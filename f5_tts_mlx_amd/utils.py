@@ -1,0 +1,136 @@
+"""Host utilities on the sampling path (reference: f5_tts_mlx/utils.py).
+
+ein notation: b - batch, n - sequence, nt - text sequence, nw - raw wave length, d - dimension.
+Tensors are torch (CPU for these index paths); semantics follow the reference line by line.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+import torch.nn.functional as F
+
+
+def exists(v):
+    return v is not None
+
+
+def default(v, d):
+    return v if exists(v) else d
+
+
+def divisible_by(num, den):
+    return (num % den) == 0
+
+
+def lens_to_mask(t: torch.Tensor, length: Optional[int] = None) -> torch.Tensor:  # Bool['b n']
+    """utils.py:39-47."""
+    if not exists(length):
+        length = int(t.max().item())
+    seq = torch.arange(length, device=t.device)
+    return seq[None, :] < t[:, None]
+
+
+def pad_to_length(t: torch.Tensor, length: int, value=0) -> torch.Tensor:
+    """utils.py:93-103."""
+    ndim = t.ndim
+    seq_len = t.shape[-1]
+    if length > seq_len:
+        if ndim in (1, 2):
+            t = F.pad(t, (0, length - seq_len), value=value)
+        else:
+            raise ValueError(f"Unsupported padding dims: {ndim}")
+    return t[..., :length]
+
+
+def pad_sequence(t: Sequence[torch.Tensor], padding_value=0) -> torch.Tensor:
+    """utils.py:106-109."""
+    max_len = max([i.shape[-1] for i in t])
+    return torch.stack([pad_to_length(i, max_len, padding_value) for i in t])
+
+
+# simple utf-8 tokenizer, since paper went character based
+
+def list_str_to_tensor(text: List[str], padding_value=-1) -> torch.Tensor:  # Int['b nt']
+    """utils.py:115-118."""
+    list_tensors = [torch.tensor([*bytes(t, "UTF-8")], dtype=torch.int32) for t in text]
+    return pad_sequence(list_tensors, padding_value=-1)
+
+
+# char tokenizer, based on custom dataset's extracted .txt file
+
+def list_str_to_idx(text: List[Union[str, List[str]]], vocab_char_map: Dict[str, int], padding_value=-1) -> torch.Tensor:
+    """utils.py:124-133 — unknown characters map to 0, padding is -1."""
+    list_idx_tensors = [torch.tensor([vocab_char_map.get(c, 0) for c in t], dtype=torch.int32) for t in text]
+    return pad_sequence(list_idx_tensors, padding_value=padding_value)
+
+
+# convert char to pinyin
+
+def convert_char_to_pinyin(text_list: List[str], polyphone: bool = True) -> List[List[str]]:
+    """utils.py:139-173.  The reference segments with jieba and romanises Chinese with pypinyin; neither
+    is installable here, so pure single-byte text takes the reference's own ASCII branch (segmentation
+    does not change the output for such text apart from the word-boundary space rule, reproduced below)
+    and text with multi-byte characters needs the optional dependencies."""
+    final_text_list = []
+    zh_quote_trans = str.maketrans({"“": '"', "”": '"', "‘": "'", "’": "'"})
+    custom_trans = str.maketrans({";": ","})
+    try:  # optional, identical to the reference when available
+        import jieba  # type: ignore
+        from pypinyin import Style, lazy_pinyin  # type: ignore
+        jieba.setLogLevel(20)
+    except Exception:  # pragma: no cover - environment dependent
+        jieba = None
+    for text in text_list:
+        char_list: List[str] = []
+        text = text.translate(zh_quote_trans).translate(custom_trans)
+        if jieba is None:
+            if len(bytes(text, "UTF-8")) != len(text):
+                raise RuntimeError("convert_char_to_pinyin: non single-byte text needs jieba + pypinyin (not installed)")
+            segs = _ascii_segments(text)
+        else:
+            segs = list(jieba.cut(text))
+        for seg in segs:
+            seg_byte_len = len(bytes(seg, "UTF-8"))
+            if seg_byte_len == len(seg):  # pure alphabets and symbols
+                if char_list and seg_byte_len > 1 and char_list[-1] not in " :'\"":
+                    char_list.append(" ")
+                char_list.extend(seg)
+            elif polyphone and seg_byte_len == 3 * len(seg):  # pure chinese characters
+                seg = lazy_pinyin(seg, style=Style.TONE3, tone_sandhi=True)
+                for c in seg:
+                    if c not in "。，、；：？！《》【】—…":
+                        char_list.append(" ")
+                    char_list.append(c)
+            else:  # mixed
+                for c in seg:
+                    if ord(c) < 256:
+                        char_list.extend(c)
+                    else:
+                        if c not in "。，、；：？！《》【】—…":
+                            char_list.append(" ")
+                            char_list.extend(lazy_pinyin(c, style=Style.TONE3, tone_sandhi=True))
+                        else:
+                            char_list.append(c)
+        final_text_list.append(char_list)
+    return final_text_list
+
+
+def _ascii_segments(text: str) -> List[str]:
+    """Segmentation jieba produces for single-byte text: its HMM fallback (`finalseg.re_skip`) keeps
+    alphanumeric runs `[a-zA-Z0-9]+(?:\\.\\d+)?%?` together and yields every other character on its own."""
+    import re
+    return re.findall(r"[a-zA-Z0-9]+(?:\.\d+)?%?|.", text, flags=re.S)
+
+
+def fetch_from_hub(hf_repo: str, quantization_bits: Optional[int] = None):
+    """utils.py:179-192 — local directory or HF snapshot (needs network)."""
+    from pathlib import Path
+    p = Path(hf_repo)
+    if p.exists():
+        return p
+    from huggingface_hub import snapshot_download
+    model_filename = "model_v1.safetensors"
+    if exists(quantization_bits):
+        model_filename = f"model_v1_{quantization_bits}b.safetensors"
+    return Path(snapshot_download(repo_id=hf_repo, allow_patterns=[model_filename, "duration_v2.safetensors", "*.txt"]))

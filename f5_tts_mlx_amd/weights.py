@@ -55,7 +55,7 @@ F5TTS_335M = DiTConfig()  # cfm.py:459-469
 
 # a small config used by the CPU/GPU parity tests (oracle finishes in seconds)
 TINY = DiTConfig(dim=256, depth=2, heads=4, dim_head=64, ff_mult=2, mel_dim=100,
-                 text_num_embeds=64, text_dim=128, conv_layers=2, conv_pos_groups=4)
+                 text_num_embeds=64, text_dim=256, conv_layers=2, conv_pos_groups=4)
 
 
 def param_specs(cfg: DiTConfig) -> List[Tuple[str, Tuple[int, ...], str]]:

@@ -1,0 +1,148 @@
+/*
+ * f5tts_hip.h -- C ABI of the MI355X-native (gfx950) F5-TTS flow-matching sampling engine.
+ *
+ * The reference (lucasnewman/f5-tts-mlx) has no FFI layer: its boundary for this path is the Python
+ * API `F5TTS.sample` (f5_tts_mlx/cfm.py:264-402) -> `DiT.__call__` (f5_tts_mlx/dit.py:374-401) with
+ * MLX arrays.  This header is what a Python/ctypes (or cgo/JNI/...) host binds instead; every entry
+ * point cites the reference code it replaces.  Conventions:
+ *   - plain pointers and sizes only; "dev" pointers are HIP device pointers, "host" pointers are
+ *     ordinary host memory; the caller owns every buffer (weights arena, workspace, inputs, outputs)
+ *   - every function returns 0 on success, non-zero on error; `f5_last_error()` (thread local)
+ *     describes the last failure.  Nothing throws across the ABI.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *     unless stated.  An engine handle is not re-entrant (one handle per device / stream at a time).
+ */
+#ifndef F5TTS_HIP_H
+#define F5TTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct f5_engine f5_engine;
+
+/* Constructor arguments of the reference DiT (dit.py:332-346) + derived sizes. */
+typedef struct f5_config {
+    int32_t dim;             /* 1024 */
+    int32_t depth;           /* 22 */
+    int32_t heads;           /* 16 */
+    int32_t dim_head;        /* 64 (only 64 is supported by the attention kernel) */
+    int32_t ff_dim;          /* dim * ff_mult = 2048 */
+    int32_t mel_dim;         /* 100 */
+    int32_t text_num_embeds; /* 2545 (embedding table has +1 rows, dit.py:184) */
+    int32_t text_dim;        /* 512 */
+    int32_t text_ff_dim;     /* text_dim * conv_mult = 1024 */
+    int32_t conv_layers;     /* 4 */
+    int32_t conv_pos_kernel; /* 31 */
+    int32_t conv_pos_groups; /* 16 (dim / groups must be 64) */
+    int32_t freq_embed_dim;  /* 256 */
+    int32_t text_max_pos;    /* 4096 */
+} f5_config;
+
+enum { F5_PREC_BF16 = 0, F5_PREC_BF16X3 = 1 };           /* MFMA operand encoding */
+enum { F5_EULER = 0, F5_MIDPOINT = 1, F5_RK4 = 2 };       /* cfm.py:38-122 */
+
+const char* f5_last_error(void);
+int f5_version(void);
+
+/* ---- engine lifetime ------------------------------------------------------------------------ */
+int f5_engine_create(const f5_config* cfg, int precision, f5_engine** out);
+void f5_engine_destroy(f5_engine* e);
+
+/* ---- weights: replaces F5TTS.load_weights / from_pretrained upload (cfm.py:475-518) ------------
+ * The caller allocates `f5_weights_bytes` of device memory (one contiguous arena, so that a single
+ * RCCL broadcast replicates the model), hands it over, then loads every tensor by its reference
+ * (MLX-layout) name, e.g. "transformer.transformer_blocks.3.attn.to_q.weight".  host_data is fp32,
+ * C-contiguous, shape as in the reference.  f5_finalize_weights checks completeness and builds the
+ * derived tables (text positional table, rope.py:63-73). */
+int f5_weights_bytes(f5_engine* e, size_t* bytes);
+int f5_set_weights_arena(f5_engine* e, void* dev_arena, size_t bytes, void* stream);
+int f5_load_tensor(f5_engine* e, const char* name, const float* host_data, int ndim, const int64_t* shape);
+int f5_finalize_weights(f5_engine* e, void* stream);
+/* for ranks that received the arena by broadcast instead of f5_load_tensor */
+int f5_mark_weights_loaded(f5_engine* e);
+
+/* ---- F5TTS.sample hot path (cfm.py:312-397) ---------------------------------------------------
+ * The Python wrapper keeps the reference's host logic (text -> ids, lens / duration clamp, time
+ * grid); the engine runs everything from the masks to the final splice on the GPU.             */
+typedef struct f5_sample_args {
+    int32_t B;                 /* utterances                                                     */
+    int32_t N;                 /* max_duration in frames (cfm.py:319)                            */
+    int32_t nt;                /* text columns                                                   */
+    const int32_t* text;       /* dev  [B][nt] token ids, -1 padded (utils.py:124-133)           */
+    const float* cond;         /* dev  [B][N][mel] reference mel, zero padded to N (cfm.py:321)  */
+    const int32_t* lens;       /* host [B] conditioning length per utterance (cfm.py:301-303)    */
+    const int32_t* durations;  /* host [B] total frames per utterance (cfm.py:317-318)           */
+    const float* y0;           /* dev  [B][N][mel] initial noise, zero beyond durations[b]       */
+    const float* t;            /* host [steps] time grid (cfm.py:379-381)                        */
+    int32_t steps;             /* number of grid POINTS                                          */
+    int32_t method;            /* F5_EULER / F5_MIDPOINT / F5_RK4                                */
+    float cfg_strength;        /* < 1e-5 disables the null branch (cfm.py:352)                   */
+    int32_t use_mask;          /* key-padding mask + output row mask; reference: batch > 1       */
+    int32_t use_graph;         /* capture/replay the whole call as one hipGraph                  */
+    float* out;                /* dev  [B][N][mel] where(cond_mask, cond, y_final)               */
+    float* trajectory;         /* dev  [steps][B][N][mel] or NULL                                */
+    void* workspace;           /* dev, f5_workspace_bytes                                        */
+    size_t workspace_bytes;
+} f5_sample_args;
+
+int f5_workspace_bytes(f5_engine* e, int B, int N, int nt, int steps, int method, size_t* bytes);
+int f5_sample(f5_engine* e, const f5_sample_args* args, void* stream);
+
+/* One DiT forward (dit.py:374-401) for tests/diagnostics: same inputs as f5_sample, evaluates the
+ * velocity field at time `t` for state `x` (dev [B][N][mel]); writes pred (and null when
+ * cfg_strength >= 1e-5) as dev [B][N][mel] each. */
+int f5_dit_forward(f5_engine* e, const f5_sample_args* args, const float* x, float t, float* pred, float* null_pred,
+                   void* stream);
+
+/* ---- per-op entry points (exported for the parity tests; all pointers are dev) ------------------ */
+/* C = A * W^T (+epilogue), bf16 MFMA; epi codes in csrc/gemm.hpp (0 = fp32 out + bias, 1 = bf16 out) */
+int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, float* out_f32,
+               void* out_bf_hi, void* out_bf_lo, int M, int N, int K, int lda, int ldw, int ldo, int nseg, int epi,
+               void* stream);
+/* dit.py:136-166: qk [B*n][2*dmodel] (RoPE'd q | k), vt [B*H][64][npad] -> out [B*n][dmodel] */
+int f5_op_attention(const void* qk_hi, const void* qk_lo, const void* vt_hi, const void* vt_lo, void* out_hi, void* out_lo,
+                    const int32_t* kv_len, int B, int H, int seq_len, int npad, int dmodel, float scale, int hp, void* stream);
+/* QKV projection + bias + RoPE + head split (dit.py:136-158) */
+int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                   const float* rope_cos, const float* rope_sin, void* qk_hi, void* qk_lo, void* vt_hi, void* vt_lo, int B,
+                   int seq_len, int npad, int heads, int dmodel, int nseg, void* stream);
+int f5_op_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, void* stream);
+/* dit.py:29-50 one grouped conv + Mish; mode 0 -> bf16 out, mode 1 -> out_f32 += */
+int f5_op_convpos(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias, void* out_hi,
+                  void* out_lo, float* out_f32, int B, int seq_len, int C, int groups, int taps, int nseg, int mode,
+                  void* stream);
+/* dit.py:270 */
+int f5_op_ln_modulate(const float* x, const float* scale, const float* shift, void* out_hi, void* out_lo, int rows, int dim,
+                      void* stream);
+/* convnext_v2.py:46-48 */
+int f5_op_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b, void* out_hi,
+                    void* out_lo, int nbatch, int seq_len, int dim, void* stream);
+/* convnext_v2.py:15-18; scratch: f5_op_grn_scratch_floats floats */
+size_t f5_op_grn_scratch_floats(int nbatch, int seq_len, int dim);
+int f5_op_grn(const float* g, const float* gamma, const float* beta, float* scratch, void* out_hi, void* out_lo, int nbatch,
+              int seq_len, int dim, void* stream);
+/* dit.py:196-222 (index path is bit exact) */
+int f5_op_text_embed(const int32_t* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
+                     int32_t* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, void* stream);
+int f5_op_text_pos_table(float* table, int max_pos, int dim, void* stream);
+/* dit.py:61-82, 267 small fp32 GEMM */
+int f5_op_time_sinus(const float* t, float* out, int n, int dim, void* stream);
+int f5_op_skinny_gemm(const float* a, const float* w, const float* b, float* out, int M, int N, int K, int silu_in,
+                      int silu_out, void* stream);
+/* cfm.py:56,364: out = base + (coef*dt/divisor) * cfg(pred, null) */
+int f5_op_cfg_axpy(const float* pred, const float* null_pred, float cfg, const float* base, const float* dt_dev, float coef,
+                   float divisor, float* out, void* xin_hi, void* xin_lo, int rows, int mel_dim, void* stream);
+
+/* ---- audio (audio.py:115-210; vocoder = vocos_mlx, third party) -------------------------------- */
+/* log-mel spectrogram of one waveform: wave dev [L] fp32 -> out dev [L/256][n_mels] */
+int f5_mel_spectrogram(const float* wave, int64_t L, const float* window, const float* filterbank, int n_fft, int hop,
+                       int n_mels, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F5TTS_HIP_H */

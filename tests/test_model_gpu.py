@@ -1,0 +1,176 @@
+"""Model-level parity on the GPU: DiT forward and F5TTS.sample (HIP engine through the C ABI) vs the oracle.
+
+Gate (BASELINE.json north_star): mean |mel_engine - mel_oracle| <= 1e-3 on identical weights / inputs /
+injected y0.  It is met in the bf16x3 precision mode (bf16 MFMA, hi/lo split operands, fp32-class
+products).  The plain bf16 mode is checked against the oracle evaluated with the SAME bf16 operand
+rounding (kernel-bug detector) and its drift vs the fp32 oracle is reported, not hidden.
+"""
+import numpy as np
+import pytest
+import torch
+
+from f5test import DEV, E, O, TINY, F5TTS_335M, report, synth_inputs, synthetic_weights
+from f5_tts_mlx_amd.cfm import F5TTS, time_grid
+from f5_tts_mlx_amd.dit import DiT
+
+pytestmark = pytest.mark.gpu
+
+MEL_L1_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def tiny_weights():
+    return synthetic_weights(TINY, seed=42)
+
+
+def _model(cfg, weights, precision):
+    m = DiT.from_config(cfg, precision=precision, device=DEV)
+    m.load_weights(weights)
+    return m
+
+
+@pytest.fixture(scope="module")
+def tiny_bf16(tiny_weights):
+    return _model(TINY, tiny_weights, "bf16")
+
+
+@pytest.fixture(scope="module")
+def tiny_x3(tiny_weights):
+    return _model(TINY, tiny_weights, "bf16x3")
+
+
+def _pad_cond(cond, N):
+    B, n_ref, mel = cond.shape
+    out = torch.zeros((B, N, mel))
+    out[:, :n_ref] = cond
+    return out
+
+
+@pytest.mark.parametrize("B,N,ragged", [(1, 70, False), (2, 150, True), (3, 64, False)])
+def test_dit_forward_parity(tiny_weights, tiny_bf16, tiny_x3, B, N, ragged):
+    cfg = TINY
+    cond, text, durations, y0 = synth_inputs(cfg, B, N, nt=24, n_ref=30, seed=B * 100 + N, ragged=ragged)
+    step_cond = _pad_cond(cond, N)          # dit-level input: already masked/padded
+    mask = O.lens_to_mask(torch.tensor(durations), N) if B > 1 else None
+    t = 0.37
+    ref = {}
+    for name, kw in (("fp32", dict()), ("emu", dict(emulate_bf16=True))):
+        orc = O.DiTOracle(cfg, tiny_weights, **kw)
+        ref[name] = (orc.forward(y0, step_cond, text, torch.tensor(t), False, False, mask),
+                     orc.forward(y0, step_cond, text, torch.tensor(t), True, True, mask))
+    for model, rname, tol in ((tiny_x3, "fp32", 2e-4), (tiny_bf16, "emu", 1.5e-2)):
+        pred, null = model.engine.dit_forward(y0.to(DEV), text.to(DEV), step_cond.to(DEV).contiguous(), [N] * B, durations, t,
+                                              use_mask=B > 1)
+        torch.cuda.synchronize()
+        for nm, got, want in (("pred", pred, ref[rname][0]), ("null", null, ref[rname][1])):
+            assert torch.isfinite(got).all()
+            mx, mean, refm = report(f"dit_forward[{model.precision}] {nm} vs oracle[{rname}] B{B} N{N}", got.cpu(), want)
+            assert mean <= tol * max(1.0, refm), (nm, model.precision)
+    # drift of plain bf16 vs the fp32 oracle (reported; bounded loosely)
+    pred, _ = tiny_bf16.engine.dit_forward(y0.to(DEV), text.to(DEV), step_cond.to(DEV).contiguous(), [N] * B, durations, t,
+                                           use_mask=B > 1)
+    _, mean, refm = report(f"dit_forward[bf16] drift vs oracle[fp32] B{B} N{N}", pred.cpu(), ref["fp32"][0])
+    assert mean <= 3e-2 * max(1.0, refm)
+
+
+def test_dit_call_signature(tiny_bf16, tiny_weights):
+    """DiT.__call__ keeps the reference signature (dit.py:374-383)."""
+    cfg = TINY
+    cond, text, durations, y0 = synth_inputs(cfg, 1, 40, nt=10, n_ref=12, seed=3)
+    sc = _pad_cond(cond, 40)
+    out = tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=False, drop_text=False, mask=None)
+    null = tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=True, drop_text=True, mask=None)
+    assert out.shape == (1, 40, cfg.mel_dim) and null.shape == out.shape
+    assert float((out - null).abs().mean()) > 1e-4
+    with pytest.raises(NotImplementedError):
+        tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=True, drop_text=False)
+
+
+@pytest.mark.parametrize("method,steps", [("euler", 8), ("midpoint", 5), ("rk4", 4)])
+@pytest.mark.parametrize("B", [1, 2])
+def test_sample_parity(tiny_weights, tiny_bf16, tiny_x3, method, steps, B):
+    cfg = TINY
+    N = 96
+    cond, text, durations, y0 = synth_inputs(cfg, B, N, nt=20, n_ref=33, seed=17 + B, ragged=B > 1)
+    kw = dict(steps=steps, method=method, cfg_strength=2.0, sway_sampling_coef=-1.0)
+    dur_t = torch.tensor(durations)
+    o_fp32 = O.sample(O.DiTOracle(cfg, tiny_weights), cond, text, dur_t, y0=y0, return_aux=True, **kw)
+    o_emu = O.sample(O.DiTOracle(cfg, tiny_weights, emulate_bf16=True), cond, text, dur_t, y0=y0, **kw)
+
+    f5 = F5TTS(transformer=tiny_x3)
+    out, traj = f5.sample(cond, text, duration=dur_t, y0=y0, **kw)
+    torch.cuda.synchronize()
+    assert out.shape == (B, N, cfg.mel_dim) and traj.shape == (steps, B, N, cfg.mel_dim)
+    _, l1, _ = report(f"sample[bf16x3] {method} B{B} final mel vs oracle[fp32]", out.cpu(), o_fp32[0])
+    assert l1 <= MEL_L1_TOL
+    _, l1t, _ = report(f"sample[bf16x3] {method} B{B} trajectory vs oracle[fp32]", traj.cpu(), o_fp32[1])
+    assert l1t <= MEL_L1_TOL
+    assert torch.equal(traj[0].cpu(), y0)                       # trajectory[0] is the injected noise
+    aux = o_fp32[2]                                             # conditioning frames are spliced back exactly
+    cm = aux["cond_mask"]
+    assert torch.equal(out.cpu()[cm], torch.nn.functional.pad(cond, (0, 0, 0, N - cond.shape[1]))[cm])
+
+    f5b = F5TTS(transformer=tiny_bf16)
+    outb, _ = f5b.sample(cond, text, duration=dur_t, y0=y0, **kw)
+    _, l1e, _ = report(f"sample[bf16] {method} B{B} vs oracle[bf16-emulated]", outb.cpu(), o_emu[0])
+    _, l1d, _ = report(f"sample[bf16] {method} B{B} drift vs oracle[fp32]", outb.cpu(), o_fp32[0])
+    assert l1e <= 2e-2 and l1d <= 5e-2
+
+
+def test_sample_graph_equals_eager(tiny_bf16):
+    cfg = TINY
+    cond, text, durations, y0 = synth_inputs(cfg, 2, 80, nt=16, n_ref=20, seed=5, ragged=True)
+    f5 = F5TTS(transformer=tiny_bf16)
+    kw = dict(duration=torch.tensor(durations), steps=6, method="euler", y0=y0)
+    a, ta = f5.sample(cond, text, use_graph=False, **kw)
+    b, tb = f5.sample(cond, text, use_graph=True, **kw)
+    c, tc = f5.sample(cond, text, use_graph=True, **kw)          # replay of the cached graph
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(ta, tb) and torch.equal(b, c) and torch.equal(tb, tc)
+
+
+def test_sample_no_cfg_and_errors(tiny_bf16, tiny_weights):
+    cfg = TINY
+    cond, text, durations, y0 = synth_inputs(cfg, 1, 64, nt=12, n_ref=16, seed=8)
+    f5 = F5TTS(transformer=tiny_bf16)
+    out, _ = f5.sample(cond, text, duration=64, steps=4, method="euler", cfg_strength=0.0, y0=y0)
+    ref = O.sample(O.DiTOracle(cfg, tiny_weights, emulate_bf16=True), cond, text, 64, y0=y0, steps=4, method="euler",
+                   cfg_strength=0.0)
+    _, l1, _ = report("sample cfg=0 vs oracle[emu]", out.cpu(), ref[0])
+    assert l1 <= 2e-2
+    with pytest.raises(ValueError, match="Unknown method: heun"):
+        f5.sample(cond, text, duration=64, steps=4, method="heun", y0=y0)
+    with pytest.raises(ValueError, match="Duration must be provided"):
+        f5.sample(cond, text, duration=None, steps=4, method="euler", y0=y0)
+    # duration is clamped to lens + 1 (cfm.py:317): asking for fewer frames than the reference audio
+    out2, traj2 = f5.sample(cond, text, duration=3, steps=3, method="euler", seed=1)
+    assert out2.shape[1] == 17
+
+
+def test_seed_determinism(tiny_bf16):
+    cfg = TINY
+    cond, text, _, _ = synth_inputs(cfg, 1, 64, nt=12, n_ref=16, seed=8)
+    f5 = F5TTS(transformer=tiny_bf16)
+    a, _ = f5.sample(cond, text, duration=48, steps=3, method="euler", seed=1234)
+    b, _ = f5.sample(cond, text, duration=48, steps=3, method="euler", seed=1234)
+    c, _ = f5.sample(cond, text, duration=48, steps=3, method="euler", seed=1235)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_full_size_forward_parity():
+    """One full-size (335M, N=937) CFG evaluation: bf16x3 engine vs the fp32 oracle."""
+    cfg = F5TTS_335M
+    w = synthetic_weights(cfg, seed=42)
+    N = 937
+    cond, text, durations, y0 = synth_inputs(cfg, 1, N, nt=160, n_ref=281, seed=1)
+    sc = _pad_cond(cond, N)
+    orc = O.DiTOracle(cfg, w)
+    want = orc.forward(y0, sc, text, torch.tensor(0.25), False, False, None)
+    for prec, tol in (("bf16x3", 2e-4), ("bf16", 2e-2)):
+        m = _model(cfg, w, prec)
+        pred, null = m.engine.dit_forward(y0.to(DEV), text.to(DEV), sc.to(DEV), [N], durations, 0.25)
+        torch.cuda.synchronize()
+        _, mean, refm = report(f"full-size forward [{prec}] vs oracle[fp32]", pred.cpu(), want)
+        assert mean <= tol * max(1.0, refm)
+        del m
+        torch.cuda.empty_cache()

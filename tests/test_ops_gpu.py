@@ -1,0 +1,362 @@
+"""Per-kernel parity: HIP op (through the C ABI) vs the oracle / plain torch fp32 on the same inputs.
+
+Tolerances: fp32 kernels 1e-5 relative; bf16 MFMA kernels are compared (a) against the SAME operands
+rounded to bf16 with fp32 accumulation (kernel-bug detector, ~1e-3 of the output scale from summation
+order only) and (b) in bf16x3 mode against full fp32 (<= 5e-5 of the output scale).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from f5test import DEV, E, O, P, bf16r, join, randn, report, rng, split_bf16, stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return E.load_library()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def _gemm(lib, a, w, bias, epi, nseg, N=None):
+    M, K = a.shape
+    N = N or w.shape[0]
+    a_hi, a_lo = split_bf16(a.to(DEV))
+    wpad = torch.zeros(((w.shape[0] + 127) // 128 * 128, K))
+    wpad[: w.shape[0]] = w
+    w_hi, w_lo = split_bf16(wpad.to(DEV))
+    out_f = torch.full((M, N), float("nan"), device=DEV)
+    out_hi = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    out_lo = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    b = bias.to(DEV) if bias is not None else None
+    E.check(lib.f5_op_gemm(P(a_hi), P(a_lo), P(w_hi), P(w_lo), P(b), P(out_f), P(out_hi), P(out_lo), M, N, K, K, K, N, nseg, epi,
+                           stream()), "f5_op_gemm")
+    sync()
+    return out_f.cpu(), out_hi.cpu(), out_lo.cpu()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (300, 256, 128), (937, 100, 256), (1874, 1024, 1024), (129, 384, 2048)])
+def test_gemm_f32_out(lib, M, N, K):
+    r = rng(M + N + K)
+    a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+    ref32 = a.double() @ w.double().T + bias.double()
+    refbf = (bf16r(a).double() @ bf16r(w).double().T) + bias.double()
+    out, _, _ = _gemm(lib, a, w, bias, 0, 1)
+    mx, mean, ref = report(f"gemm bf16 {M}x{N}x{K} vs bf16-rounded operands", out, refbf)
+    assert mx <= 2e-4 * max(1.0, float(refbf.abs().max()))
+    out3, _, _ = _gemm(lib, a, w, bias, 0, 3)
+    mx, mean, ref = report(f"gemm bf16x3 {M}x{N}x{K} vs fp64", out3, ref32)
+    assert mx <= 5e-5 * max(1.0, float(ref32.abs().max()))
+
+
+def test_gemm_asymmetric_identity(lib):
+    """A = I with an asymmetric W detects a transposed / permuted C write (CDNA guide rule 16)."""
+    K = 128
+    a = torch.eye(K)
+    w = torch.arange(256 * K, dtype=torch.float32).reshape(256, K) % 251
+    out, _, _ = _gemm(lib, a, w, None, 0, 1)
+    assert torch.equal(out, w.T.contiguous()[:K]), "C tile layout is wrong"
+
+
+@pytest.mark.parametrize("epi", [1, 2, 3])
+def test_gemm_epilogues(lib, epi):
+    r = rng(epi)
+    M, N, K = 257, 384, 256
+    a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+    pre = a.double() @ w.double().T + bias.double()
+    if epi == 1:
+        ref = pre
+    elif epi == 2:
+        ref = F.gelu(pre, approximate="tanh")
+    else:
+        ref = F.gelu(pre)
+    out_f, out_hi, out_lo = _gemm(lib, a, w, bias, epi, 3)
+    got = out_f if epi == 3 else join(out_hi, out_lo)
+    mx, _, _ = report(f"gemm epilogue {epi} (bf16x3)", got, ref)
+    assert mx <= 1e-4
+    if epi != 3:  # hi part alone is the bf16 rounding of the value
+        mxh, _, _ = report(f"gemm epilogue {epi} hi-part", out_hi.float(), ref)
+        assert mxh <= 2 ** -8 * float(ref.abs().max()) + 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# QKV + RoPE + attention
+# ------------------------------------------------------------------------------------------------
+def _attention_case(lib, B, H, N, kv_len, nseg, seed=0):
+    D = H * 64
+    r = rng(seed)
+    x = randn(r, B * N, D)
+    w = randn(r, 3 * D, D, scale=D ** -0.5)
+    bias = randn(r, 3 * D, scale=0.1)
+    npad = (N + 63) // 64 * 64
+    x_hi, x_lo = split_bf16(x.to(DEV))
+    w_hi, w_lo = split_bf16(w.to(DEV))
+    cos_t = torch.empty((N, 32), device=DEV)
+    sin_t = torch.empty((N, 32), device=DEV)
+    E.check(lib.f5_op_rope_table(P(cos_t), P(sin_t), N, 64, stream()))
+    qk = [torch.zeros((B * N, 2 * D), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    vt = [torch.zeros((B * H, 64, npad), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    E.check(lib.f5_op_qkv_rope(P(x_hi), P(x_lo), P(w_hi), P(w_lo), P(bias.to(DEV)), P(cos_t), P(sin_t), P(qk[0]), P(qk[1]),
+                               P(vt[0]), P(vt[1]), B, N, npad, H, D, nseg, stream()), "qkv_rope")
+    out = [torch.zeros((B * N, D), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    kv = torch.tensor(kv_len, dtype=torch.int32, device=DEV) if kv_len is not None else None
+    E.check(lib.f5_op_attention(P(qk[0]), P(qk[1]), P(vt[0]), P(vt[1]), P(out[0]), P(out[1]), P(kv), B, H, N, npad, D,
+                                C.c_float(0.125), int(nseg == 3), stream()), "attention")
+    sync()
+    # --- reference (oracle functions) in fp64
+    xx = x.double() if nseg == 3 else bf16r(x).double()
+    ww = w.double() if nseg == 3 else bf16r(w).double()
+    qkv = xx @ ww.T + bias.double()
+    q, k, v = [t.reshape(B, N, H, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    freqs = O.rotary_freqs(64, N).double()
+    q, k = O.apply_rotary_pos_emb(q, freqs), O.apply_rotary_pos_emb(k, freqs)
+    # rope table parity
+    report("rope cos table", cos_t.cpu(), freqs.cos()[:, 0::2])
+    assert float((cos_t.cpu().double() - freqs.cos()[:, 0::2]).abs().max()) < 1e-5 * max(1, N / 100)
+    # q/k/v written by the epilogue
+    got_q = join(qk[0], qk[1] if nseg == 3 else None).cpu()[:, :D].reshape(B, N, H, 64).transpose(1, 2)
+    got_k = join(qk[0], qk[1] if nseg == 3 else None).cpu()[:, D:].reshape(B, N, H, 64).transpose(1, 2)
+    got_v = join(vt[0], vt[1] if nseg == 3 else None).cpu().reshape(B, H, 64, npad)[..., :N].transpose(-1, -2)
+    tol_in = 5e-5 if nseg == 3 else 2e-2
+    for nm, g, rf in (("q", got_q, q), ("k", got_k, k), ("v", got_v, v)):
+        mx, _, _ = report(f"qkv_rope {nm} nseg={nseg} B{B} H{H} N{N}", g, rf)
+        assert mx <= tol_in * max(1.0, float(rf.abs().max())), nm
+    assert float(join(vt[0], vt[1]).cpu().reshape(B, H, 64, npad)[..., N:].abs().max() if npad > N else 0.0) == 0.0
+    # attention proper, from the operands the kernel actually saw
+    qq, kk, vv = got_q.double(), got_k.double(), got_v.double()
+    s = (qq @ kk.transpose(-1, -2)) * 0.125
+    if kv_len is not None:
+        keep = torch.arange(N)[None, :] < torch.tensor(kv_len)[:, None]
+        s = s.masked_fill(~keep[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, dim=-1) @ vv).transpose(1, 2).reshape(B * N, D)
+    got = join(out[0], out[1] if nseg == 3 else None).cpu()
+    mx, mean, _ = report(f"attention nseg={nseg} B{B} H{H} N{N} kv={kv_len}", got, ref)
+    tol = 5e-5 if nseg == 3 else 1.5e-2
+    assert mx <= tol * max(1.0, float(ref.abs().max()))
+    assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 130, 499, 937])
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_attention_shapes(lib, N, nseg):
+    _attention_case(lib, 1, 2, N, None, nseg, seed=N)
+
+
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_attention_ragged_mask(lib, nseg):
+    _attention_case(lib, 3, 2, 200, [200, 130, 1], nseg, seed=7)
+
+
+def test_attention_softmax_spike(lib):
+    """force large running-max jumps across KV tiles (online-softmax rescale path)."""
+    B, H, N, D = 1, 2, 300, 128
+    r = rng(3)
+    q = randn(r, B * N, D)
+    k = randn(r, B * N, D)
+    k[70] *= 30.0
+    k[200] *= 60.0
+    v = randn(r, B * N, D)
+    npad = 320
+    qk = torch.cat([q, k], dim=1)
+    qk_hi, qk_lo = split_bf16(qk.to(DEV))
+    vt_full = torch.zeros((B * H, 64, npad))
+    vt_full[..., :N] = v.reshape(N, H, 64).permute(1, 2, 0)
+    vt_hi, vt_lo = split_bf16(vt_full.to(DEV))
+    out = [torch.zeros((B * N, D), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    E.check(lib.f5_op_attention(P(qk_hi), P(qk_lo), P(vt_hi), P(vt_lo), P(out[0]), P(out[1]), P(None), B, H, N, npad, D,
+                                C.c_float(0.125), 1, stream()))
+    sync()
+    qq = q.double().reshape(N, H, 64).transpose(0, 1)
+    kk = k.double().reshape(N, H, 64).transpose(0, 1)
+    vv = v.double().reshape(N, H, 64).transpose(0, 1)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) * 0.125, dim=-1) @ vv).transpose(0, 1).reshape(N, D)
+    mx, _, _ = report("attention spike", join(out[0], out[1]).cpu(), ref)
+    assert mx <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# conv position embedding
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,C", [(1, 50, 128), (2, 130, 256), (1, 937, 1024)])
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_convpos(lib, B, N, C, nseg):
+    r = rng(N + C)
+    G, taps = C // 64, 31
+    x = randn(r, B, N, C)
+    w = randn(r, C, taps, 64, scale=(taps * 64) ** -0.5)     # reference layout (out, k, in/groups)
+    bias = randn(r, C, scale=0.1)
+    x_hi, x_lo = split_bf16(x.reshape(B * N, C).to(DEV))
+    w_hi, w_lo = split_bf16(w.reshape(C, taps * 64).to(DEV))
+    out = [torch.zeros((B * N, C), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    acc = randn(r, B * N, C).to(DEV)
+    acc0 = acc.clone()
+    E.check(lib.f5_op_convpos(P(x_hi), P(x_lo), P(w_hi), P(w_lo), P(bias.to(DEV)), P(out[0]), P(out[1]), P(None), B, N, C, G,
+                              taps, nseg, 0, stream()), "convpos mode0")
+    E.check(lib.f5_op_convpos(P(x_hi), P(x_lo), P(w_hi), P(w_lo), P(bias.to(DEV)), P(None), P(None), P(acc), B, N, C, G, taps,
+                              nseg, 1, stream()), "convpos mode1")
+    sync()
+    xx = x.double() if nseg == 3 else bf16r(x).double()
+    ww = w.double() if nseg == 3 else bf16r(w).double()
+    y = F.conv1d(xx.transpose(1, 2), ww.permute(0, 2, 1), bias.double(), padding=taps // 2, groups=G).transpose(1, 2)
+    ref = (y * torch.tanh(F.softplus(y))).reshape(B * N, C)
+    got = join(out[0], out[1] if nseg == 3 else None).cpu()
+    mx, _, _ = report(f"convpos nseg={nseg} B{B} N{N} C{C}", got, ref)
+    tol = 5e-5 if nseg == 3 else 1e-2
+    assert mx <= tol * max(1.0, float(ref.abs().max()))
+    mx2, _, _ = report("convpos accumulate mode", (acc - acc0).cpu(), ref)
+    assert mx2 <= (5e-5 if nseg == 3 else 2e-3) * max(1.0, float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# row kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,dim", [(1, 256), (5, 512), (937, 1024)])
+def test_ln_modulate(lib, rows, dim):
+    r = rng(rows)
+    x, sc, sh = randn(r, rows, dim) * 3 + 0.5, randn(r, dim, scale=0.5), randn(r, dim, scale=0.5)
+    hi = torch.zeros((rows, dim), dtype=torch.bfloat16, device=DEV)
+    lo = torch.zeros_like(hi)
+    E.check(lib.f5_op_ln_modulate(P(x.to(DEV)), P(sc.to(DEV)), P(sh.to(DEV)), P(hi), P(lo), rows, dim, stream()))
+    sync()
+    ref = O.DiTOracle.layer_norm(x.double()) * (1 + sc.double()) + sh.double()
+    mx, _, _ = report(f"ln_modulate {rows}x{dim}", join(hi, lo).cpu(), ref)
+    assert mx <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((hi.float().cpu() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("B,N,dim", [(1, 5, 256), (2, 100, 512)])
+def test_dwconv_ln(lib, B, N, dim):
+    r = rng(N)
+    x = randn(r, B, N, dim)
+    dw_w, dw_b = randn(r, dim, 7, 1, scale=0.4), randn(r, dim, scale=0.1)
+    ln_w, ln_b = 1 + randn(r, dim, scale=0.1), randn(r, dim, scale=0.1)
+    hi = torch.zeros((B * N, dim), dtype=torch.bfloat16, device=DEV)
+    lo = torch.zeros_like(hi)
+    E.check(lib.f5_op_dwconv_ln(P(x.to(DEV)), P(dw_w.reshape(dim, 7).contiguous().to(DEV)), P(dw_b.to(DEV)), P(ln_w.to(DEV)),
+                                P(ln_b.to(DEV)), P(hi), P(lo), B, N, dim, stream()))
+    sync()
+    y = F.conv1d(x.double().transpose(1, 2), dw_w.double().permute(0, 2, 1), dw_b.double(), padding=3, groups=dim).transpose(1, 2)
+    ref = O.DiTOracle.layer_norm(y, ln_w.double(), ln_b.double()).reshape(B * N, dim)
+    mx, _, _ = report(f"dwconv_ln B{B} N{N} d{dim}", join(hi, lo).cpu(), ref)
+    assert mx <= 3e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,N,dim", [(1, 31, 256), (3, 100, 1024)])
+def test_grn(lib, B, N, dim):
+    r = rng(dim)
+    g, gamma, beta = randn(r, B, N, dim), randn(r, dim, scale=0.1), randn(r, dim, scale=0.1)
+    scratch = torch.zeros(lib.f5_op_grn_scratch_floats(B, N, dim), device=DEV)
+    hi = torch.zeros((B * N, dim), dtype=torch.bfloat16, device=DEV)
+    lo = torch.zeros_like(hi)
+    E.check(lib.f5_op_grn(P(g.to(DEV)), P(gamma.to(DEV)), P(beta.to(DEV)), P(scratch), P(hi), P(lo), B, N, dim, stream()))
+    sync()
+    gd = g.double()
+    gx = torch.linalg.vector_norm(gd, ord=2, dim=1, keepdim=True)
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + 1e-6)
+    ref = (gamma.double() * (gd * nx) + beta.double() + gd).reshape(B * N, dim)
+    mx, _, _ = report(f"grn B{B} N{N} d{dim}", join(hi, lo).cpu(), ref)
+    assert mx <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_text_embed_bit_exact_index_path(lib):
+    r = rng(11)
+    B, N, nt, dim, V = 3, 40, 12, 128, 50
+    text = torch.from_numpy(r.integers(0, V, (B, nt)).astype(np.int32))
+    text[1, 9:] = -1
+    text[2, 0:] = -1
+    text[0, 3] = 0                                   # a real token with id 0 (-> 1 after the +1 shift)
+    table = randn(r, V + 1, dim)
+    pos = torch.empty((4096, dim), device=DEV)
+    E.check(lib.f5_op_text_pos_table(P(pos), 4096, dim, stream()))
+    out = torch.zeros((2, B, N, dim), device=DEV)
+    ids = torch.full((2, B, N), -7, dtype=torch.int32, device=DEV)
+    keep = torch.full((2, B, N), 9, dtype=torch.uint8, device=DEV)
+    E.check(lib.f5_op_text_embed(P(text.to(DEV)), nt, P(table.to(DEV)), P(pos), 4096, P(out), P(ids), P(keep), B, N, dim,
+                                 stream()))
+    sync()
+    ref_pos = O.precompute_freqs_cis(dim, 4096)
+    mxp, _, _ = report("text pos table", pos.cpu(), ref_pos)
+    assert mxp <= 4e-4                                # fp32 angle up to 4095 rad: sin/cos argument rounding
+    cfg = type("C", (), dict(text_dim=dim, text_max_pos=4096, conv_layers=0))()
+    orc = O.DiTOracle.__new__(O.DiTOracle)
+    orc.cfg, orc.dtype, orc.emu = cfg, torch.float32, False
+    orc.w = {"transformer.text_embed.text_embed.weight": table}
+    for br, drop in ((0, False), (1, True)):
+        emb, ref_ids = orc.text_embed(text, N, drop)
+        assert torch.equal(ids[br].cpu().to(torch.int64), ref_ids), "token index path must be bit exact"
+        shifted = torch.nn.functional.pad(text.to(torch.int64) + 1, (0, N - nt))
+        assert torch.equal(keep[br].cpu().bool(), shifted != 0)
+        want = (emb + ref_pos[:N][None]) * (shifted != 0)[..., None]
+        got = out[br].cpu()
+        # same table on both sides: use the device table for an exact comparison
+        want_dev = (table[ref_ids] + pos.cpu()[:N][None]) * (shifted != 0)[..., None]
+        assert torch.equal(got, want_dev)
+        assert float((got - want).abs().max()) <= 4e-4
+
+
+def test_time_tables(lib):
+    r = rng(5)
+    n, F_, D = 7, 256, 512
+    t = torch.tensor([0.0, 0.0012834, 0.3, 0.5, 0.77, 0.94935, 1.0])
+    sin_out = torch.empty((n, F_), device=DEV)
+    E.check(lib.f5_op_time_sinus(P(t.to(DEV)), P(sin_out), n, F_, stream()))
+    half = F_ // 2
+    emb = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    arg = (1000 * t[:, None]) * emb[None, :]
+    ref = torch.cat([arg.double().sin(), arg.double().cos()], dim=-1)
+    sync()
+    mx, _, _ = report("time sinus", sin_out.cpu(), ref)
+    assert mx <= 2e-4                                   # argument up to 1000 rad in fp32
+    a, w, b = randn(r, n, F_), randn(r, D, F_, scale=F_ ** -0.5), randn(r, D, scale=0.1)
+    out = torch.empty((n, D), device=DEV)
+    for si, so in ((0, 0), (1, 0), (0, 1)):
+        E.check(lib.f5_op_skinny_gemm(P(a.to(DEV)), P(w.to(DEV)), P(b.to(DEV)), P(out), n, D, F_, si, so, stream()))
+        sync()
+        aa = F.silu(a.double()) if si else a.double()
+        ref = aa @ w.double().T + b.double()
+        ref = F.silu(ref) if so else ref
+        mx, _, _ = report(f"skinny gemm silu_in={si} silu_out={so}", out.cpu(), ref)
+        assert mx <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_cfg_axpy(lib):
+    r = rng(9)
+    rows, mel = 77, 100
+    pred, null, base = randn(r, rows, mel), randn(r, rows, mel), randn(r, rows, mel)
+    dt = torch.tensor([0.0506], device=DEV)
+    out = torch.empty((rows, mel), device=DEV)
+    xin = [torch.full((rows, 128), 5.0, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    E.check(lib.f5_op_cfg_axpy(P(pred.to(DEV)), P(null.to(DEV)), C.c_float(2.0), P(base.to(DEV)), P(dt), C.c_float(0.5),
+                               C.c_float(1.0), P(out), P(xin[0]), P(xin[1]), rows, mel, stream()))
+    sync()
+    k = pred + (pred - null) * 2.0
+    ref = base + (np.float32(0.5) * np.float32(0.0506)) * k
+    assert float((out.cpu() - ref).abs().max()) <= 1e-6
+    assert float(join(xin[0], xin[1]).cpu()[:, :mel].sub(out.cpu()).abs().max()) <= 1e-5
+    assert float(xin[0].float().cpu()[:, mel:].abs().max()) == 0.0
+
+
+def test_mel_fixture(lib):
+    """log-mel of the reference's WAV fixture vs the oracle (and its Appendix-C known-answer stats)."""
+    import scipy.io.wavfile as wf
+    from f5_tts_mlx_amd.audio import log_mel_spectrogram
+    from f5_tts_mlx_amd.engine import library_path
+    sr, a = wf.read(str(library_path().parent.parent / "assets" / "test_en_1_ref_short.wav"))
+    audio = (a.astype(np.float64) / 32768.0).astype(np.float32)
+    got = log_mel_spectrogram(torch.from_numpy(audio)).cpu()
+    ref = torch.from_numpy(O.log_mel_spectrogram(audio, dtype=np.float64))
+    assert got.shape == (1, 499, 100)
+    mx, mean, _ = report("mel fixture", got, ref)
+    assert mean <= 1e-5 and mx <= 2e-3
+    assert abs(float(got.mean()) - (-1.26651)) < 1e-4 and abs(float(got.max()) - 4.46371) < 1e-4
