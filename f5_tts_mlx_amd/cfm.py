@@ -79,6 +79,30 @@ def time_grid(steps: int, sway_sampling_coef: Optional[float]) -> np.ndarray:
     return t
 
 
+def prepare_lengths(text: torch.Tensor, cond_seq_len: int, batch: int, duration, lens, max_duration: int, method: str):
+    """Host-side scalar logic of `F5TTS.sample` (cfm.py:288-319, :383-390) on CPU tensors.
+
+    Returns (text int32 (b, nt), lens int64 (b,), duration int64 (b,), max_duration int).  Raises the
+    reference's ValueErrors before anything reaches the GPU."""
+    if not exists(lens):
+        lens = torch.full((batch,), cond_seq_len, dtype=torch.int64)
+    lens = torch.as_tensor(lens).to("cpu", torch.int64)
+    text = torch.as_tensor(text).to("cpu", torch.int32)
+    text_lens = (text != -1).sum(dim=-1)
+    lens = torch.maximum(text_lens, lens)                                   # cfm.py:301-303
+    if duration is None:
+        raise ValueError("Duration must be provided or a duration predictor must be set.")   # cfm.py:310
+    if isinstance(duration, int):
+        duration = torch.full((batch,), duration, dtype=torch.int64)
+    duration = torch.as_tensor(duration).to("cpu", torch.int64)
+    duration = torch.maximum(lens + 1, duration)                            # cfm.py:317
+    duration = torch.clip(duration, 0, max_duration)                        # cfm.py:318
+    max_duration = int(duration.max().item())                               # cfm.py:319
+    if method not in ("midpoint", "euler", "rk4"):
+        raise ValueError(f"Unknown method: {method}")                       # cfm.py:390
+    return text, lens, duration, max_duration
+
+
 class F5TTS:
     """Conditional flow matching wrapper (cfm.py:128-167).  Training (`__call__` loss) is out of scope."""
 
@@ -145,39 +169,18 @@ class F5TTS:
             assert cond.shape[0] == 1, "raw-wave conditioning supports batch 1 (cfm.py:284)"
             cond = self._mel_spec(cond[0])
             assert cond.shape[-1] == self.num_channels
-        cond = cond.to(device, torch.float32)
 
         batch, cond_seq_len = cond.shape[:2]
-        if not exists(lens):
-            lens = torch.full((batch,), cond_seq_len, dtype=torch.int64)
-        lens = torch.as_tensor(lens).to("cpu", torch.int64)
-
-        # text (cfm.py:294-303)
         if isinstance(text, list):
             if exists(self._vocab_char_map):
                 text = list_str_to_idx(text, self._vocab_char_map)
             else:
                 text = list_str_to_tensor(text)
             assert text.shape[0] == batch
-        text = torch.as_tensor(text).to("cpu", torch.int32)
-        if exists(text):
-            text_lens = (text != -1).sum(dim=-1)
-            lens = torch.maximum(text_lens, lens)
-
-        # duration (cfm.py:307-319)
         if duration is None and self._duration_predictor is not None:
             duration = self.predict_duration(cond, text, speed)
-        elif duration is None:
-            raise ValueError("Duration must be provided or a duration predictor must be set.")
-        if isinstance(duration, int):
-            duration = torch.full((batch,), duration, dtype=torch.int64)
-        duration = torch.as_tensor(duration).to("cpu", torch.int64)
-        duration = torch.maximum(lens + 1, duration)
-        duration = torch.clip(duration, 0, max_duration)
-        max_duration = int(duration.max().item())
-
-        if method not in ("midpoint", "euler", "rk4"):
-            raise ValueError(f"Unknown method: {method}")
+        text, lens, duration, max_duration = prepare_lengths(text, cond_seq_len, batch, duration, lens, max_duration, method)
+        cond = cond.to(device, torch.float32)
 
         # pad the conditioning mel to max_duration (cfm.py:321); masks are built on the GPU from lens/durations
         if max_duration >= cond_seq_len:

@@ -115,6 +115,16 @@ class Engine:
               "f5_set_weights_arena")
         self._workspace: Optional[torch.Tensor] = None
         self.weights_ready = False
+        # hipGraph capture is illegal on the legacy default stream: the engine owns a side stream and
+        # orders it against the caller's current stream with events (wait_stream)
+        self._stream = torch.cuda.Stream(device=self.device)
+
+    def _run_on_side_stream(self, fn):
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            fn(C.c_void_p(self._stream.cuda_stream))
+        cur.wait_stream(self._stream)
 
     def __del__(self):
         try:
@@ -205,7 +215,7 @@ class Engine:
             trajectory = torch.empty((steps, B, N, mel), dtype=torch.float32, device=self.device)
         a, keep = self._args(text, cond, lens, durations, y0, t, steps, method, cfg_strength, use_mask, use_graph, out,
                              trajectory if return_trajectory else None, ws)
-        check(self.lib.f5_sample(self._h, C.byref(a), stream_ptr(self.device)), "f5_sample")
+        self._run_on_side_stream(lambda st: check(self.lib.f5_sample(self._h, C.byref(a), st), "f5_sample"))
         del keep
         return out, (trajectory if return_trajectory else None)
 
@@ -221,7 +231,7 @@ class Engine:
         null = torch.empty_like(cond) if cfg_strength >= 1e-5 else None
         a, keep = self._args(text, cond, lens, durations, None, np.zeros(2, np.float32), 2, "euler", cfg_strength, use_mask,
                              False, None, None, ws)
-        check(self.lib.f5_dit_forward(self._h, C.byref(a), ptr(x), C.c_float(t), ptr(pred), ptr(null), stream_ptr(self.device)),
-              "f5_dit_forward")
+        self._run_on_side_stream(lambda st: check(
+            self.lib.f5_dit_forward(self._h, C.byref(a), ptr(x), C.c_float(t), ptr(pred), ptr(null), st), "f5_dit_forward"))
         del keep
         return pred, null

@@ -1,0 +1,66 @@
+"""Multi-GPU path on CPU: shard arithmetic + the weight-broadcast / output-gather protocol under gloo (world_size 2)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from f5_tts_mlx_amd.dist import broadcast_weights, gather_outputs, shard_batch, shard_ranges
+
+
+def test_shard_ranges_partition():
+    for n in (0, 1, 7, 8, 255, 256, 257):
+        for w in (1, 2, 3, 8):
+            r = shard_ranges(n, w)
+            assert len(r) == w and r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [e - s for s, e in r]
+            assert max(sizes) - min(sizes) <= 1 and sorted(sizes, reverse=True) == sizes
+    idx, npad = shard_batch([900, 937, 500, 640, 700], 2, 1)
+    assert list(idx) == [3, 4] and npad == 937          # every shard pads to the GLOBAL max duration
+    assert shard_ranges(256, 8)[3] == (96, 128)         # BASELINE configs[3]: 32 utterances per GPU
+
+
+class _FakeEngine:
+    def __init__(self, rank):
+        self.arena = torch.full((1000,), float(rank + 1)) if rank else torch.arange(1000, dtype=torch.float32)
+        self.loaded = rank == 0
+
+    def mark_loaded_from_broadcast(self):
+        self.loaded = True
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _FakeEngine(rank)
+    ms = broadcast_weights(eng, src=0)
+    ok = eng.loaded and torch.equal(eng.arena, torch.arange(1000, dtype=torch.float32)) and ms >= 0
+    counts = [3, 2]
+    local = torch.full((counts[rank], 4, 5), float(rank))
+    g = gather_outputs(local, counts)
+    if rank == 0:
+        ok = ok and g.shape == (5, 4, 5) and float(g[:3].sum()) == 0.0 and float(g[3:].mean()) == 1.0
+    else:
+        ok = ok and g is None
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}
+
+
+def test_single_rank_needs_no_collective():
+    assert broadcast_weights(_FakeEngine(0)) == 0.0
