@@ -270,7 +270,7 @@ extern "C" int f5_engine_create(const f5_config* cfg, int precision, f5_engine**
 
 extern "C" void f5_engine_destroy(f5_engine* e) {
     if (!e) return;
-    for (auto& g : e->graphs) hipGraphExecDestroy(g.exec);
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     delete e;
 }
 
@@ -802,12 +802,12 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
             const int rc = run_sample_body(c, a);
             const hipError_t ec = hipStreamEndCapture(s, &graph);
             if (rc) {
-                if (graph) hipGraphDestroy(graph);
+                if (graph) (void)hipGraphDestroy(graph);
                 return rc;
             }
             F5_HIP_CHECK(ec);
             F5_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            hipGraphDestroy(graph);
+            (void)hipGraphDestroy(graph);
             e->graphs.push_back({key, exec});
         }
         F5_HIP_CHECK(hipGraphLaunch(exec, s));
@@ -847,11 +847,18 @@ extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float
 // ------------------------------------------------------------------------------------------------
 // per-op entry points
 // ------------------------------------------------------------------------------------------------
+extern int f5_gemm_tile_override;
+extern "C" int f5_debug_set_gemm_tile(int sel) {
+    F5_REQUIRE(sel >= 0 && sel <= 3, "gemm tile override must be 0 (auto), 1 (128x128), 2 (64x128) or 3 (64x64)");
+    f5_gemm_tile_override = sel;
+    return 0;
+}
+
 extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                           float* out_f32, void* out_bf_hi, void* out_bf_lo, int M, int N, int K, int lda, int ldw, int ldo,
                           int nseg, int epi, void* stream) {
-    F5_REQUIRE(epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU_TANH || epi == EPI_GELU_ERF,
-               "f5_op_gemm supports epilogues 0-3 only");
+    F5_REQUIRE(epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU_TANH || epi == EPI_GELU_ERF || epi == EPI_GELU_ERF_BF16,
+               "f5_op_gemm supports epilogues 0-3 and 8 only");
     F5GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A[0] = (const bf16_t*)a_hi;
@@ -1008,4 +1015,36 @@ extern "C" int f5_op_cfg_axpy(const float* pred, const float* null_pred, float c
     o.rows = rows;
     o.mel_dim = mel_dim;
     return f5_launch_ode_stage(o, (hipStream_t)stream);
+}
+
+// x[row][col] += gate[col] * ((A W^T + bias)[row][col] * keep[row])   (dit.py:319,323; Vocos layer scale + residual)
+extern "C" int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                                     const float* gate, const uint8_t* rowkeep, float* x, int M, int N, int K, int lda, int ldw,
+                                     int ldx, int nseg, void* stream) {
+    F5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = (const bf16_t*)a_hi;
+    g.A[1] = (const bf16_t*)a_lo;
+    g.W[0] = (const bf16_t*)w_hi;
+    g.W[1] = (const bf16_t*)w_lo;
+    g.lda = lda;
+    g.ldw = ldw;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.nseg = nseg;
+    g.bias = bias;
+    g.gate = gate;
+    g.rowkeep = rowkeep;
+    g.out_f32 = x;
+    g.ldo = ldx;
+    F5_REQUIRE(gate != nullptr && x != nullptr, "gemm_resid_gate: null gate / x");
+    return f5_launch_gemm(g, EPI_RESID_GATE, (hipStream_t)stream);
+}
+extern "C" int f5_op_layernorm(const float* x, const float* w, const float* b, float* out_f32, void* out_hi, void* out_lo,
+                               int rows, int dim, void* stream) {
+    return f5_launch_layernorm(x, w, b, out_f32, (bf16_t*)out_hi, (bf16_t*)out_lo, rows, dim, 1e-6f, (hipStream_t)stream);
+}
+extern "C" int f5_op_im2col7(const float* x, void* out_hi, void* out_lo, int nbatch, int seq_len, int channels, void* stream) {
+    return f5_launch_im2col7(x, (bf16_t*)out_hi, (bf16_t*)out_lo, nbatch, seq_len, channels, (hipStream_t)stream);
 }

@@ -11,6 +11,7 @@ enum F5Epi : int {
     EPI_QKV_ROPE = 5,    // q,k: rope(acc + bias) -> qk[row][col]; v -> vt[b,h][d][n] (dit.py:136-158)
     EPI_ADDROWS = 6,     // out_f32 = acc + addrows[row][col]; out_bf = bf16(same)  (dit.py:250 split GEMM)
     EPI_RESID_KEEP = 7,  // out_f32 = (resid[row][col] + acc + bias) * keep[row]  (convnext_v2.py:53-54, dit.py:225)
+    EPI_GELU_ERF_BF16 = 8,  // out_bf = bf16(gelu_erf(acc + bias))              (Vocos ConvNeXt block)
 };
 
 struct F5GemmArgs {

@@ -469,3 +469,87 @@ int f5_launch_rowkeep(const int* dur, uint8_t* keep, int nbatch, int seq_len, hi
     F5_LAUNCH_CHECK();
     return 0;
 }
+
+// =================================================================================================
+// LayerNorm (affine), one wave per row
+// =================================================================================================
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ out_f32,
+                                                        bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int rows,
+                                                        float eps) {
+    constexpr int DIM = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[NV];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)row * DIM + i * 256 + lane * 4);
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = f5_wave_sum(sum) * (1.0f / DIM);
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            sq += d * d;
+        }
+    const float rstd = rsqrtf(f5_wave_sum(sq) * (1.0f / DIM) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+        if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + (size_t)row * DIM + c) = y;
+        if (out_hi) *reinterpret_cast<u32x2*>(out_hi + (size_t)row * DIM + c) = u32x2{f5_pack2(y[0], y[1]), f5_pack2(y[2], y[3])};
+        if (out_lo)
+            *reinterpret_cast<u32x2*>(out_lo + (size_t)row * DIM + c) = u32x2{f5_pack2_lo(y[0], y[1]), f5_pack2_lo(y[2], y[3])};
+    }
+}
+int f5_launch_layernorm(const float* x, const float* w, const float* b, float* out_f32, bf16_t* out_hi, bf16_t* out_lo,
+                        int rows, int dim, float eps, hipStream_t s) {
+    F5_REQUIRE(dim % 256 == 0 && dim >= 256 && dim <= 1024, "layernorm: dim must be 256/512/768/1024 (got %d)", dim);
+    const dim3 grid(f5_cdiv(rows, 4)), block(256);
+#define LN_ARGS x, w, b, out_f32, out_hi, out_lo, rows, eps
+    switch (dim / 256) {
+        case 1: hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, s, LN_ARGS); break;
+        case 2: hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, s, LN_ARGS); break;
+        case 3: hipLaunchKernelGGL((layernorm_kernel<3>), grid, block, 0, s, LN_ARGS); break;
+        default: hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, LN_ARGS); break;
+    }
+#undef LN_ARGS
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ x, bf16_t* __restrict__ out_hi,
+                                                      bf16_t* __restrict__ out_lo, int seq_len, int channels, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over rows * 7 * 128
+    if (i >= total) return;
+    const size_t row = i / (7 * 128);
+    const int rem = (int)(i - row * (7 * 128));
+    const int t = rem >> 7, c = rem & 127;
+    const int b = (int)(row / seq_len);
+    const int n = (int)(row - (size_t)b * seq_len) + t - 3;
+    float v = 0.0f;
+    if (c < channels && n >= 0 && n < seq_len) v = x[((size_t)b * seq_len + n) * channels + c];
+    bf16_t h, l;
+    f5_split(v, h, l);
+    out_hi[i] = h;
+    if (out_lo) out_lo[i] = l;
+}
+int f5_launch_im2col7(const float* x, bf16_t* out_hi, bf16_t* out_lo, int nbatch, int seq_len, int channels, hipStream_t s) {
+    F5_REQUIRE(channels <= 128, "im2col7: channels must be <= 128");
+    const size_t total = (size_t)nbatch * seq_len * 7 * 128;
+    hipLaunchKernelGGL(im2col7_kernel, dim3(f5_cdiv((long)total, 256)), dim3(256), 0, s, x, out_hi, out_lo, seq_len, channels,
+                       total);
+    F5_LAUNCH_CHECK();
+    return 0;
+}

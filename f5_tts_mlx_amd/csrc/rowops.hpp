@@ -67,3 +67,9 @@ int f5_launch_splice(const float* cond, const float* y, const int* lens, float* 
 
 // rowkeep[b*seq+n] = n < dur[b]  for 2 branches ([nb][seq])
 int f5_launch_rowkeep(const int* dur, uint8_t* keep, int nbatch, int seq_len, hipStream_t s);
+
+// LayerNorm with affine weight/bias over the last axis (dim = 256..1024), fp32 out and/or bf16 (hi, lo) out
+int f5_launch_layernorm(const float* x, const float* w, const float* b, float* out_f32, bf16_t* out_hi, bf16_t* out_lo,
+                        int rows, int dim, float eps, hipStream_t s);
+// im2col for Conv1d(k=7, pad=3) on channels-last input (c <= 128): out[b*n][7*128] bf16, tap-major, zero padded
+int f5_launch_im2col7(const float* x, bf16_t* out_hi, bf16_t* out_lo, int nbatch, int seq_len, int channels, hipStream_t s);

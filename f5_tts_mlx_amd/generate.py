@@ -1,0 +1,181 @@
+"""Text-to-speech entry point (reference: f5_tts_mlx/generate.py).
+
+`generate(...)` keeps the reference's keyword arguments, defaults and control flow (single vs per-sentence generation,
+seconds -> frames with 93.75 frames/s, RMS normalisation that only scales UP, reference trimmed by SAMPLES).  Differences:
+WAV I/O uses scipy (soundfile is not installed), playback (`AudioPlayer`, PortAudio) is out of scope, and the function
+returns the waveform (the reference returns None).  Without `output_path` nothing is played; the wave is just returned.
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import pkgutil
+import re
+import sys
+from pathlib import Path
+from typing import Literal, Optional
+
+import numpy as np
+import torch
+
+from .cfm import F5TTS
+from .utils import convert_char_to_pinyin
+
+SAMPLE_RATE = 24_000
+HOP_LENGTH = 256
+FRAMES_PER_SEC = SAMPLE_RATE / HOP_LENGTH
+TARGET_RMS = 0.1
+DEFAULT_REF_TEXT = "Some call me nature, others call me mother nature."   # generate.py:143
+
+
+def split_sentences(text):
+    """generate.py:30-36."""
+    sentence_endings = re.compile(r"([.!?;:])")
+    sentences = sentence_endings.split(text)
+    sentences = [sentences[i] + sentences[i + 1] for i in range(0, len(sentences) - 1, 2)]
+    return [sentence.strip() for sentence in sentences if sentence.strip()]
+
+
+def estimated_duration(ref_audio, ref_text: str, gen_text: str, speed: float = 1.0):
+    """generate.py:104-111 (quirk kept: the 'pause punctuation' pattern is a literal sequence, not a class)."""
+    ref_audio_len = ref_audio.shape[0] // HOP_LENGTH
+    zh_pause_punc = r"。，、；：？！"
+    ref_text_len = len(ref_text.encode("utf-8")) + 3 * len(re.findall(zh_pause_punc, ref_text))
+    gen_text_len = len(gen_text.encode("utf-8")) + 3 * len(re.findall(zh_pause_punc, gen_text))
+    duration_in_frames = ref_audio_len + int(ref_audio_len / ref_text_len * gen_text_len / speed)
+    print(f"Got estimated duration: {duration_in_frames / FRAMES_PER_SEC}")
+    return duration_in_frames / FRAMES_PER_SEC
+
+
+def read_wav(path_or_bytes):
+    """float64 samples in [-1, 1) + sample rate (what `soundfile.read` returns for PCM16/float WAVs)."""
+    import io
+    import scipy.io.wavfile as wf
+    src = io.BytesIO(path_or_bytes) if isinstance(path_or_bytes, (bytes, bytearray)) else path_or_bytes
+    sr, a = wf.read(src)
+    if a.dtype == np.int16:
+        a = a.astype(np.float64) / 32768.0
+    elif a.dtype == np.int32:
+        a = a.astype(np.float64) / 2147483648.0
+    elif a.dtype == np.uint8:
+        a = (a.astype(np.float64) - 128.0) / 128.0
+    else:
+        a = a.astype(np.float64)
+    if a.ndim > 1:
+        a = a[:, 0]
+    return a, sr
+
+
+def write_wav(path, wave: np.ndarray, sample_rate: int = SAMPLE_RATE) -> None:
+    import scipy.io.wavfile as wf
+    wf.write(path, sample_rate, np.asarray(wave, dtype=np.float32))
+
+
+def generate(
+    generation_text: str,
+    duration: Optional[float] = None,
+    estimate_duration: bool = False,
+    model_name: str = "lucasnewman/f5-tts-mlx",
+    ref_audio_path: Optional[str] = None,
+    ref_audio_text: Optional[str] = None,
+    steps: int = 8,
+    method: Literal["euler", "midpoint"] = "rk4",
+    cfg_strength: float = 2.0,
+    sway_sampling_coef: float = -1.0,
+    speed: float = 1.0,  # used when duration is None as part of the duration heuristic
+    seed: Optional[int] = None,
+    quantization_bits: Optional[int] = None,
+    output_path: Optional[str] = None,
+    f5tts: Optional[F5TTS] = None,          # extension: reuse an already loaded model
+):
+    if f5tts is None:
+        f5tts = F5TTS.from_pretrained(model_name, quantization_bits=quantization_bits)
+
+    if ref_audio_path is None:
+        data = pkgutil.get_data("f5_tts_mlx_amd", "assets/test_en_1_ref_short.wav")   # generate.py:133-143
+        audio, sr = read_wav(data)
+        ref_audio_text = DEFAULT_REF_TEXT
+    else:
+        audio, sr = read_wav(ref_audio_path)
+        if sr != SAMPLE_RATE:
+            raise ValueError("Reference audio must have a sample rate of 24kHz")
+
+    audio = torch.from_numpy(np.asarray(audio)).to(torch.float32)
+    ref_audio_duration = audio.shape[0] / SAMPLE_RATE
+    print(f"Got reference audio with duration: {ref_audio_duration:.2f} seconds")
+
+    rms = torch.sqrt(torch.mean(torch.square(audio)))
+    if rms < TARGET_RMS:
+        audio = audio * TARGET_RMS / rms
+
+    sentences = split_sentences(generation_text)
+    is_single_generation = len(sentences) <= 1 or duration is not None
+
+    def run(text_for_model, dur):
+        wave, _ = f5tts.sample(audio[None], text=text_for_model, duration=dur, steps=steps, method=method, speed=speed,
+                               cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, seed=seed)
+        wave = wave.reshape(-1) if wave.ndim > 1 and wave.shape[0] == 1 else wave
+        return wave[audio.shape[0]:]                                  # trim the reference by SAMPLES (generate.py:183)
+
+    start_date = datetime.datetime.now()
+    if is_single_generation:
+        if duration is not None:
+            duration = int(duration * FRAMES_PER_SEC)
+        elif estimate_duration:
+            duration = int(estimated_duration(audio, ref_audio_text, generation_text, speed) * FRAMES_PER_SEC)
+        text = convert_char_to_pinyin([ref_audio_text + " " + generation_text])
+        wave = run(text, duration)
+    else:
+        output = []
+        for sentence_text in sentences:
+            if duration is not None:
+                duration = int(duration * FRAMES_PER_SEC)
+            elif estimate_duration:                                   # quirk kept: uses the WHOLE text (generate.py:208)
+                duration = int(estimated_duration(audio, ref_audio_text, generation_text, speed) * FRAMES_PER_SEC)
+            text = convert_char_to_pinyin([ref_audio_text + " " + sentence_text])
+            output.append(run(text, duration))
+        wave = torch.cat(output, dim=0)
+
+    if wave.is_cuda:
+        torch.cuda.synchronize()
+    generated_duration = wave.shape[0] / SAMPLE_RATE
+    print(f"Generated {generated_duration:.2f}s of audio in {datetime.datetime.now() - start_date}.")
+
+    if output_path is not None:
+        write_wav(output_path, wave.detach().cpu().numpy(), SAMPLE_RATE)
+    return wave
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="Generate audio from text using f5-tts on MI355X")
+    parser.add_argument("--model", type=str, default="lucasnewman/f5-tts-mlx", help="Name or local path of the model to use")
+    parser.add_argument("--text", type=str, default=None, help="Text to generate speech from (leave blank to input via stdin)")
+    parser.add_argument("--duration", type=float, default=None, help="Duration of the generated audio in seconds")
+    parser.add_argument("--estimate-duration", type=bool, default=False, help="Estimate duration from the reference audio")
+    parser.add_argument("--ref-audio", type=str, default=None, help="Path to the reference audio file")
+    parser.add_argument("--ref-text", type=str, default=None, help="Text spoken in the reference audio")
+    parser.add_argument("--output", type=str, default=None, help="Path to save the generated audio output")
+    parser.add_argument("--steps", type=int, default=8, help="Number of steps to take when sampling the neural ODE")
+    parser.add_argument("--method", type=str, default="rk4", choices=["euler", "midpoint", "rk4"], help="ODE method")
+    parser.add_argument("--cfg", type=float, default=2.0, help="Strength of classifer free guidance")
+    parser.add_argument("--sway-coef", type=float, default=-1.0, help="Coefficient for sway sampling")
+    parser.add_argument("--speed", type=float, default=1.0, help="Speed factor for the duration heuristic")
+    parser.add_argument("--seed", type=int, default=None, help="Seed for noise generation")
+    parser.add_argument("--q", type=int, default=None, choices=[4, 8], help="(MLX-only) quantized checkpoints")
+    args = parser.parse_args(argv)
+
+    if args.text is None:
+        if not sys.stdin.isatty():
+            args.text = sys.stdin.read()
+        else:
+            print("Please enter the text to generate:")
+            args.text = input("> ")
+
+    generate(generation_text=args.text, duration=args.duration, estimate_duration=args.estimate_duration, model_name=args.model,
+             ref_audio_path=args.ref_audio, ref_audio_text=args.ref_text, steps=args.steps, method=args.method,
+             cfg_strength=args.cfg, sway_sampling_coef=args.sway_coef, speed=args.speed, seed=args.seed,
+             quantization_bits=args.q, output_path=args.output)
+
+
+if __name__ == "__main__":
+    main()

@@ -137,6 +137,23 @@ int f5_op_skinny_gemm(const float* a, const float* w, const float* b, float* out
 int f5_op_cfg_axpy(const float* pred, const float* null_pred, float cfg, const float* base, const float* dt_dev, float coef,
                    float divisor, float* out, void* xin_hi, void* xin_lo, int rows, int mel_dim, void* stream);
 
+/* x += gate[col] * ((A W^T + bias) * keep[row])  (dit.py:319,323; also Vocos' layer-scale + residual) */
+int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                          const float* gate, const uint8_t* rowkeep, float* x, int M, int N, int K, int lda, int ldw, int ldx,
+                          int nseg, void* stream);
+/* nn.LayerNorm with affine parameters, eps 1e-6; fp32 and/or bf16 (hi, lo) outputs (any may be NULL) */
+int f5_op_layernorm(const float* x, const float* w, const float* b, float* out_f32, void* out_hi, void* out_lo, int rows,
+                    int dim, void* stream);
+/* im2col for Conv1d(k=7, pad=3), channels-last input with <= 128 channels -> bf16 [rows][7*128] */
+int f5_op_im2col7(const float* x, void* out_hi, void* out_lo, int nbatch, int seq_len, int channels, void* stream);
+/* Vocos ISTFT head (vocos_mlx Vocos.decode tail, cfm.py:399-400): x [nframes][ldx>=1026] (log-mag | phase) ->
+ * wave [hop*(nframes-1)]; frames_scratch [nframes][1024] */
+int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scratch, float* wave, int nframes, int n_fft,
+                int hop, void* stream);
+
+/* debug / benchmarking hook: force the GEMM block tile (0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64) */
+int f5_debug_set_gemm_tile(int sel);
+
 /* ---- audio (audio.py:115-210; vocoder = vocos_mlx, third party) -------------------------------- */
 /* log-mel spectrogram of one waveform: wave dev [L] fp32 -> out dev [L/256][n_mels] */
 int f5_mel_spectrogram(const float* wave, int64_t L, const float* window, const float* filterbank, int n_fft, int hop,

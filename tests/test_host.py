@@ -190,3 +190,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(E, "_LIB_PATH", tmp_path / "nope.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         E.load_library()
+
+
+# ---- generate() host pieces (generate.py:30-36, 104-111, 154-163) -------------------------------------
+def test_generate_helpers(tmp_path):
+    from f5_tts_mlx_amd import generate as G
+    assert G.split_sentences("Hello there. How are you? Fine") == ["Hello there.", "How are you?"]   # trailing fragment dropped
+    assert G.split_sentences("no punctuation") == []
+    assert G.FRAMES_PER_SEC == 93.75 and int(10.0 * G.FRAMES_PER_SEC) == 937
+    audio = torch.zeros(256 * 40)
+    d = G.estimated_duration(audio, "abcd", "abcdefgh", speed=1.0)
+    assert abs(d - (40 + int(40 / 4 * 8)) / 93.75) < 1e-9
+    a, sr = G.read_wav(os.path.join(ASSETS, "test_en_1_ref_short.wav"))
+    assert sr == 24000 and a.dtype == np.float64 and a.shape == (127987,) and abs(np.sqrt(np.mean(a ** 2)) - 0.12888) < 1e-4
+    p = tmp_path / "o.wav"
+    G.write_wav(str(p), np.linspace(-0.5, 0.5, 1000, dtype=np.float32))
+    b, sr2 = G.read_wav(str(p))
+    assert sr2 == 24000 and np.allclose(b, np.linspace(-0.5, 0.5, 1000), atol=1e-6)
+    assert G.DEFAULT_REF_TEXT == "Some call me nature, others call me mother nature."

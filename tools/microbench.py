@@ -78,6 +78,12 @@ def ln_case(rows, dim):
 
 
 if __name__ == "__main__":
+    for tile in (1, 2, 3):
+        lib.f5_debug_set_gemm_tile(tile)
+        for (N, K, epi) in ((3072, 1024, 1), (1024, 1024, 0), (2048, 1024, 2), (1024, 2048, 0)):
+            print("tile", tile, end=" ")
+            gemm_case(1874, N, K, epi, 1)
+    lib.f5_debug_set_gemm_tile(0)
     for M in (1874, 7496, 59968):
         for (N, K, epi) in ((3072, 1024, 1), (1024, 1024, 0), (2048, 1024, 2), (1024, 2048, 0)):
             gemm_case(M, N, K, epi, 1)
