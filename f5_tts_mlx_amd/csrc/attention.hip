@@ -209,6 +209,216 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
     }
 }
 
+// =================================================================================================
+// v2: same math / layouts, but K and V^T tiles go HBM -> LDS with global_load_lds into a ring of NST
+// tiles (3 for bf16: two tiles in flight while one is consumed; 2 for bf16x3), counted vmcnt, ONE barrier per
+// tile, no staging VGPRs (=> 3 workgroups per CU for bf16).  LDS images are lane-linear 128-byte rows, so the
+// 16-byte XOR swizzle chunk ^= (row>>1)&7 is applied to the SOURCE address and again on every read.  The
+// O rescale is skipped when no lane's running max moved (exact: alpha == 1 for every lane).
+// =================================================================================================
+__device__ __forceinline__ void attn_glds16(const bf16_t* gptr, bf16_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
+}
+__device__ __forceinline__ int attn_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+template <bool HP>
+__global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p) {
+    constexpr int NP = HP ? 2 : 1;
+    constexpr int NST = HP ? 2 : 3;
+    constexpr int TILE = 64 * 64;                       // elements per K or V^T tile image
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NST * NP * 2 * TILE];   // [stage][part][K | V^T][64*64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lq = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
+    const int ntile = (kvlen + 63) >> 6;
+    const size_t rowbase = (size_t)b * p.seq_len;
+
+    bf16x8 qf[NP][4];
+    {
+        int qr = q0 + lq;
+        if (qr > p.seq_len - 1) qr = p.seq_len - 1;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                qf[pp][ks] = *reinterpret_cast<const bf16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+    }
+
+    // staging: 2 chunks of K and 2 of V^T per thread and part; linear chunk q_ = i*256 + tid of the [64][8] image
+    int srow[2], schunk[2], ldsoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q_ = i * 256 + tid;
+        srow[i] = q_ >> 3;
+        schunk[i] = (q_ & 7) ^ ((srow[i] >> 1) & 7);
+        ldsoff[i] = (i * 256 + wave * 64) * 8;
+    }
+#define A2_ISSUE(j_)                                                                                         \
+    {                                                                                                        \
+        const int key0_ = (j_) * 64;                                                                         \
+        bf16_t* st_ = smem + ((j_) % NST) * (NP * 2 * TILE);                                                 \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            int key_ = key0_ + srow[i];                                                                      \
+            if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                                  \
+            _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                              \
+                attn_glds16(p.qk[pp] + (rowbase + key_) * p.ldqk + p.dmodel + h * 64 + schunk[i] * 8,        \
+                            st_ + (pp * 2) * TILE + ldsoff[i]);                                              \
+                attn_glds16(p.vt[pp] + ((size_t)bh * 64 + srow[i]) * p.npad + key0_ + schunk[i] * 8,         \
+                            st_ + (pp * 2 + 1) * TILE + ldsoff[i]);                                          \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        o[0][e] = 0.0f;
+        o[1][e] = 0.0f;
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    A2_ISSUE(0);
+    if (NST == 3 && ntile > 1) A2_ISSUE(1);
+
+    for (int j = 0; j < ntile; ++j) {
+        // wait for tile j (own loads), then make every wave's part visible; tile j+1 may stay in flight (NST == 3)
+        if (NST == 3 && j + 1 < ntile) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + NST - 1 < ntile) A2_ISSUE(j + NST - 1);   // slot consumed in iteration j-1: every wave is past it
+
+        const bf16_t* st = smem + (j % NST) * (NP * 2 * TILE);
+        const bf16_t* sK = st;
+        const bf16_t* sV = st + TILE;
+        const bf16_t* sKl = st + (NP - 1) * 2 * TILE;
+        const bf16_t* sVl = st + (NP - 1) * 2 * TILE + TILE;
+
+        f32x16 s[2];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kb][e] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = attn_swz(kb * 32 + lq, ks * 2 + hi);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sK[off]);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[kb], 0, 0, 0);
+                if (HP) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sKl[off]);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[0][ks], s[kb], 0, 0, 0);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+
+        const int key0 = j * 64;
+        if (key0 + 64 > kvlen) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= kvlen) s[kb][r] = -INFINITY;
+                }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        if (__any(tmax > m_run)) {          // wave-uniform: rescale only when some lane's running max moved
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o[0][e] *= alpha;
+                o[1][e] *= alpha;
+            }
+        }
+        const float mc = m_run * c2;
+        float psum = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
+                s[kb][r] = pv;
+                psum += pv;
+            }
+        l_run += psum;
+
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ++ks4) {
+            const int kb = ks4 >> 1, sp = ks4 & 1;
+            uint32_t pw[4], pwl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p0 = s[kb][8 * sp + 2 * e], p1 = s[kb][8 * sp + 2 * e + 1];
+                pw[e] = f5_pack2(p0, p1);
+                if (HP) pwl[e] = f5_pack2_lo(p0, p1);
+            }
+            const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+            bf16x8 pbl = pb;
+            if (HP) pbl = __builtin_bit_cast(bf16x8, u32x4{pwl[0], pwl[1], pwl[2], pwl[3]});
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int row = db * 32 + lq;
+                const int o0 = attn_swz(row, 2 * ks4) + hi * 4, o1 = attn_swz(row, 2 * ks4 + 1) + hi * 4;
+                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&sV[o0]);
+                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&sV[o1]);
+                const bf16x8 a = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                if (HP) {
+                    const bf16x4 w0 = *reinterpret_cast<const bf16x4*>(&sVl[o0]);
+                    const bf16x4 w1 = *reinterpret_cast<const bf16x4*>(&sVl[o1]);
+                    const bf16x8 al = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pb, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pbl, o[db], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + lq;
+    if (qr < p.seq_len) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = db * 32 + 8 * rg + 4 * hi;
+                const float v0 = o[db][rg * 4 + 0] * inv, v1 = o[db][rg * 4 + 1] * inv;
+                const float v2 = o[db][rg * 4 + 2] * inv, v3 = o[db][rg * 4 + 3] * inv;
+                const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
+                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+                if (HP && p.out[1])
+                    *reinterpret_cast<u32x2*>(p.out[1] + off) = u32x2{f5_pack2_lo(v0, v1), f5_pack2_lo(v2, v3)};
+            }
+    }
+}
+
+int f5_attn_version = 2;   // 1 = register-staged kernel, 2 = global_load_lds ring (default)
+
 int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     F5_REQUIRE(a.B > 0 && a.H > 0 && a.seq_len > 0, "attention: bad shape");
     F5_REQUIRE(a.npad % 64 == 0 && a.npad >= a.seq_len, "attention: npad must be a multiple of 64 and >= seq_len");
@@ -217,9 +427,11 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     dim3 grid(f5_cdiv(a.seq_len, 128), a.B * a.H);
     if (a.hp) {
         F5_REQUIRE(a.qk[1] && a.vt[1] && a.out[1], "attention: bf16x3 needs lo buffers");
-        hipLaunchKernelGGL((f5_attn_kernel<true>), grid, dim3(256), 0, stream, a);
+        if (f5_attn_version == 2) hipLaunchKernelGGL((f5_attn2_kernel<true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((f5_attn_kernel<true>), grid, dim3(256), 0, stream, a);
     } else {
-        hipLaunchKernelGGL((f5_attn_kernel<false>), grid, dim3(256), 0, stream, a);
+        if (f5_attn_version == 2) hipLaunchKernelGGL((f5_attn2_kernel<false>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((f5_attn_kernel<false>), grid, dim3(256), 0, stream, a);
     }
     F5_LAUNCH_CHECK();
     return 0;

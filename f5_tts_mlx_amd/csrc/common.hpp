@@ -72,15 +72,21 @@ __device__ inline uint32_t f5_pack2_lo(float a, float b) {
 
 // ---- activations (MLX semantics, see oracle/f5_oracle.py) ------------------------------------
 __device__ inline float f5_silu(float x) { return x / (1.0f + __expf(-x)); }
+// tanh-approximated GELU (nn.GELU(approx="tanh"), dit.py:94,309):  0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),
+// u = sqrt(2/pi) (x + 0.044715 x^3).  One v_exp_f32 + one v_rcp_f32 instead of a libm tanhf (~40 instructions);
+// relative error ~2e-7 (rcp + exp2 ulp), exact limits (exp -> inf gives 0, exp -> 0 gives x).
 __device__ inline float f5_gelu_tanh(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+    const float u = k0 * (x + k1 * x * x * x);
+    const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * u);   // exp(-2u)
+    return x * __builtin_amdgcn_rcpf(1.0f + t);
 }
 __device__ inline float f5_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+// Mish (nn.Mish, dit.py:35,37): x tanh(softplus(x)); with w = e^x: tanh(log(1+w)) = (w^2 + 2w) / (w^2 + 2w + 2)
 __device__ inline float f5_mish(float x) {
-    float sp = (x > 20.0f) ? x : log1pf(expf(x));
-    return x * tanhf(sp);
+    const float w = __builtin_amdgcn_exp2f(1.4426950408889634f * fminf(x, 30.0f));
+    const float n = w * (w + 2.0f);
+    return x * n * __builtin_amdgcn_rcpf(n + 2.0f);
 }
 
 // ---- wave helpers ----------------------------------------------------------------------------

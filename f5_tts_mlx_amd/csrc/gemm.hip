@@ -252,6 +252,389 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
     gemm_epilogue<EPI, MB, NB>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// =================================================================================================
+// v2: 256x256x64 block tile, 512 threads = 8 waves (2 x 4), wave tile 128x64 = 4x2 accumulators of
+// v_mfma_f32_32x32x16_bf16 (128 acc registers).  Operands go HBM -> LDS directly with
+// global_load_lds (16 B per lane, no VGPR staging); the LDS image of each 128-row half tile is
+// lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address and again on the read
+// (CDNA4 guide rule 21).  LDS = 2 K-tiles x 4 half tiles (A0,A1,B0,B1) x 16 KB = 128 KB, one
+// workgroup per CU.  A K-tile is consumed in 4 phases (one 64x32 C quadrant x K=64 = 8 MFMAs each);
+// every phase also issues ONE half tile (2 global_load_lds per lane) of a future K-tile into the
+// slot whose last reader finished a phase earlier:
+//     tile t, phase 1: A0(t+1)   phase 2: A1(t+1)   phase 3: B0(t+2)   phase 4: B1(t+2)
+// (B halves are last read in phase 2, A halves in phase 3).  Waits are COUNTED: at the end of a
+// K-tile `s_waitcnt vmcnt(4)` retires everything except the two B halves issued for tile t+2, which
+// stay in flight across the barrier.  Barriers: end of phases 2, 3 (WAR on the slots about to be
+// overwritten) and 4 (RAW for the next tile).
+// =================================================================================================
+#define V2_HALF_ELEMS (128 * BK)
+
+__device__ __forceinline__ void glds16(const bf16_t* gptr, bf16_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
+}
+
+// ---- v2 epilogue for bf16 outputs: stage the wave's 128x64 tile through its private 16 KB of LDS so that
+// HBM sees 16-byte stores in full 128-byte row segments (the MFMA C layout would otherwise emit 2-byte stores).
+// Row-major outputs (FF1 / q / k / plain bf16): 32-row passes, [32][72] hi + [32][72] lo per pass.
+// V (QKV columns >= 2*dmodel) is written TRANSPOSED, Vt[(b*H+h)*64+d][n]: the tile is staged [d][token] and
+// stored along the token axis; 16-byte stores may be 2-byte aligned (legal on gfx950, tools/probes/unaligned.hip)
+// and are split element-wise where a chunk crosses a batch-element boundary.
+#define EP_LD 72
+template <int EPI>
+__device__ __forceinline__ void gemm256_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[4][2], bf16_t* reg, int m0, int n0,
+                                                      int wm, int wn, int lane) {
+    const int hi = lane >> 5, lcol = lane & 31;
+    const int colbase = n0 + wn * 64;                 // 64 columns = one head of q, k or v
+    const bool two = (EPI == EPI_QKV_ROPE) ? (p.out_bf[1] != nullptr) : (p.out_bf[1] != nullptr);
+    float bcol[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
+    const bool is_v = (EPI == EPI_QKV_ROPE) && (colbase >= 2 * p.dmodel);
+
+    if (!is_v) {
+        bf16_t* rh = reg;
+        bf16_t* rl = reg + 32 * EP_LD;
+#pragma unroll
+        for (int mb4 = 0; mb4 < 4; ++mb4) {
+            const int rowblk = m0 + wm * 128 + mb4 * 32;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                // rope cos/sin for this lane's 4 rows x 2 column blocks (global loads never alias the LDS stores below)
+                float rc[4][2], rs[4][2];
+                if (EPI == EPI_QKV_ROPE) {
+                    const int rowbase = rowblk + rg * 8 + hi * 4;
+                    const int nbase = rowbase % p.seq_len;
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri) {
+                        int n = nbase + ri;
+                        if (n >= p.seq_len) n -= p.seq_len;
+                        const bool ok = rowbase + ri < p.M;
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const int j = ((nb * 32 + lcol) & 63) >> 1;
+                            rc[ri][nb] = ok ? p.rope_cos[n * 32 + j] : 1.0f;
+                            rs[ri][nb] = ok ? p.rope_sin[n * 32 + j] : 0.0f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    const int r = rg * 4 + ri;
+                    const int lrow = ri + 8 * rg + 4 * hi;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        float v = acc[mb4][nb][r] + bcol[nb];
+                        if (EPI == EPI_GELU_TANH) v = f5_gelu_tanh(v);
+                        if (EPI == EPI_GELU_ERF_BF16) v = f5_gelu_erf(v);
+                        if (EPI == EPI_QKV_ROPE) {
+                            const float partner = __shfl_xor(v, 1, 64);
+                            v = (lcol & 1) ? (v * rc[ri][nb] + partner * rs[ri][nb]) : (v * rc[ri][nb] - partner * rs[ri][nb]);
+                        }
+                        bf16_t h, l;
+                        f5_split(v, h, l);
+                        rh[lrow * EP_LD + nb * 32 + lcol] = h;
+                        if (two) rl[lrow * EP_LD + nb * 32 + lcol] = l;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lrow = i * 8 + (lane >> 3), chunk = lane & 7;
+                const int grow = rowblk + lrow;
+                if (grow < p.M) {
+                    const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
+                    *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * EP_LD + chunk * 8]);
+                    if (two)
+                        *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * EP_LD + chunk * 8]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // ---- V: transposed staging, [64 d][64 tokens (+8 pad)] per pass, hi then lo
+        const int head = (colbase - 2 * p.dmodel) >> 6;
+        const bool two_v = p.vt[1] != nullptr;
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                if (part == 1 && !two_v) break;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            float v[4];
+#pragma unroll
+                            for (int ri = 0; ri < 4; ++ri) v[ri] = acc[mq * 2 + mb][nb][rg * 4 + ri] + bcol[nb];
+                            const u32x2 pk = part == 0 ? u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])}
+                                                       : u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
+                            const int tok = mb * 32 + rg * 8 + 4 * hi;
+                            *reinterpret_cast<u32x2*>(&reg[(nb * 32 + lcol) * EP_LD + tok]) = pk;
+                        }
+                __builtin_amdgcn_wave_barrier();
+                bf16_t* dstbase = p.vt[part];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = i * 64 + lane;
+                    const int d = c >> 3, t0 = (c & 7) * 8;
+                    const int grow = m0 + wm * 128 + mq * 64 + t0;
+                    if (grow < p.M) {
+                        const int b = grow / p.seq_len;
+                        const int n = grow - b * p.seq_len;
+                        const u32x4 val = *reinterpret_cast<const u32x4*>(&reg[d * EP_LD + t0]);
+                        bf16_t* dst = dstbase + ((size_t)(b * p.heads + head) * 64 + d) * p.npad + n;
+                        if (n + 8 <= p.seq_len && grow + 8 <= p.M) {
+                            *reinterpret_cast<u32x4*>(dst) = val;       // may be only 2-byte aligned: legal on gfx950
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const int g2 = grow + e;
+                                if (g2 < p.M) {
+                                    const int b2 = g2 / p.seq_len, n2 = g2 - b2 * p.seq_len;
+                                    const u16 bits = (u16)(val[e >> 1] >> (16 * (e & 1)));
+                                    reinterpret_cast<u16*>(dstbase)[((size_t)(b2 * p.heads + head) * 64 + d) * p.npad + n2] = bits;
+                                }
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+// ---- v2 epilogue for  x += gate * ((acc + bias) * keep)  (dit.py:319,323): the wave's tile is staged as fp32
+// [32 rows][68] per pass so that the read-modify-write of the residual stream uses 16-byte accesses.
+#define EPF_LD 68
+__device__ __forceinline__ void gemm256_epilogue_resid(const F5GemmArgs& p, f32x16 (&acc)[4][2], float* reg, int m0, int n0,
+                                                       int wm, int wn, int lane) {
+    const int hi = lane >> 5, lcol = lane & 31;
+    const int colbase = n0 + wn * 64;
+    float bcol[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
+    const int chunk = lane & 15;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gate + colbase + chunk * 4);
+#pragma unroll
+    for (int mb4 = 0; mb4 < 4; ++mb4) {
+        const int rowblk = m0 + wm * 128 + mb4 * 32;
+        // residual values + row masks first (global loads), then LDS round trip, then stores
+        f32x4 xr[8];
+        float kp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int grow = rowblk + i * 4 + (lane >> 4);
+            const bool ok = grow < p.M;
+            xr[i] = ok ? *reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4)
+                       : f32x4{0.f, 0.f, 0.f, 0.f};
+            kp[i] = (ok && p.rowkeep != nullptr) ? (float)p.rowkeep[grow] : 1.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) reg[lrow * EPF_LD + nb * 32 + lcol] = acc[mb4][nb][r] + bcol[nb];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lrow = i * 4 + (lane >> 4);
+            const int grow = rowblk + lrow;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&reg[lrow * EPF_LD + chunk * 4]);
+            if (grow < p.M) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = xr[i][e] + g4[e] * (v[e] * kp[i]);
+                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4) = o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * V2_HALF_ELEMS];   // [dbuf][A0,A1,B0,B1][128*64]
+
+    const int bid = blockIdx.x;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // ---- staging addresses: 2 chunks per thread per half tile -----------------------------------
+    // linear chunk q_ = j*512 + tid of the [128][8] half-tile image; row = q_>>3, slot = q_&7,
+    // source chunk = slot ^ ((row>>1)&7)
+    size_t srcA[2][2], srcB[2][2];   // [half][j] element offsets (without k0)
+    int ldsoff[2];                   // [j] element offset of this WAVE's 1 KB destination inside a half tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q_ = j * 512 + tid;
+        const int row = q_ >> 3, slot = q_ & 7;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        ldsoff[j] = (j * 512 + wave * 64) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int gr = m0 + h * 128 + row;
+            if (gr > p.M - 1) gr = p.M - 1;
+            if (p.a_row_mod > 0) gr = gr % p.a_row_mod;
+            srcA[h][j] = (size_t)gr * p.lda + chunk * 8;
+            srcB[h][j] = (size_t)(n0 + h * 128 + row) * p.ldw + chunk * 8;
+        }
+    }
+
+    const int kt = p.K / BK;
+    const int T = kt * p.nseg;
+
+    // issue one half tile (A half h / B half h) of K-tile `tt` into its slot (slots: A0,A1,B0,B1 per K-tile parity)
+#define V2_ISSUE_A(tt_, h_)                                                                         \
+    {                                                                                               \
+        const int seg_ = (tt_) / kt;                                                                \
+        const int k0_ = ((tt_) - seg_ * kt) * BK;                                                   \
+        bf16_t* dst_ = smem + (((tt_) & 1) * 4 + (h_)) * V2_HALF_ELEMS;                             \
+        const bf16_t* Ap_ = (seg_ == 1) ? p.A[1] : p.A[0];                                          \
+        glds16(Ap_ + srcA[(h_)][0] + k0_, dst_ + ldsoff[0]);                                        \
+        glds16(Ap_ + srcA[(h_)][1] + k0_, dst_ + ldsoff[1]);                                        \
+    }
+#define V2_ISSUE_B(tt_, h_)                                                                         \
+    {                                                                                               \
+        const int seg_ = (tt_) / kt;                                                                \
+        const int k0_ = ((tt_) - seg_ * kt) * BK;                                                   \
+        bf16_t* dst_ = smem + (((tt_) & 1) * 4 + 2 + (h_)) * V2_HALF_ELEMS;                         \
+        const bf16_t* Wp_ = (seg_ == 2) ? p.W[1] : p.W[0];                                          \
+        glds16(Wp_ + srcB[(h_)][0] + k0_, dst_ + ldsoff[0]);                                        \
+        glds16(Wp_ + srcB[(h_)][1] + k0_, dst_ + ldsoff[1]);                                        \
+    }
+#define V2_BARRIER()                                   \
+    {                                                  \
+        asm volatile("" ::: "memory");                 \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // ---- prologue: tile 0 (4 halves) + B halves of tile 1 -----------------------------------------
+    V2_ISSUE_A(0, 0);
+    V2_ISSUE_A(0, 1);
+    V2_ISSUE_B(0, 0);
+    V2_ISSUE_B(0, 1);
+    if (T > 1) {
+        V2_ISSUE_B(1, 0);
+        V2_ISSUE_B(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    V2_BARRIER();
+
+    const int frow = lane & 31;
+    const int fk = lane >> 5;
+    // fragment read offsets inside a half tile (elements): row r, chunk c -> r*64 + ((c ^ ((r>>1)&7))<<3)
+    for (int tt = 0; tt < T; ++tt) {
+        const bf16_t* base = smem + (tt & 1) * 4 * V2_HALF_ELEMS;
+        const bf16_t* sA = base + wm * V2_HALF_ELEMS;                  // this wave's A half (128 rows)
+        const bf16_t* sB = base + (2 + (wn >> 1)) * V2_HALF_ELEMS;     // this wave's B half
+        const int brow0 = (wn & 1) * 64;
+        bf16x8 af[2][4], bfr[2][4];
+
+        // ---- phase 1: A(mq=0), B(nq=0); quadrant (0,0); issue A0(t+1)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(mb * 32 + frow, ks * 2 + fk)]);
+            bfr[0][ks] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(brow0 + frow, ks * 2 + fk)]);
+        }
+        if (tt + 1 < T) V2_ISSUE_A(tt + 1, 0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[0][ks], acc[mb][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- phase 2: B(nq=1); quadrant (0,1); issue A1(t+1)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bfr[1][ks] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(brow0 + 32 + frow, ks * 2 + fk)]);
+        if (tt + 1 < T) V2_ISSUE_A(tt + 1, 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[1][ks], acc[mb][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        V2_BARRIER();   // every wave has finished reading the B halves of this tile
+
+        // ---- phase 3: A(mq=1); quadrant (1,1); issue B0(t+2)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(64 + mb * 32 + frow, ks * 2 + fk)]);
+        if (tt + 2 < T) V2_ISSUE_B(tt + 2, 0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                acc[2 + mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[1][ks], acc[2 + mb][1], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        V2_BARRIER();   // every wave has finished reading the A halves of this tile
+
+        // ---- phase 4: quadrant (1,0) from registers; issue B1(t+2)
+        if (tt + 2 < T) V2_ISSUE_B(tt + 2, 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                acc[2 + mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[0][ks], acc[2 + mb][0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        // next tile's operands: everything but the two B halves just issued for tile t+2 must have landed
+        if (tt + 2 < T) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        V2_BARRIER();
+    }
+
+    if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
+        gemm256_epilogue_bf16<EPI>(p, acc, smem + wave * 8192, m0, n0, wm, wn, lane);
+    } else if (EPI == EPI_RESID_GATE) {
+        gemm256_epilogue_resid(p, acc, reinterpret_cast<float*>(smem + wave * 8192), m0, n0, wm, wn, lane);
+    } else {
+        gemm_epilogue<EPI, 4, 2>(p, acc, m0, n0, wm, wn, lane);
+    }
+}
+
+template <int EPI>
+static int launch_v2(const F5GemmArgs& a, hipStream_t stream) {
+    const int tiles_m = f5_cdiv(a.M, 256), tiles_n = a.N / 256;
+    const int ntiles = tiles_m * tiles_n;
+    hipLaunchKernelGGL((f5_gemm256_kernel<EPI>), dim3(ntiles), dim3(512), 0, stream, a, tiles_n, ntiles);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int EPI, int MB, int NB>
 static int launch_cfg(const F5GemmArgs& a, hipStream_t stream) {
     const int tiles_m = f5_cdiv(a.M, 64 * MB), tiles_n = f5_cdiv(a.N, 64 * NB);
@@ -263,13 +646,19 @@ static int launch_cfg(const F5GemmArgs& a, hipStream_t stream) {
 
 // tile shape: the largest of 128x128 / 64x128 / 64x64 that still gives the 256 CUs >= 1.5 workgroups each
 // (small-batch shapes such as M = 1874 are otherwise a fraction of one wave of tiles)
-int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64 (microbenchmarks)
+int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 v2 (microbenchmarks)
 template <int EPI>
 static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     const long t128 = (long)f5_cdiv(a.M, 128) * f5_cdiv(a.N, 128);
     const long t64x128 = (long)f5_cdiv(a.M, 64) * f5_cdiv(a.N, 128);
     int sel = f5_gemm_tile_override;
-    if (sel == 0) sel = t128 >= 384 ? 1 : (t64x128 >= 384 ? 2 : 3);
+    const long t256 = (long)f5_cdiv(a.M, 256) * (a.N / 256);
+    const bool v2ok = (a.N % 256 == 0) && (a.M >= 256);
+    if (sel == 4 || (sel == 0 && v2ok && t256 >= 512)) {
+        F5_REQUIRE(v2ok, "gemm: the 256x256 kernel needs N %% 256 == 0 and M >= 256");
+        return launch_v2<EPI>(a, stream);
+    }
+    if (sel == 0 || sel == 4) sel = t128 >= 384 ? 1 : (t64x128 >= 384 ? 2 : 3);
     if (EPI == EPI_QKV_ROPE && sel == 3) sel = 2;  // the V^T / head mapping wants >= one whole head per tile column
     if (sel == 1) return launch_cfg<EPI, 2, 2>(a, stream);
     if (sel == 2) return launch_cfg<EPI, 1, 2>(a, stream);

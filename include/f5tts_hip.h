@@ -151,8 +151,10 @@ int f5_op_im2col7(const float* x, void* out_hi, void* out_lo, int nbatch, int se
 int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scratch, float* wave, int nframes, int n_fft,
                 int hop, void* stream);
 
-/* debug / benchmarking hook: force the GEMM block tile (0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64) */
+/* debug / benchmarking hook: force the GEMM block tile (0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 global_load_lds kernel) */
 int f5_debug_set_gemm_tile(int sel);
+/* 1 = register-staged attention kernel, 2 = global_load_lds ring (default) */
+int f5_debug_set_attn_version(int v);
 
 /* ---- audio (audio.py:115-210; vocoder = vocos_mlx, third party) -------------------------------- */
 /* log-mel spectrogram of one waveform: wave dev [L] fp32 -> out dev [L/256][n_mels] */

@@ -372,3 +372,77 @@ def test_mel_fixture(lib):
     mx, mean, _ = report("mel fixture", got, ref)
     assert mean <= 1e-5 and mx <= 2e-3
     assert abs(float(got.mean()) - (-1.26651)) < 1e-4 and abs(float(got.max()) - 4.46371) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# 256x256 global_load_lds GEMM (v2) forced through the debug hook
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture
+def force_v2(lib):
+    E.check(lib.f5_debug_set_gemm_tile(4))
+    yield
+    E.check(lib.f5_debug_set_gemm_tile(0))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1000, 256, 192), (1874, 1024, 1024), (700, 768, 2048)])
+def test_gemm_v2_f32_out(lib, force_v2, M, N, K):
+    r = rng(M + N + K + 1)
+    a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+    refbf = (bf16r(a).double() @ bf16r(w).double().T) + bias.double()
+    out, _, _ = _gemm(lib, a, w, bias, 0, 1)
+    mx, _, _ = report(f"gemm256 bf16 {M}x{N}x{K} vs bf16-rounded operands", out, refbf)
+    assert mx <= 2e-4 * max(1.0, float(refbf.abs().max()))
+    ref32 = a.double() @ w.double().T + bias.double()
+    out3, _, _ = _gemm(lib, a, w, bias, 0, 3)
+    mx, _, _ = report(f"gemm256 bf16x3 {M}x{N}x{K} vs fp64", out3, ref32)
+    assert mx <= 5e-5 * max(1.0, float(ref32.abs().max()))
+
+
+def test_gemm_v2_identity_and_repeat(lib, force_v2):
+    K = 256
+    a = torch.eye(K)[:256]
+    w = (torch.arange(512 * K, dtype=torch.float32).reshape(512, K) % 251) - 100
+    for _ in range(3):   # repeated launches: the LDS ring / counted waits must not leave stale state
+        out, _, _ = _gemm(lib, a, w, None, 0, 1)
+        assert torch.equal(out, w.T.contiguous()[:256]), "v2 C tile layout / staging is wrong"
+
+
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_attention_path_with_v2_qkv(lib, force_v2, nseg):
+    _attention_case(lib, 2, 4, 300, [300, 211], nseg, seed=21)     # D = 256: QKV GEMM runs on the 256x256 kernel
+
+
+def test_attention_v1_kernel_still_correct(lib):
+    """the register-staged kernel stays selectable through the debug hook (A/B benchmarking)"""
+    E.check(lib.f5_debug_set_attn_version(1))
+    try:
+        _attention_case(lib, 2, 2, 333, [333, 100], 1, seed=5)
+        _attention_case(lib, 1, 2, 130, None, 3, seed=6)
+    finally:
+        E.check(lib.f5_debug_set_attn_version(2))
+
+
+@pytest.mark.parametrize("tile", [0, 4])
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_gemm_resid_gate(lib, tile, nseg):
+    """x += gate * ((A W^T + b) * keep[row])  (dit.py:172-173, 319, 323) on both GEMM kernels."""
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        r = rng(31 + tile)
+        M, N, K = 700, 512, 256
+        a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+        gate, x0 = randn(r, N), randn(r, M, N)
+        keep = torch.from_numpy((r.random(M) > 0.3).astype(np.uint8))
+        a_hi, a_lo = split_bf16(a.to(DEV))
+        w_hi, w_lo = split_bf16(w.to(DEV))
+        bias_d, gate_d, keep_d, x = bias.to(DEV), gate.to(DEV), keep.to(DEV), x0.to(DEV).clone()
+        E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(a_lo), P(w_hi), P(w_lo), P(bias_d), P(gate_d), P(keep_d), P(x), M, N, K, K, K,
+                                          N, nseg, stream()), "gemm_resid_gate")
+        sync()
+        aa = a.double() if nseg == 3 else bf16r(a).double()
+        ww = w.double() if nseg == 3 else bf16r(w).double()
+        ref = x0.double() + gate.double() * ((aa @ ww.T + bias.double()) * keep.double()[:, None])
+        mx, _, _ = report(f"gemm resid_gate tile={tile} nseg={nseg}", x.cpu(), ref)
+        assert mx <= (5e-5 if nseg == 3 else 2e-4) * max(1.0, float(ref.abs().max()))
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))

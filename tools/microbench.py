@@ -83,12 +83,26 @@ if __name__ == "__main__":
         for (N, K, epi) in ((3072, 1024, 1), (1024, 1024, 0), (2048, 1024, 2), (1024, 2048, 0)):
             print("tile", tile, end=" ")
             gemm_case(1874, N, K, epi, 1)
+    for M in (7496, 59968):
+        lib.f5_debug_set_gemm_tile(4)
+        for (N, K, epi) in ((3072, 1024, 1), (1024, 1024, 0), (2048, 1024, 2), (1024, 2048, 0)):
+            print("v2", end=" ")
+            gemm_case(M, N, K, epi, 1)
+    print("v2", end=" "); gemm_case(59968, 3072, 1024, 1, 3)
+    print("v2", end=" "); gemm_case(8192, 8192, 8192, 1, 1)
+    print("v2", end=" "); gemm_case(4096, 4096, 4096, 1, 1)
     lib.f5_debug_set_gemm_tile(0)
     for M in (1874, 7496, 59968):
         for (N, K, epi) in ((3072, 1024, 1), (1024, 1024, 0), (2048, 1024, 2), (1024, 2048, 0)):
             gemm_case(M, N, K, epi, 1)
     gemm_case(59968, 3072, 1024, 1, 3)
     gemm_case(8192, 8192, 8192, 1, 1)
+    for ver in (1, 2):
+        lib.f5_debug_set_attn_version(ver)
+        print("attn version", ver)
+        for B in (2, 64):
+            attn_case(B, 16, 937, 0)
+        attn_case(64, 16, 937, 1)
     for B in (2, 64):
         attn_case(B, 16, 937, 0)
     attn_case(2, 16, 937, 1)
