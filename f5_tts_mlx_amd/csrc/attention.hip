@@ -222,7 +222,9 @@ __device__ __forceinline__ void attn_glds16(const bf16_t* gptr, bf16_t* lds_wave
 }
 __device__ __forceinline__ int attn_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
-template <bool HP>
+// ABL = timing-only ablation (results are wrong unless ABL == 0): 1 no exp2, 2 no barrier/vmcnt wait, 3 no PV MFMAs,
+// 4 no S MFMAs, 5 no softmax VALU at all (debug hook f5_debug_set_attn_ablation; CDNA4 guide: ablate before optimising)
+template <bool HP, int ABL>
 __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p) {
     constexpr int NP = HP ? 2 : 1;
     constexpr int NST = HP ? 2 : 3;
@@ -289,14 +291,16 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 
     for (int j = 0; j < ntile; ++j) {
         // wait for tile j (own loads), then make every wave's part visible; tile j+1 may stay in flight (NST == 3)
-        if (NST == 3 && j + 1 < ntile) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ABL != 2) {
+            if (NST == 3 && j + 1 < ntile) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
         if (j + NST - 1 < ntile) A2_ISSUE(j + NST - 1);   // slot consumed in iteration j-1: every wave is past it
 
         const bf16_t* st = smem + (j % NST) * (NP * 2 * TILE);
@@ -315,7 +319,12 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = attn_swz(kb * 32 + lq, ks * 2 + hi);
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sK[off]);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[kb], 0, 0, 0);
+                if (ABL == 4) {
+                    asm volatile("" ::"v"(a));
+                    s[kb][ks] += (float)ks;
+                } else {
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[kb], 0, 0, 0);
+                }
                 if (HP) {
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sKl[off]);
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[0][ks], s[kb], 0, 0, 0);
@@ -336,12 +345,14 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
                 }
         }
         float tmax = -INFINITY;
+        if (ABL != 5) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        if (__any(tmax > m_run)) {          // wave-uniform: rescale only when some lane's running max moved
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        }
+        if (ABL != 5 && __any(tmax > m_run)) {          // wave-uniform: rescale only when some lane's running max moved
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
             m_run = m_new;
@@ -358,9 +369,12 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
+                float pv;
+                if (ABL == 5) pv = s[kb][r];
+                else if (ABL == 1) pv = s[kb][r] * c2 - mc;
+                else pv = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
                 s[kb][r] = pv;
-                psum += pv;
+                if (ABL != 5) psum += pv;
             }
         l_run += psum;
 
@@ -385,7 +399,12 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
                 const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&sV[o0]);
                 const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&sV[o1]);
                 const bf16x8 a = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                if (ABL == 3) {
+                    asm volatile("" ::"v"(a), "v"(pb));
+                    o[db][ks4] += 1.0f;
+                } else {
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                }
                 if (HP) {
                     const bf16x4 w0 = *reinterpret_cast<const bf16x4*>(&sVl[o0]);
                     const bf16x4 w1 = *reinterpret_cast<const bf16x4*>(&sVl[o1]);
@@ -417,7 +436,188 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
     }
 }
 
-int f5_attn_version = 2;   // 1 = register-staged kernel, 2 = global_load_lds ring (default)
+// =================================================================================================
+// v3 (bf16 only): v2 + software pipelining inside the wave.  Ablations of v2 (tools/attn_ablate.py) show that
+// QK^T MFMAs, softmax VALU and PV MFMAs each cost ~1/3 of the time and do not overlap: co-resident waves run the
+// same phase at the same time.  Here the 8 MFMAs of S(j+1) = K(j+1) Q^T are issued in the same basic block as the
+// exp2 / sum / pack of tile j (independent registers), so the matrix pipe works under the softmax of every wave.
+// Ring of 3 K/V tiles: slot j%3 feeds PV(j), slot (j+1)%3 feeds S(j+1), slot (j+2)%3 is being loaded.
+// =================================================================================================
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
+    constexpr int TILE = 64 * 64;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[3 * 2 * TILE];   // [stage][K | V^T][64*64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lq = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
+    const int ntile = (kvlen + 63) >> 6;
+    const size_t rowbase = (size_t)b * p.seq_len;
+
+    bf16x8 qf[4];
+    {
+        int qr = q0 + lq;
+        if (qr > p.seq_len - 1) qr = p.seq_len - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+    }
+    int srow[2], schunk[2], ldsoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q_ = i * 256 + tid;
+        srow[i] = q_ >> 3;
+        schunk[i] = (q_ & 7) ^ ((srow[i] >> 1) & 7);
+        ldsoff[i] = (i * 256 + wave * 64) * 8;
+    }
+#define A3_ISSUE(j_)                                                                                         \
+    {                                                                                                        \
+        const int key0_ = (j_) * 64;                                                                         \
+        bf16_t* st_ = smem + ((j_) % 3) * (2 * TILE);                                                        \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            int key_ = key0_ + srow[i];                                                                      \
+            if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                                  \
+            attn_glds16(p.qk[0] + (rowbase + key_) * p.ldqk + p.dmodel + h * 64 + schunk[i] * 8, st_ + ldsoff[i]); \
+            attn_glds16(p.vt[0] + ((size_t)bh * 64 + srow[i]) * p.npad + key0_ + schunk[i] * 8, st_ + TILE + ldsoff[i]); \
+        }                                                                                                    \
+    }
+#define A3_SCORES(dst_, slot_)                                                                               \
+    {                                                                                                        \
+        const bf16_t* sK_ = smem + (slot_) * (2 * TILE);                                                     \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                   \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) dst_[kb][e] = 0.0f;                               \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                               \
+                const bf16x8 a_ = *reinterpret_cast<const bf16x8*>(&sK_[attn_swz(kb * 32 + lq, ks * 2 + hi)]); \
+                dst_[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, qf[ks], dst_[kb], 0, 0, 0);          \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        o[0][e] = 0.0f;
+        o[1][e] = 0.0f;
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    A3_ISSUE(0);
+    if (ntile > 1) {
+        A3_ISSUE(1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x16 s[2];
+    A3_SCORES(s, 0);
+
+    for (int j = 0; j < ntile; ++j) {
+        // tile j+1 (issued one iteration ago) must have landed everywhere; the barrier also retires slot (j-1)%3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 2 < ntile) A3_ISSUE(j + 2);
+
+        // ---- running max of tile j (S(j) is complete) ------------------------------------------------
+        const int key0 = j * 64;
+        if (key0 + 64 > kvlen) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= kvlen) s[kb][r] = -INFINITY;
+                }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        if (__any(tmax > m_run)) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o[0][e] *= alpha;
+                o[1][e] *= alpha;
+            }
+        }
+        const float mc = m_run * c2;
+
+        // ---- S(j+1) MFMAs (slot (j+1)%3; stale but harmless data after the last tile) in the SAME basic block as
+        //      the exponentials of tile j: independent registers, the scheduler interleaves them
+        f32x16 sn[2];
+        A3_SCORES(sn, (j + 1) % 3);
+        float psum = 0.0f;
+        uint32_t pw[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
+                const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1] * c2 - mc);
+                psum += p0 + p1;
+                pw[kb][r >> 1] = f5_pack2(p0, p1);
+            }
+        l_run += psum;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);  // 14 VALU
+        }
+
+        // ---- O^T += V(j)^T P(j)^T ---------------------------------------------------------------------
+        const bf16_t* sV = smem + (j % 3) * (2 * TILE) + TILE;
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ++ks4) {
+            const int kb = ks4 >> 1, sp = ks4 & 1;
+            const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[kb][4 * sp], pw[kb][4 * sp + 1], pw[kb][4 * sp + 2], pw[kb][4 * sp + 3]});
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int row = db * 32 + lq;
+                const int o0 = attn_swz(row, 2 * ks4) + hi * 4, o1 = attn_swz(row, 2 * ks4 + 1) + hi * 4;
+                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&sV[o0]);
+                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&sV[o1]);
+                const bf16x8 a = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+            }
+        }
+        s[0] = sn[0];
+        s[1] = sn[1];
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + lq;
+    if (qr < p.seq_len) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = db * 32 + 8 * rg + 4 * hi;
+                const float v0 = o[db][rg * 4 + 0] * inv, v1 = o[db][rg * 4 + 1] * inv;
+                const float v2 = o[db][rg * 4 + 2] * inv, v3 = o[db][rg * 4 + 3] * inv;
+                const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
+                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+            }
+    }
+}
+
+int f5_attn_version = 3;   // 1 = register-staged, 2 = global_load_lds ring, 3 = ring + in-wave software pipelining (bf16 default)
+int f5_attn_ablation = 0;  // timing experiments only
 
 int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     F5_REQUIRE(a.B > 0 && a.H > 0 && a.seq_len > 0, "attention: bad shape");
@@ -427,10 +627,23 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     dim3 grid(f5_cdiv(a.seq_len, 128), a.B * a.H);
     if (a.hp) {
         F5_REQUIRE(a.qk[1] && a.vt[1] && a.out[1], "attention: bf16x3 needs lo buffers");
-        if (f5_attn_version == 2) hipLaunchKernelGGL((f5_attn2_kernel<true>), grid, dim3(256), 0, stream, a);
+        if (f5_attn_version >= 2) hipLaunchKernelGGL((f5_attn2_kernel<true, 0>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((f5_attn_kernel<true>), grid, dim3(256), 0, stream, a);
     } else {
-        if (f5_attn_version == 2) hipLaunchKernelGGL((f5_attn2_kernel<false>), grid, dim3(256), 0, stream, a);
+        if (f5_attn_version == 3) {
+            hipLaunchKernelGGL((f5_attn3_kernel<3>), grid, dim3(256), 0, stream, a);
+        } else if (f5_attn_version == 4) {
+            hipLaunchKernelGGL((f5_attn3_kernel<2>), grid, dim3(256), 0, stream, a);
+        } else if (f5_attn_version == 2) {
+            switch (f5_attn_ablation) {
+                case 1: hipLaunchKernelGGL((f5_attn2_kernel<false, 1>), grid, dim3(256), 0, stream, a); break;
+                case 2: hipLaunchKernelGGL((f5_attn2_kernel<false, 2>), grid, dim3(256), 0, stream, a); break;
+                case 3: hipLaunchKernelGGL((f5_attn2_kernel<false, 3>), grid, dim3(256), 0, stream, a); break;
+                case 4: hipLaunchKernelGGL((f5_attn2_kernel<false, 4>), grid, dim3(256), 0, stream, a); break;
+                case 5: hipLaunchKernelGGL((f5_attn2_kernel<false, 5>), grid, dim3(256), 0, stream, a); break;
+                default: hipLaunchKernelGGL((f5_attn2_kernel<false, 0>), grid, dim3(256), 0, stream, a); break;
+            }
+        }
         else hipLaunchKernelGGL((f5_attn_kernel<false>), grid, dim3(256), 0, stream, a);
     }
     F5_LAUNCH_CHECK();

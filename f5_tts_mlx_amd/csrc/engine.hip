@@ -849,13 +849,18 @@ extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float
 // ------------------------------------------------------------------------------------------------
 extern int f5_attn_version;
 extern "C" int f5_debug_set_attn_version(int v) {
-    F5_REQUIRE(v == 1 || v == 2, "attention version must be 1 or 2");
+    F5_REQUIRE(v >= 1 && v <= 4, "attention version must be 1..4");
     f5_attn_version = v;
+    return 0;
+}
+extern int f5_attn_ablation;
+extern "C" int f5_debug_set_attn_ablation(int v) {
+    f5_attn_ablation = v;
     return 0;
 }
 extern int f5_gemm_tile_override;
 extern "C" int f5_debug_set_gemm_tile(int sel) {
-    F5_REQUIRE(sel >= 0 && sel <= 4, "gemm tile override must be 0 (auto), 1 (128x128), 2 (64x128), 3 (64x64) or 4 (256x256)");
+    F5_REQUIRE(sel >= 0 && sel <= 6, "gemm tile override must be 0 (auto) .. 6");
     f5_gemm_tile_override = sel;
     return 0;
 }

@@ -635,6 +635,121 @@ static int launch_v2(const F5GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// =================================================================================================
+// v1r: the small-tile kernel with global_load_lds staging into a ring of NST K-tiles (NST-1 tiles in flight,
+// counted vmcnt, one barrier per K tile).  Used for small-batch shapes (M ~ 2 * 937 rows) where the chip is only
+// filled by 64x64 / 64x128 tiles and the old one-tile-deep register prefetch left every iteration latency bound.
+// =================================================================================================
+template <int EPI, int MB, int NB, int NST>
+__global__ __launch_bounds__(256) void f5_gemm_ring_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
+    constexpr int BMt = 64 * MB, BNt = 64 * NB;
+    constexpr int NA = MB * 2, NW = NB * 2;
+    constexpr int G = NA + NW;                          // global_load_lds per thread per K tile
+    constexpr int STAGE = (BMt + BNt) * BK;             // elements
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NST * STAGE];
+
+    const int bid = blockIdx.x;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BMt, n0 = tn * BNt;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    size_t a_src[NA], w_src[NW];
+    int a_dst[NA], w_dst[NW];                           // wave-uniform LDS element offsets inside a stage
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int q_ = i * 256 + tid;
+        const int row = q_ >> 3, chunk = (q_ & 7) ^ ((row >> 1) & 7);
+        int gr = m0 + row;
+        if (gr > p.M - 1) gr = p.M - 1;
+        if (p.a_row_mod > 0) gr = gr % p.a_row_mod;
+        a_src[i] = (size_t)gr * p.lda + chunk * 8;
+        a_dst[i] = (i * 256 + wave * 64) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int q_ = i * 256 + tid;
+        const int row = q_ >> 3, chunk = (q_ & 7) ^ ((row >> 1) & 7);
+        w_src[i] = (size_t)(n0 + row) * p.ldw + chunk * 8;
+        w_dst[i] = BMt * BK + (i * 256 + wave * 64) * 8;
+    }
+    const int kt = p.K / BK;
+    const int T = kt * p.nseg;
+#define RING_ISSUE(tt_)                                                                                      \
+    {                                                                                                        \
+        const int seg_ = (tt_) / kt;                                                                         \
+        const int k0_ = ((tt_) - seg_ * kt) * BK;                                                            \
+        bf16_t* st_ = smem + ((tt_) % NST) * STAGE;                                                          \
+        const bf16_t* Ap_ = (seg_ == 1) ? p.A[1] : p.A[0];                                                   \
+        const bf16_t* Wp_ = (seg_ == 2) ? p.W[1] : p.W[0];                                                   \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) glds16(Ap_ + a_src[i] + k0_, st_ + a_dst[i]);         \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i) glds16(Wp_ + w_src[i] + k0_, st_ + w_dst[i]);         \
+    }
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < T) RING_ISSUE(st);
+
+    const int frow = lane & 31;
+    const int fk = lane >> 5;
+    for (int tt = 0; tt < T; ++tt) {
+        // tile tt must have landed; up to NST-2 younger tiles may stay in flight (conservative vmcnt(0) at the tail)
+        if (tt + NST - 2 < T) {
+            if (NST == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+            else if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tt + NST - 1 < T) RING_ISSUE(tt + NST - 1);   // refills the slot consumed in iteration tt-1
+
+        const bf16_t* sA = smem + (tt % NST) * STAGE;
+        const bf16_t* sB = sA + BMt * BK;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MB], bfr[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                af[mb] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(wm * (32 * MB) + mb * 32 + frow, ks * 2 + fk)]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                bfr[nb] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(wn * (32 * NB) + nb * 32 + frow, ks * 2 + fk)]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+        }
+    }
+    gemm_epilogue<EPI, MB, NB>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int EPI, int MB, int NB>
+static int launch_ring(const F5GemmArgs& a, hipStream_t stream) {
+    const int tiles_m = f5_cdiv(a.M, 64 * MB), tiles_n = f5_cdiv(a.N, 64 * NB);
+    const int ntiles = tiles_m * tiles_n;
+    hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, NB, 4>), dim3(ntiles), dim3(256), 0, stream, a, tiles_n, ntiles);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int EPI, int MB, int NB>
 static int launch_cfg(const F5GemmArgs& a, hipStream_t stream) {
     const int tiles_m = f5_cdiv(a.M, 64 * MB), tiles_n = f5_cdiv(a.N, 64 * NB);
@@ -646,7 +761,8 @@ static int launch_cfg(const F5GemmArgs& a, hipStream_t stream) {
 
 // tile shape: the largest of 128x128 / 64x128 / 64x64 that still gives the 256 CUs >= 1.5 workgroups each
 // (small-batch shapes such as M = 1874 are otherwise a fraction of one wave of tiles)
-int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 v2 (microbenchmarks)
+int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 v2, 5 = 64x128 ring, 6 = 64x64 ring
+int f5_gemm_ring_default = 1;   // auto mode: small tiles use the global_load_lds ring kernel
 template <int EPI>
 static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     const long t128 = (long)f5_cdiv(a.M, 128) * f5_cdiv(a.N, 128);
@@ -659,8 +775,12 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
         return launch_v2<EPI>(a, stream);
     }
     if (sel == 0 || sel == 4) sel = t128 >= 384 ? 1 : (t64x128 >= 384 ? 2 : 3);
-    if (EPI == EPI_QKV_ROPE && sel == 3) sel = 2;  // the V^T / head mapping wants >= one whole head per tile column
+    if (EPI == EPI_QKV_ROPE && sel == 3) sel = 2;
+    if (EPI == EPI_QKV_ROPE && sel == 6) sel = 5;  // the V^T / head mapping wants >= one whole head per tile column
+    if (sel == 5) return launch_ring<EPI, 1, 2>(a, stream);
+    if (sel == 6) return launch_ring<EPI, 1, 1>(a, stream);
     if (sel == 1) return launch_cfg<EPI, 2, 2>(a, stream);
+    if (f5_gemm_ring_default) return sel == 2 ? launch_ring<EPI, 1, 2>(a, stream) : launch_ring<EPI, 1, 1>(a, stream);
     if (sel == 2) return launch_cfg<EPI, 1, 2>(a, stream);
     return launch_cfg<EPI, 1, 1>(a, stream);
 }

@@ -155,6 +155,8 @@ int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scra
 int f5_debug_set_gemm_tile(int sel);
 /* 1 = register-staged attention kernel, 2 = global_load_lds ring (default) */
 int f5_debug_set_attn_version(int v);
+/* timing-only ablations of the attention kernel (results are wrong unless 0) */
+int f5_debug_set_attn_ablation(int v);
 
 /* ---- audio (audio.py:115-210; vocoder = vocos_mlx, third party) -------------------------------- */
 /* log-mel spectrogram of one waveform: wave dev [L] fp32 -> out dev [L/256][n_mels] */

@@ -412,17 +412,19 @@ def test_attention_path_with_v2_qkv(lib, force_v2, nseg):
     _attention_case(lib, 2, 4, 300, [300, 211], nseg, seed=21)     # D = 256: QKV GEMM runs on the 256x256 kernel
 
 
-def test_attention_v1_kernel_still_correct(lib):
-    """the register-staged kernel stays selectable through the debug hook (A/B benchmarking)"""
-    E.check(lib.f5_debug_set_attn_version(1))
+@pytest.mark.parametrize("ver", [1, 2, 4])
+def test_attention_other_kernel_versions(lib, ver):
+    """the older kernels stay selectable through the debug hook (A/B benchmarking); default is version 3"""
+    E.check(lib.f5_debug_set_attn_version(ver))
     try:
         _attention_case(lib, 2, 2, 333, [333, 100], 1, seed=5)
         _attention_case(lib, 1, 2, 130, None, 3, seed=6)
+        _attention_case(lib, 1, 2, 937, None, 1, seed=7)
     finally:
-        E.check(lib.f5_debug_set_attn_version(2))
+        E.check(lib.f5_debug_set_attn_version(3))
 
 
-@pytest.mark.parametrize("tile", [0, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("nseg", [1, 3])
 def test_gemm_resid_gate(lib, tile, nseg):
     """x += gate * ((A W^T + b) * keep[row])  (dit.py:172-173, 319, 323) on both GEMM kernels."""
@@ -444,5 +446,24 @@ def test_gemm_resid_gate(lib, tile, nseg):
         ref = x0.double() + gate.double() * ((aa @ ww.T + bias.double()) * keep.double()[:, None])
         mx, _, _ = report(f"gemm resid_gate tile={tile} nseg={nseg}", x.cpu(), ref)
         assert mx <= (5e-5 if nseg == 3 else 2e-4) * max(1.0, float(ref.abs().max()))
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 6])
+def test_gemm_all_small_tile_kernels(lib, tile):
+    """every block-tile variant (register-staged 128x128 / 64x128 / 64x64 and the global_load_lds ring 64x128 / 64x64)"""
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        for (M, N, K) in ((1, 128, 64), (333, 384, 192), (1874, 1024, 1024), (130, 100, 2048)):
+            r = rng(M + N + K + tile)
+            a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+            refbf = (bf16r(a).double() @ bf16r(w).double().T) + bias.double()
+            out, _, _ = _gemm(lib, a, w, bias, 0, 1)
+            mx, _, _ = report(f"gemm tile={tile} {M}x{N}x{K}", out, refbf)
+            assert mx <= 2e-4 * max(1.0, float(refbf.abs().max()))
+            out3, _, _ = _gemm(lib, a, w, bias, 0, 3)
+            ref32 = a.double() @ w.double().T + bias.double()
+            assert float((out3.double() - ref32).abs().max()) <= 5e-5 * max(1.0, float(ref32.abs().max()))
     finally:
         E.check(lib.f5_debug_set_gemm_tile(0))

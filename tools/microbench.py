@@ -78,7 +78,7 @@ def ln_case(rows, dim):
 
 
 if __name__ == "__main__":
-    for tile in (1, 2, 3):
+    for tile in (2, 3, 5, 6):
         lib.f5_debug_set_gemm_tile(tile)
         for (N, K, epi) in ((3072, 1024, 1), (1024, 1024, 0), (2048, 1024, 2), (1024, 2048, 0)):
             print("tile", tile, end=" ")
