@@ -858,9 +858,33 @@ extern "C" int f5_debug_set_attn_ablation(int v) {
     f5_attn_ablation = v;
     return 0;
 }
+extern int f5_gemm_big_kernel;
+extern int f5_gemm_v3_stagger;
+extern "C" int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles) {
+    F5_REQUIRE(v == 2 || v == 3, "big GEMM kernel must be 2 (256x256) or 3 (128x256, two workgroups per CU)");
+    f5_gemm_big_kernel = v;
+    f5_gemm_v3_stagger = stagger_cycles;
+    return 0;
+}
+extern int f5_gemm_ring_default;
+extern "C" int f5_debug_set_gemm_ring(int v) {
+    f5_gemm_ring_default = v ? 1 : 0;
+    return 0;
+}
+extern int f5_gemm_order;
+extern "C" int f5_debug_set_gemm_order(int v) {
+    F5_REQUIRE(v >= 0 && v <= 2, "gemm order must be 0 (auto), 1 (n fastest) or 2 (m fastest)");
+    f5_gemm_order = v;
+    return 0;
+}
+extern int f5_gemm_debug_flags;
+extern "C" int f5_debug_set_gemm_flags(int v) {
+    f5_gemm_debug_flags = v;
+    return 0;
+}
 extern int f5_gemm_tile_override;
 extern "C" int f5_debug_set_gemm_tile(int sel) {
-    F5_REQUIRE(sel >= 0 && sel <= 6, "gemm tile override must be 0 (auto) .. 6");
+    F5_REQUIRE(sel >= 0 && sel <= 7, "gemm tile override must be 0 (auto) .. 7");
     f5_gemm_tile_override = sel;
     return 0;
 }

@@ -164,7 +164,16 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    // tile numbering: n fastest (neighbouring tiles share the A panel) or, when tiles_n < 0, m fastest with
+    // tiles_m = -tiles_n (neighbouring tiles share the W panel: better when the whole A operand fits in an XCD's L2)
+    int tm, tn;
+    if (tiles_n > 0) {
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+    } else {
+        tn = tile / (-tiles_n);
+        tm = tile - tn * (-tiles_n);
+    }
     const int m0 = tm * BMt, n0 = tn * BNt;
 
     const int tid = threadIdx.x;
@@ -274,34 +283,35 @@ __device__ __forceinline__ void glds16(const bf16_t* gptr, bf16_t* lds_wave_base
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
 
-// ---- v2 epilogue for bf16 outputs: stage the wave's 128x64 tile through its private 16 KB of LDS so that
-// HBM sees 16-byte stores in full 128-byte row segments (the MFMA C layout would otherwise emit 2-byte stores).
-// Row-major outputs (FF1 / q / k / plain bf16): 32-row passes, [32][72] hi + [32][72] lo per pass.
-// V (QKV columns >= 2*dmodel) is written TRANSPOSED, Vt[(b*H+h)*64+d][n]: the tile is staged [d][token] and
-// stored along the token axis; 16-byte stores may be 2-byte aligned (legal on gfx950, tools/probes/unaligned.hip)
-// and are split element-wise where a chunk crosses a batch-element boundary.
-#define EP_LD 72
-template <int EPI>
-__device__ __forceinline__ void gemm256_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[4][2], bf16_t* reg, int m0, int n0,
-                                                      int wm, int wn, int lane) {
+// ---- LDS-staged epilogues (used by the 256x256 and the 128x256 kernels).  A wave owns a (32*MBW) x (32*NBW) tile
+// and a private LDS region; the MFMA C layout (lane = column, registers = rows) is turned into 16-byte global accesses
+// in full row segments.  bf16 row-major outputs (FF1 / q / k / plain bf16): 32-row passes, [32][W+8] hi (+ lo).
+// V (QKV columns >= 2*dmodel) is written TRANSPOSED, Vt[(b*H+h)*64+d][n]: staged [d][64 tokens (+8)] and stored along
+// the token axis; those 16-byte stores may be only 2-byte aligned (legal on gfx950, tools/probes/unaligned.hip) and
+// are split element-wise where a chunk crosses a batch-element boundary.
+template <int EPI, int MBW, int NBW>
+__device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], bf16_t* reg, int row0,
+                                                     int colbase, int lane) {
+    constexpr int W = 32 * NBW;
+    constexpr int LD = W + 8;
+    constexpr int CPR = W / 8;             // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;          // rows per store instruction
     const int hi = lane >> 5, lcol = lane & 31;
-    const int colbase = n0 + wn * 64;                 // 64 columns = one head of q, k or v
-    const bool two = (EPI == EPI_QKV_ROPE) ? (p.out_bf[1] != nullptr) : (p.out_bf[1] != nullptr);
-    float bcol[2];
+    const bool two = p.out_bf[1] != nullptr;
+    float bcol[NBW];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
+    for (int nb = 0; nb < NBW; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
     const bool is_v = (EPI == EPI_QKV_ROPE) && (colbase >= 2 * p.dmodel);
 
     if (!is_v) {
         bf16_t* rh = reg;
-        bf16_t* rl = reg + 32 * EP_LD;
+        bf16_t* rl = reg + 32 * LD;
 #pragma unroll
-        for (int mb4 = 0; mb4 < 4; ++mb4) {
-            const int rowblk = m0 + wm * 128 + mb4 * 32;
+        for (int mb = 0; mb < MBW; ++mb) {
+            const int rowblk = row0 + mb * 32;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                // rope cos/sin for this lane's 4 rows x 2 column blocks (global loads never alias the LDS stores below)
-                float rc[4][2], rs[4][2];
+                float rc[4][NBW], rs[4][NBW];
                 if (EPI == EPI_QKV_ROPE) {
                     const int rowbase = rowblk + rg * 8 + hi * 4;
                     const int nbase = rowbase % p.seq_len;
@@ -311,7 +321,7 @@ __device__ __forceinline__ void gemm256_epilogue_bf16(const F5GemmArgs& p, f32x1
                         if (n >= p.seq_len) n -= p.seq_len;
                         const bool ok = rowbase + ri < p.M;
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) {
+                        for (int nb = 0; nb < NBW; ++nb) {
                             const int j = ((nb * 32 + lcol) & 63) >> 1;
                             rc[ri][nb] = ok ? p.rope_cos[n * 32 + j] : 1.0f;
                             rs[ri][nb] = ok ? p.rope_sin[n * 32 + j] : 0.0f;
@@ -323,8 +333,8 @@ __device__ __forceinline__ void gemm256_epilogue_bf16(const F5GemmArgs& p, f32x1
                     const int r = rg * 4 + ri;
                     const int lrow = ri + 8 * rg + 4 * hi;
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        float v = acc[mb4][nb][r] + bcol[nb];
+                    for (int nb = 0; nb < NBW; ++nb) {
+                        float v = acc[mb][nb][r] + bcol[nb];
                         if (EPI == EPI_GELU_TANH) v = f5_gelu_tanh(v);
                         if (EPI == EPI_GELU_ERF_BF16) v = f5_gelu_erf(v);
                         if (EPI == EPI_QKV_ROPE) {
@@ -333,38 +343,39 @@ __device__ __forceinline__ void gemm256_epilogue_bf16(const F5GemmArgs& p, f32x1
                         }
                         bf16_t h, l;
                         f5_split(v, h, l);
-                        rh[lrow * EP_LD + nb * 32 + lcol] = h;
-                        if (two) rl[lrow * EP_LD + nb * 32 + lcol] = l;
+                        rh[lrow * LD + nb * 32 + lcol] = h;
+                        if (two) rl[lrow * LD + nb * 32 + lcol] = l;
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int lrow = i * 8 + (lane >> 3), chunk = lane & 7;
+            for (int i = 0; i < 32 / RPI; ++i) {
+                const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
                 const int grow = rowblk + lrow;
                 if (grow < p.M) {
                     const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
-                    *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * EP_LD + chunk * 8]);
+                    *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
                     if (two)
-                        *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * EP_LD + chunk * 8]);
+                        *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
     } else {
-        // ---- V: transposed staging, [64 d][64 tokens (+8 pad)] per pass, hi then lo
-        const int head = (colbase - 2 * p.dmodel) >> 6;
+        // ---- V: transposed staging, [W d-rows][64 tokens (+8 pad)] per pass of two 32-row blocks, hi then lo
+        constexpr int TLD = 72;
+        const int head0 = (colbase - 2 * p.dmodel) >> 6;
         const bool two_v = p.vt[1] != nullptr;
 #pragma unroll
-        for (int mq = 0; mq < 2; ++mq) {
+        for (int mq = 0; mq < MBW / 2; ++mq) {
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
                 if (part == 1 && !two_v) break;
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
+                    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
                             float v[4];
@@ -373,20 +384,21 @@ __device__ __forceinline__ void gemm256_epilogue_bf16(const F5GemmArgs& p, f32x1
                             const u32x2 pk = part == 0 ? u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])}
                                                        : u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
                             const int tok = mb * 32 + rg * 8 + 4 * hi;
-                            *reinterpret_cast<u32x2*>(&reg[(nb * 32 + lcol) * EP_LD + tok]) = pk;
+                            *reinterpret_cast<u32x2*>(&reg[(nb * 32 + lcol) * TLD + tok]) = pk;
                         }
                 __builtin_amdgcn_wave_barrier();
-                bf16_t* dstbase = p.vt[part];
+                u16* dstbase = reinterpret_cast<u16*>(p.vt[part]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < W / 8; ++i) {
                     const int c = i * 64 + lane;
                     const int d = c >> 3, t0 = (c & 7) * 8;
-                    const int grow = m0 + wm * 128 + mq * 64 + t0;
+                    const int grow = row0 + mq * 64 + t0;
                     if (grow < p.M) {
                         const int b = grow / p.seq_len;
                         const int n = grow - b * p.seq_len;
-                        const u32x4 val = *reinterpret_cast<const u32x4*>(&reg[d * EP_LD + t0]);
-                        bf16_t* dst = dstbase + ((size_t)(b * p.heads + head) * 64 + d) * p.npad + n;
+                        const u32x4 val = *reinterpret_cast<const u32x4*>(&reg[d * TLD + t0]);
+                        const int head = head0 + (d >> 6), dd = d & 63;
+                        u16* dst = dstbase + ((size_t)(b * p.heads + head) * 64 + dd) * p.npad + n;
                         if (n + 8 <= p.seq_len && grow + 8 <= p.M) {
                             *reinterpret_cast<u32x4*>(dst) = val;       // may be only 2-byte aligned: legal on gfx950
                         } else {
@@ -395,8 +407,7 @@ __device__ __forceinline__ void gemm256_epilogue_bf16(const F5GemmArgs& p, f32x1
                                 const int g2 = grow + e;
                                 if (g2 < p.M) {
                                     const int b2 = g2 / p.seq_len, n2 = g2 - b2 * p.seq_len;
-                                    const u16 bits = (u16)(val[e >> 1] >> (16 * (e & 1)));
-                                    reinterpret_cast<u16*>(dstbase)[((size_t)(b2 * p.heads + head) * 64 + d) * p.npad + n2] = bits;
+                                    dstbase[((size_t)(b2 * p.heads + head) * 64 + dd) * p.npad + n2] = (u16)(val[e >> 1] >> (16 * (e & 1)));
                                 }
                             }
                         }
@@ -408,27 +419,30 @@ __device__ __forceinline__ void gemm256_epilogue_bf16(const F5GemmArgs& p, f32x1
     }
 }
 
-// ---- v2 epilogue for  x += gate * ((acc + bias) * keep)  (dit.py:319,323): the wave's tile is staged as fp32
-// [32 rows][68] per pass so that the read-modify-write of the residual stream uses 16-byte accesses.
-#define EPF_LD 68
-__device__ __forceinline__ void gemm256_epilogue_resid(const F5GemmArgs& p, f32x16 (&acc)[4][2], float* reg, int m0, int n0,
-                                                       int wm, int wn, int lane) {
+// x += gate * ((acc + bias) * keep)  (dit.py:319,323): fp32 tile staged [32 rows][W+4] so that the read-modify-write of
+// the residual stream uses 16-byte accesses; the residual values are loaded before the LDS round trip.
+template <int MBW, int NBW>
+__device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], float* reg, int row0,
+                                                      int colbase, int lane) {
+    constexpr int W = 32 * NBW;
+    constexpr int LD = W + 4;
+    constexpr int CPR = W / 4;             // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;          // rows per instruction
+    constexpr int NI = 32 / RPI;           // instructions per 32-row pass
     const int hi = lane >> 5, lcol = lane & 31;
-    const int colbase = n0 + wn * 64;
-    float bcol[2];
+    float bcol[NBW];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
-    const int chunk = lane & 15;
+    for (int nb = 0; nb < NBW; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
+    const int chunk = lane % CPR;
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gate + colbase + chunk * 4);
 #pragma unroll
-    for (int mb4 = 0; mb4 < 4; ++mb4) {
-        const int rowblk = m0 + wm * 128 + mb4 * 32;
-        // residual values + row masks first (global loads), then LDS round trip, then stores
-        f32x4 xr[8];
-        float kp[8];
+    for (int mb = 0; mb < MBW; ++mb) {
+        const int rowblk = row0 + mb * 32;
+        f32x4 xr[NI];
+        float kp[NI];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int grow = rowblk + i * 4 + (lane >> 4);
+        for (int i = 0; i < NI; ++i) {
+            const int grow = rowblk + i * RPI + lane / CPR;
             const bool ok = grow < p.M;
             xr[i] = ok ? *reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4)
                        : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -438,14 +452,14 @@ __device__ __forceinline__ void gemm256_epilogue_resid(const F5GemmArgs& p, f32x
         for (int r = 0; r < 16; ++r) {
             const int lrow = (r & 3) + 8 * (r >> 2) + 4 * hi;
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) reg[lrow * EPF_LD + nb * 32 + lcol] = acc[mb4][nb][r] + bcol[nb];
+            for (int nb = 0; nb < NBW; ++nb) reg[lrow * LD + nb * 32 + lcol] = acc[mb][nb][r] + bcol[nb];
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int lrow = i * 4 + (lane >> 4);
+        for (int i = 0; i < NI; ++i) {
+            const int lrow = i * RPI + lane / CPR;
             const int grow = rowblk + lrow;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&reg[lrow * EPF_LD + chunk * 4]);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&reg[lrow * LD + chunk * 4]);
             if (grow < p.M) {
                 f32x4 o;
 #pragma unroll
@@ -617,10 +631,17 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         V2_BARRIER();
     }
 
+    if (p.debug_flags & 1) {   // timing experiment: main loop only
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
-        gemm256_epilogue_bf16<EPI>(p, acc, smem + wave * 8192, m0, n0, wm, wn, lane);
+        staged_epilogue_bf16<EPI, 4, 2>(p, acc, smem + wave * 8192, m0 + wm * 128, n0 + wn * 64, lane);
     } else if (EPI == EPI_RESID_GATE) {
-        gemm256_epilogue_resid(p, acc, reinterpret_cast<float*>(smem + wave * 8192), m0, n0, wm, wn, lane);
+        staged_epilogue_resid<4, 2>(p, acc, reinterpret_cast<float*>(smem + wave * 8192), m0 + wm * 128, n0 + wn * 64, lane);
     } else {
         gemm_epilogue<EPI, 4, 2>(p, acc, m0, n0, wm, wn, lane);
     }
@@ -640,6 +661,14 @@ static int launch_v2(const F5GemmArgs& a, hipStream_t stream) {
 // counted vmcnt, one barrier per K tile).  Used for small-batch shapes (M ~ 2 * 937 rows) where the chip is only
 // filled by 64x64 / 64x128 tiles and the old one-tile-deep register prefetch left every iteration latency bound.
 // =================================================================================================
+int f5_gemm_order = 0;   // 0 auto, 1 force n-fastest, 2 force m-fastest (ring kernel tile numbering)
+static bool gemm_mfast(const F5GemmArgs& a) {
+    if (f5_gemm_order == 1) return false;
+    if (f5_gemm_order == 2) return true;
+    const size_t a_bytes = (size_t)(a.a_row_mod > 0 ? a.a_row_mod : a.M) * a.K * 2 * (a.nseg == 3 ? 2 : 1);
+    return a_bytes <= (size_t)4 << 20;     // whole A operand fits in one XCD's 4 MB L2
+}
+
 template <int EPI, int MB, int NB, int NST>
 __global__ __launch_bounds__(256) void f5_gemm_ring_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
     constexpr int BMt = 64 * MB, BNt = 64 * NB;
@@ -652,7 +681,16 @@ __global__ __launch_bounds__(256) void f5_gemm_ring_kernel(F5GemmArgs p, int til
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    // tile numbering: n fastest (neighbouring tiles share the A panel) or, when tiles_n < 0, m fastest with
+    // tiles_m = -tiles_n (neighbouring tiles share the W panel: better when the whole A operand fits in an XCD's L2)
+    int tm, tn;
+    if (tiles_n > 0) {
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+    } else {
+        tn = tile / (-tiles_n);
+        tm = tile - tn * (-tiles_n);
+    }
     const int m0 = tm * BMt, n0 = tn * BNt;
 
     const int tid = threadIdx.x;
@@ -745,7 +783,161 @@ template <int EPI, int MB, int NB>
 static int launch_ring(const F5GemmArgs& a, hipStream_t stream) {
     const int tiles_m = f5_cdiv(a.M, 64 * MB), tiles_n = f5_cdiv(a.N, 64 * NB);
     const int ntiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, NB, 4>), dim3(ntiles), dim3(256), 0, stream, a, tiles_n, ntiles);
+    const int order = gemm_mfast(a) ? -tiles_m : tiles_n;
+    // ring depth: keep TWO workgroups per CU (<= 80 KB of LDS each): 64x64 tiles take 4 stages (64 KB), 64x128 take 3 (72 KB)
+    constexpr int NST = (MB + NB) * 8 * 4 <= 80 ? 4 : 3;
+    hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, NB, NST>), dim3(ntiles), dim3(256), 0, stream, a, order, ntiles);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// v3: 128x256x32 block tile, 256 threads = 4 waves (2 x 2), wave tile 64x128 (2x4 accumulators), global_load_lds
+// ring of 3 K-tiles of 24 KB => 72 KB of LDS and <= 256 registers, i.e. TWO workgroups per CU.  Rationale (measured
+// with the skip-epilogue ablation, tools/gemm_ablate.py): at K = 1024 the epilogue is 26-42 % of a 256x256 tile's time
+// and is bound by the CU's store path / HBM (x += ... moves 8 B per output), during which the matrix pipes idle.  With
+// two resident workgroups that are half a tile out of phase (the second wave of workgroups starts with a one-off
+// sleep), one workgroup's epilogue runs under the other's main loop.  64-byte LDS rows: swizzle chunk ^= (row>>2)&3.
+// =================================================================================================
+#define V3_BK 32
+__device__ __forceinline__ int swz32(int row, int chunk) { return row * V3_BK + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void f5_gemm_v3_kernel(F5GemmArgs p, int tiles_n, int ntiles, int stagger_cycles) {
+    constexpr int BMt = 128, BNt = 256, NST = 3;
+    constexpr int NA = 2, NW = 4, G = NA + NW;
+    constexpr int STAGE = (BMt + BNt) * V3_BK;          // 12288 elements = 24 KB
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NST * STAGE];
+
+    const int bid = blockIdx.x;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    // tile numbering: n fastest (neighbouring tiles share the A panel) or, when tiles_n < 0, m fastest with
+    // tiles_m = -tiles_n (neighbouring tiles share the W panel: better when the whole A operand fits in an XCD's L2)
+    int tm, tn;
+    if (tiles_n > 0) {
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+    } else {
+        tn = tile / (-tiles_n);
+        tm = tile - tn * (-tiles_n);
+    }
+    const int m0 = tm * BMt, n0 = tn * BNt;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // de-phase the two co-resident workgroups: blocks 256..511 (second slot of every CU in dispatch order) start late
+    if (bid >= 256 && bid < 512) {
+        for (int c = 0; c < stagger_cycles; c += 64 * 100) __builtin_amdgcn_s_sleep(100);
+    }
+
+    size_t a_src[NA], w_src[NW];
+    int a_dst[NA], w_dst[NW];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int q_ = i * 256 + tid;
+        const int row = q_ >> 2, chunk = (q_ & 3) ^ ((row >> 2) & 3);
+        int gr = m0 + row;
+        if (gr > p.M - 1) gr = p.M - 1;
+        if (p.a_row_mod > 0) gr = gr % p.a_row_mod;
+        a_src[i] = (size_t)gr * p.lda + chunk * 8;
+        a_dst[i] = (i * 256 + wave * 64) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int q_ = i * 256 + tid;
+        const int row = q_ >> 2, chunk = (q_ & 3) ^ ((row >> 2) & 3);
+        w_src[i] = (size_t)(n0 + row) * p.ldw + chunk * 8;
+        w_dst[i] = BMt * V3_BK + (i * 256 + wave * 64) * 8;
+    }
+    const int kt = p.K / V3_BK;
+    const int T = kt * p.nseg;
+#define V3_ISSUE(tt_)                                                                                        \
+    {                                                                                                        \
+        const int seg_ = (tt_) / kt;                                                                         \
+        const int k0_ = ((tt_) - seg_ * kt) * V3_BK;                                                         \
+        bf16_t* st_ = smem + ((tt_) % NST) * STAGE;                                                          \
+        const bf16_t* Ap_ = (seg_ == 1) ? p.A[1] : p.A[0];                                                   \
+        const bf16_t* Wp_ = (seg_ == 2) ? p.W[1] : p.W[0];                                                   \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) glds16(Ap_ + a_src[i] + k0_, st_ + a_dst[i]);         \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i) glds16(Wp_ + w_src[i] + k0_, st_ + w_dst[i]);         \
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    V3_ISSUE(0);
+    if (T > 1) V3_ISSUE(1);
+
+    const int frow = lane & 31;
+    const int fk = lane >> 5;
+    for (int tt = 0; tt < T; ++tt) {
+        if (tt + 1 < T) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");     // tile tt landed, tile tt+1 may be in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tt + 2 < T) V3_ISSUE(tt + 2);                                 // slot of tile tt-1: every wave is past it
+
+        const bf16_t* sA = smem + (tt % NST) * STAGE;
+        const bf16_t* sB = sA + BMt * V3_BK;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bfr[4];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) af[mb] = *reinterpret_cast<const bf16x8*>(&sA[swz32(wm * 64 + mb * 32 + frow, ks * 2 + fk)]);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const bf16x8*>(&sB[swz32(wn * 128 + nb * 32 + frow, ks * 2 + fk)]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    if (p.debug_flags & 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    // every wave must be done reading the ring before it is reused as epilogue staging space
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16_t* reg = smem + wave * 9216;     // 18 KB per wave
+    if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
+        staged_epilogue_bf16<EPI, 2, 4>(p, acc, reg, m0 + wm * 64, n0 + wn * 128, lane);
+    } else if (EPI == EPI_RESID_GATE) {
+        staged_epilogue_resid<2, 4>(p, acc, reinterpret_cast<float*>(reg), m0 + wm * 64, n0 + wn * 128, lane);
+    } else {
+        gemm_epilogue<EPI, 2, 4>(p, acc, m0, n0, wm, wn, lane);
+    }
+}
+
+int f5_gemm_v3_stagger = -1;   // cycles of initial delay for workgroups 256..511 (-1: auto = half a tile's main loop)
+template <int EPI>
+static int launch_v3(const F5GemmArgs& a, hipStream_t stream) {
+    const int tiles_m = f5_cdiv(a.M, 128), tiles_n = a.N / 256;
+    const int ntiles = tiles_m * tiles_n;
+    int stagger = f5_gemm_v3_stagger;
+    if (stagger < 0) stagger = (a.K / V3_BK) * a.nseg * 16 * 32;   // ~ half of (K tiles x 16 MFMAs x 32 cycles x 2 workgroups)
+    hipLaunchKernelGGL((f5_gemm_v3_kernel<EPI>), dim3(ntiles), dim3(256), 0, stream, a, tiles_n, ntiles, stagger);
     F5_LAUNCH_CHECK();
     return 0;
 }
@@ -762,6 +954,8 @@ static int launch_cfg(const F5GemmArgs& a, hipStream_t stream) {
 // tile shape: the largest of 128x128 / 64x128 / 64x64 that still gives the 256 CUs >= 1.5 workgroups each
 // (small-batch shapes such as M = 1874 are otherwise a fraction of one wave of tiles)
 int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 v2, 5 = 64x128 ring, 6 = 64x64 ring
+int f5_gemm_debug_flags = 0;
+int f5_gemm_big_kernel = 2;       // auto mode, large shapes: 2 = 256x256 (1 WG/CU), 3 = 128x256 (2 WG/CU, overlapped epilogue)
 int f5_gemm_ring_default = 1;   // auto mode: small tiles use the global_load_lds ring kernel
 template <int EPI>
 static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
@@ -770,11 +964,15 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     int sel = f5_gemm_tile_override;
     const long t256 = (long)f5_cdiv(a.M, 256) * (a.N / 256);
     const bool v2ok = (a.N % 256 == 0) && (a.M >= 256);
+    if (sel == 7 || (sel == 0 && v2ok && t256 >= 512 && f5_gemm_big_kernel == 3)) {
+        F5_REQUIRE(v2ok && a.K % V3_BK == 0, "gemm: the 128x256 kernel needs N %% 256 == 0 and M >= 256");
+        return launch_v3<EPI>(a, stream);
+    }
     if (sel == 4 || (sel == 0 && v2ok && t256 >= 512)) {
         F5_REQUIRE(v2ok, "gemm: the 256x256 kernel needs N %% 256 == 0 and M >= 256");
         return launch_v2<EPI>(a, stream);
     }
-    if (sel == 0 || sel == 4) sel = t128 >= 384 ? 1 : (t64x128 >= 384 ? 2 : 3);
+    if (sel == 0 || sel == 4 || sel == 7) sel = t128 >= 384 ? 1 : (t64x128 >= 384 ? 2 : 3);
     if (EPI == EPI_QKV_ROPE && sel == 3) sel = 2;
     if (EPI == EPI_QKV_ROPE && sel == 6) sel = 5;  // the V^T / head mapping wants >= one whole head per tile column
     if (sel == 5) return launch_ring<EPI, 1, 2>(a, stream);
@@ -785,7 +983,9 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     return launch_cfg<EPI, 1, 1>(a, stream);
 }
 
-int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream) {
+int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
+    F5GemmArgs a = a_in;
+    a.debug_flags = f5_gemm_debug_flags;
     F5_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % BK == 0, "gemm: bad shape M=%d N=%d K=%d (K must be a multiple of %d)",
                a.M, a.N, a.K, BK);
     F5_REQUIRE(a.nseg == 1 || a.nseg == 3, "gemm: nseg must be 1 or 3");

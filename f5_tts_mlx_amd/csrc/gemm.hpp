@@ -36,6 +36,7 @@ struct F5GemmArgs {
     const float* rope_sin;
     int seq_len, npad, heads, dmodel;
     bf16_t* vt[2];            // [B*heads][64][npad]
+    int debug_flags;          // bit 0: skip the epilogue (timing experiments only)
 };
 
 int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);

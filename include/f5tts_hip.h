@@ -153,6 +153,14 @@ int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scra
 
 /* debug / benchmarking hook: force the GEMM block tile (0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 global_load_lds kernel) */
 int f5_debug_set_gemm_tile(int sel);
+/* bit 0: skip GEMM epilogues (timing experiments only; results are garbage) */
+int f5_debug_set_gemm_flags(int v);
+/* small-tile GEMM tile numbering: 0 auto, 1 n fastest, 2 m fastest */
+int f5_debug_set_gemm_order(int v);
+/* small-tile GEMM staging: 1 = global_load_lds ring (default), 0 = register-staged double buffer */
+int f5_debug_set_gemm_ring(int v);
+/* large-shape GEMM kernel in auto mode: 2 = 256x256 (one workgroup per CU), 3 = 128x256 (two per CU); stagger < 0 = auto */
+int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles);
 /* 1 = register-staged attention kernel, 2 = global_load_lds ring (default) */
 int f5_debug_set_attn_version(int v);
 /* timing-only ablations of the attention kernel (results are wrong unless 0) */

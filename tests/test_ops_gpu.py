@@ -424,7 +424,7 @@ def test_attention_other_kernel_versions(lib, ver):
         E.check(lib.f5_debug_set_attn_version(3))
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("nseg", [1, 3])
 def test_gemm_resid_gate(lib, tile, nseg):
     """x += gate * ((A W^T + b) * keep[row])  (dit.py:172-173, 319, 323) on both GEMM kernels."""
@@ -467,3 +467,41 @@ def test_gemm_all_small_tile_kernels(lib, tile):
             assert float((out3.double() - ref32).abs().max()) <= 5e-5 * max(1.0, float(ref32.abs().max()))
     finally:
         E.check(lib.f5_debug_set_gemm_tile(0))
+
+
+@pytest.fixture
+def force_v3(lib):
+    E.check(lib.f5_debug_set_gemm_tile(7))
+    yield
+    E.check(lib.f5_debug_set_gemm_tile(0))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (300, 512, 96), (1874, 1024, 1024), (700, 768, 2048)])
+def test_gemm_v3_f32_out(lib, force_v3, M, N, K):
+    r = rng(M + N + K + 3)
+    a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+    refbf = (bf16r(a).double() @ bf16r(w).double().T) + bias.double()
+    out, _, _ = _gemm(lib, a, w, bias, 0, 1) if K % 64 == 0 else (None, None, None)
+    if out is not None:
+        mx, _, _ = report(f"gemm v3 bf16 {M}x{N}x{K}", out, refbf)
+        assert mx <= 2e-4 * max(1.0, float(refbf.abs().max()))
+        out3, _, _ = _gemm(lib, a, w, bias, 0, 3)
+        ref32 = a.double() @ w.double().T + bias.double()
+        assert float((out3.double() - ref32).abs().max()) <= 5e-5 * max(1.0, float(ref32.abs().max()))
+
+
+@pytest.mark.parametrize("epi", [1, 2, 8])
+def test_gemm_v3_bf16_epilogues(lib, force_v3, epi):
+    r = rng(50 + epi)
+    M, N, K = 777, 512, 256
+    a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+    pre = a.double() @ w.double().T + bias.double()
+    ref = pre if epi == 1 else (F.gelu(pre, approximate="tanh") if epi == 2 else F.gelu(pre))
+    _, out_hi, out_lo = _gemm(lib, a, w, bias, epi, 3)
+    mx, _, _ = report(f"gemm v3 epilogue {epi}", join(out_hi, out_lo), ref)
+    assert mx <= 1e-4
+
+
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_attention_path_with_v3_qkv(lib, force_v3, nseg):
+    _attention_case(lib, 2, 4, 300, [300, 211], nseg, seed=22)

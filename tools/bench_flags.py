@@ -1,0 +1,18 @@
+"""Run bench.py in-process after setting debug hooks:  python tools/bench_flags.py order=1 ring=0 attn=3 -- --steps 3"""
+import os, runpy, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from f5_tts_mlx_amd import engine as E
+lib = E.load_library()
+args = sys.argv[1:]
+split = args.index("--") if "--" in args else len(args)
+for kv in args[:split]:
+    k, v = kv.split("=")
+    v = int(v)
+    if k == "order": lib.f5_debug_set_gemm_order(v)
+    elif k == "tile": lib.f5_debug_set_gemm_tile(v)
+    elif k == "attn": lib.f5_debug_set_attn_version(v)
+    elif k == "big": lib.f5_debug_set_gemm_big_kernel(v, -1)
+    elif k == "ring": lib.f5_debug_set_gemm_ring(v)
+    else: raise SystemExit(f"unknown flag {k}")
+sys.argv = ["bench.py"] + args[split + 1:]
+runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), run_name="__main__")
