@@ -978,7 +978,12 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     if (sel == 5) return launch_ring<EPI, 1, 2>(a, stream);
     if (sel == 6) return launch_ring<EPI, 1, 1>(a, stream);
     if (sel == 1) return launch_cfg<EPI, 2, 2>(a, stream);
-    if (f5_gemm_ring_default) return sel == 2 ? launch_ring<EPI, 1, 2>(a, stream) : launch_ring<EPI, 1, 1>(a, stream);
+    if (f5_gemm_ring_default) {
+        // the ring kernels hold 2 workgroups per CU (512 slots); the register-staged 64x128 kernel needs only 48 KB of
+        // LDS (3 per CU, 768 slots): prefer it when that turns two rounds of tiles into one (QKV at M = 2*937: 720 tiles)
+        if (sel == 2 && t64x128 > 512 && t64x128 <= 768) return launch_cfg<EPI, 1, 2>(a, stream);
+        return sel == 2 ? launch_ring<EPI, 1, 2>(a, stream) : launch_ring<EPI, 1, 1>(a, stream);
+    }
     if (sel == 2) return launch_cfg<EPI, 1, 2>(a, stream);
     return launch_cfg<EPI, 1, 1>(a, stream);
 }
