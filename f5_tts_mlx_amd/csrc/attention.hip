@@ -221,6 +221,11 @@ __device__ __forceinline__ void attn_glds16(const bf16_t* gptr, bf16_t* lds_wave
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
 __device__ __forceinline__ int attn_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+// K tile rows are stored PERMUTED: LDS row i of a 32-key block holds key (i&3) + 4*(i>>3) + 16*((i>>2)&1).  In the
+// S^T = K Q^T accumulator layout lane-half hi then owns the 16 CONSECUTIVE keys 16*hi + r (r = register index), so
+// the P operand of a 16-key MFMA step is 8 consecutive keys and the matching V^T fragment is ONE ds_read_b128
+// (no bank conflicts, no register shuffles) instead of two ds_read_b64 halves.
+__device__ __forceinline__ int attn_kperm(int i) { return (i & 32) | ((i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1)); }
 
 // ABL = timing-only ablation (results are wrong unless ABL == 0): 1 no exp2, 2 no barrier/vmcnt wait, 3 no PV MFMAs,
 // 4 no S MFMAs, 5 no softmax VALU at all (debug hook f5_debug_set_attn_ablation; CDNA4 guide: ablate before optimising)
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
         const int key0_ = (j_) * 64;                                                                         \
         bf16_t* st_ = smem + ((j_) % NST) * (NP * 2 * TILE);                                                 \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-            int key_ = key0_ + srow[i];                                                                      \
+            int key_ = key0_ + attn_kperm(srow[i]);                                                          \
             if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                                  \
             _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                              \
                 attn_glds16(p.qk[pp] + (rowbase + key_) * p.ldqk + p.dmodel + h * 64 + schunk[i] * 8,        \
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int key = key0 + kb * 32 + 16 * hi + r;
                     if (key >= kvlen) s[kb][r] = -INFINITY;
                 }
         }
@@ -394,11 +399,8 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int row = db * 32 + lq;
-                const int o0 = attn_swz(row, 2 * ks4) + hi * 4, o1 = attn_swz(row, 2 * ks4 + 1) + hi * 4;
-                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&sV[o0]);
-                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&sV[o1]);
-                const bf16x8 a = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const int voff = attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sV[voff]);
                 if (ABL == 3) {
                     asm volatile("" ::"v"(a), "v"(pb));
                     o[db][ks4] += 1.0f;
@@ -406,9 +408,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
                 }
                 if (HP) {
-                    const bf16x4 w0 = *reinterpret_cast<const bf16x4*>(&sVl[o0]);
-                    const bf16x4 w1 = *reinterpret_cast<const bf16x4*>(&sVl[o1]);
-                    const bf16x8 al = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sVl[voff]);
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pb, o[db], 0, 0, 0);
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pbl, o[db], 0, 0, 0);
                 }
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
         const int key0_ = (j_) * 64;                                                                         \
         bf16_t* st_ = smem + ((j_) % 3) * (2 * TILE);                                                        \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-            int key_ = key0_ + srow[i];                                                                      \
+            int key_ = key0_ + attn_kperm(srow[i]);                                                          \
             if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                                  \
             attn_glds16(p.qk[0] + (rowbase + key_) * p.ldqk + p.dmodel + h * 64 + schunk[i] * 8, st_ + ldsoff[i]); \
             attn_glds16(p.vt[0] + ((size_t)bh * 64 + srow[i]) * p.npad + key0_ + schunk[i] * 8, st_ + TILE + ldsoff[i]); \
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int key = key0 + kb * 32 + 16 * hi + r;
                     if (key >= kvlen) s[kb][r] = -INFINITY;
                 }
         }
@@ -587,11 +587,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
             const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[kb][4 * sp], pw[kb][4 * sp + 1], pw[kb][4 * sp + 2], pw[kb][4 * sp + 3]});
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int row = db * 32 + lq;
-                const int o0 = attn_swz(row, 2 * ks4) + hi * 4, o1 = attn_swz(row, 2 * ks4 + 1) + hi * 4;
-                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&sV[o0]);
-                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&sV[o1]);
-                const bf16x8 a = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sV[attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp)]);
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
             }
         }
