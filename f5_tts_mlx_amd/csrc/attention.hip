@@ -257,27 +257,41 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
                 qf[pp][ks] = *reinterpret_cast<const bf16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
     }
 
-    // staging: 2 chunks of K and 2 of V^T per thread and part; linear chunk q_ = i*256 + tid of the [64][8] image
-    int srow[2], schunk[2], ldsoff[2];
+    // staging pointers (advanced by one KV tile per issue: tiles are issued in increasing order) + wave-uniform LDS offsets
+    const bf16_t* kptr[NP][2];
+    const bf16_t* vptr[NP][2];
+    int krow[2], kcol[2], ldsoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q_ = i * 256 + tid;
-        srow[i] = q_ >> 3;
-        schunk[i] = (q_ & 7) ^ ((srow[i] >> 1) & 7);
+        const int srow = q_ >> 3;
+        const int schunk = (q_ & 7) ^ ((srow >> 1) & 7);
+        krow[i] = attn_kperm(srow);
+        kcol[i] = p.dmodel + h * 64 + schunk * 8;
         ldsoff[i] = (i * 256 + wave * 64) * 8;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            kptr[pp][i] = p.qk[pp] + (rowbase + krow[i]) * p.ldqk + kcol[i];
+            vptr[pp][i] = p.vt[pp] + ((size_t)bh * 64 + srow) * p.npad + schunk * 8;
+        }
     }
+    const size_t kstep = (size_t)64 * p.ldqk;
 #define A2_ISSUE(j_)                                                                                         \
     {                                                                                                        \
-        const int key0_ = (j_) * 64;                                                                         \
         bf16_t* st_ = smem + ((j_) % NST) * (NP * 2 * TILE);                                                 \
+        const bool tail_ = ((j_) * 64 + 63) > p.seq_len - 1;                                                 \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-            int key_ = key0_ + attn_kperm(srow[i]);                                                          \
-            if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                                  \
             _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                              \
-                attn_glds16(p.qk[pp] + (rowbase + key_) * p.ldqk + p.dmodel + h * 64 + schunk[i] * 8,        \
-                            st_ + (pp * 2) * TILE + ldsoff[i]);                                              \
-                attn_glds16(p.vt[pp] + ((size_t)bh * 64 + srow[i]) * p.npad + key0_ + schunk[i] * 8,         \
-                            st_ + (pp * 2 + 1) * TILE + ldsoff[i]);                                          \
+                const bf16_t* ks_ = kptr[pp][i];                                                             \
+                if (tail_) {                                                                                 \
+                    int key_ = (j_) * 64 + krow[i];                                                          \
+                    if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                          \
+                    ks_ = p.qk[pp] + (rowbase + key_) * p.ldqk + kcol[i];                                    \
+                }                                                                                            \
+                attn_glds16(ks_, st_ + (pp * 2) * TILE + ldsoff[i]);                                         \
+                attn_glds16(vptr[pp][i], st_ + (pp * 2 + 1) * TILE + ldsoff[i]);                             \
+                kptr[pp][i] += kstep;                                                                        \
+                vptr[pp][i] += 64;                                                                           \
             }                                                                                                \
         }                                                                                                    \
     }
@@ -466,23 +480,38 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
         for (int ks = 0; ks < 4; ++ks)
             qf[ks] = *reinterpret_cast<const bf16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
     }
-    int srow[2], schunk[2], ldsoff[2];
+    // staging pointers (advanced by one KV tile per issue) and wave-uniform LDS offsets
+    const bf16_t* kptr[2];
+    const bf16_t* vptr[2];
+    int krow[2], kcol[2], ldsoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q_ = i * 256 + tid;
-        srow[i] = q_ >> 3;
-        schunk[i] = (q_ & 7) ^ ((srow[i] >> 1) & 7);
+        const int srow = q_ >> 3;
+        const int schunk = (q_ & 7) ^ ((srow >> 1) & 7);
+        krow[i] = attn_kperm(srow);
+        kcol[i] = p.dmodel + h * 64 + schunk * 8;
+        kptr[i] = p.qk[0] + (rowbase + krow[i]) * p.ldqk + kcol[i];
+        vptr[i] = p.vt[0] + ((size_t)bh * 64 + srow) * p.npad + schunk * 8;
         ldsoff[i] = (i * 256 + wave * 64) * 8;
     }
+    const size_t kstep = (size_t)64 * p.ldqk;
+    // issue KV tile j_ (tiles are issued in increasing order: pointers advance by one tile per issue)
 #define A3_ISSUE(j_)                                                                                         \
     {                                                                                                        \
-        const int key0_ = (j_) * 64;                                                                         \
         bf16_t* st_ = smem + ((j_) % 3) * (2 * TILE);                                                        \
+        const bool tail_ = ((j_) * 64 + 63) > p.seq_len - 1;                                                 \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-            int key_ = key0_ + attn_kperm(srow[i]);                                                          \
-            if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                                  \
-            attn_glds16(p.qk[0] + (rowbase + key_) * p.ldqk + p.dmodel + h * 64 + schunk[i] * 8, st_ + ldsoff[i]); \
-            attn_glds16(p.vt[0] + ((size_t)bh * 64 + srow[i]) * p.npad + key0_ + schunk[i] * 8, st_ + TILE + ldsoff[i]); \
+            const bf16_t* ks_ = kptr[i];                                                                     \
+            if (tail_) {                                                                                     \
+                int key_ = (j_) * 64 + krow[i];                                                              \
+                if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                              \
+                ks_ = p.qk[0] + (rowbase + key_) * p.ldqk + kcol[i];                                         \
+            }                                                                                                \
+            attn_glds16(ks_, st_ + ldsoff[i]);                                                               \
+            attn_glds16(vptr[i], st_ + TILE + ldsoff[i]);                                                    \
+            kptr[i] += kstep;                                                                                \
+            vptr[i] += 64;                                                                                   \
         }                                                                                                    \
     }
 #define A3_SCORES(dst_, slot_)                                                                               \
@@ -491,11 +520,24 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
         _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                   \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) dst_[kb][e] = 0.0f;                               \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                               \
-                const bf16x8 a_ = *reinterpret_cast<const bf16x8*>(&sK_[attn_swz(kb * 32 + lq, ks * 2 + hi)]); \
+                const bf16x8 a_ = *reinterpret_cast<const bf16x8*>(&sK_[koff[kb][ks]]);                      \
                 dst_[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, qf[ks], dst_[kb], 0, 0, 0);          \
             }                                                                                                \
         }                                                                                                    \
     }
+    // loop-invariant LDS fragment offsets
+    int koff[2][4], voff[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            koff[kb][ks] = attn_swz(kb * 32 + lq, ks * 2 + hi);
+            voff[kb][ks] = attn_swz(kb * 32 + lq, ks * 2 + hi);   // [db][ks4]: row db*32+lq, chunk 4*(ks4>>1) + 2*hi + (ks4&1)
+        }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ++ks4) voff[db][ks4] = attn_swz(db * 32 + lq, 4 * (ks4 >> 1) + 2 * hi + (ks4 & 1));
 
     f32x16 o[2];
 #pragma unroll
@@ -516,83 +558,69 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    f32x16 s[2];
-    A3_SCORES(s, 0);
+    f32x16 sa[2], sb[2];
+    A3_SCORES(sa, 0);
 
-    for (int j = 0; j < ntile; ++j) {
-        // tile j+1 (issued one iteration ago) must have landed everywhere; the barrier also retires slot (j-1)%3
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (j + 2 < ntile) A3_ISSUE(j + 2);
+    // one KV tile: softmax + PV of tile j_ from scores cur_, while the scores of tile j_+1 are produced into nxt_
+#define A3_BODY(j_, cur_, nxt_)                                                                              \
+    {                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+        asm volatile("" ::: "memory");                                                                       \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("" ::: "memory");                                                                       \
+        if ((j_) + 2 < ntile) A3_ISSUE((j_) + 2);                                                            \
+        const int key0_ = (j_) * 64;                                                                         \
+        if (key0_ + 64 > kvlen) {                                                                            \
+            _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                 \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                               \
+                    if (key0_ + kb * 32 + 16 * hi + r >= kvlen) cur_[kb][r] = -INFINITY;                     \
+        }                                                                                                    \
+        float tmax_ = -INFINITY;                                                                             \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) tmax_ = fmaxf(tmax_, cur_[kb][r]);                \
+        tmax_ = fmaxf(tmax_, __shfl_xor(tmax_, 32, 64));                                                     \
+        if (__any(tmax_ > m_run)) {                                                                          \
+            const float m_new_ = fmaxf(m_run, tmax_);                                                        \
+            const float alpha_ = __builtin_amdgcn_exp2f((m_run - m_new_) * c2);                              \
+            m_run = m_new_;                                                                                  \
+            l_run *= alpha_;                                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                 \
+                o[0][e] *= alpha_;                                                                           \
+                o[1][e] *= alpha_;                                                                           \
+            }                                                                                                \
+        }                                                                                                    \
+        const float mc_ = m_run * c2;                                                                        \
+        A3_SCORES(nxt_, ((j_) + 1) % 3);                                                                     \
+        float psum_ = 0.0f;                                                                                  \
+        uint32_t pw_[2][8];                                                                                  \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
+            _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                              \
+                const float p0_ = __builtin_amdgcn_exp2f(cur_[kb][r] * c2 - mc_);                            \
+                const float p1_ = __builtin_amdgcn_exp2f(cur_[kb][r + 1] * c2 - mc_);                        \
+                psum_ += p0_ + p1_;                                                                          \
+                pw_[kb][r >> 1] = f5_pack2(p0_, p1_);                                                        \
+            }                                                                                                \
+        l_run += psum_;                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                              \
+        }                                                                                                    \
+        const bf16_t* sV_ = smem + ((j_) % 3) * (2 * TILE) + TILE;                                           \
+        _Pragma("unroll") for (int ks4 = 0; ks4 < 4; ++ks4) {                                                \
+            const int kb = ks4 >> 1, sp = ks4 & 1;                                                           \
+            const bf16x8 pb_ = __builtin_bit_cast(                                                           \
+                bf16x8, u32x4{pw_[kb][4 * sp], pw_[kb][4 * sp + 1], pw_[kb][4 * sp + 2], pw_[kb][4 * sp + 3]}); \
+            _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                               \
+                const bf16x8 a_ = *reinterpret_cast<const bf16x8*>(&sV_[voff[db][ks4]]);                     \
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, pb_, o[db], 0, 0, 0);                    \
+            }                                                                                                \
+        }                                                                                                    \
+    }
 
-        // ---- running max of tile j (S(j) is complete) ------------------------------------------------
-        const int key0 = j * 64;
-        if (key0 + 64 > kvlen) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + kb * 32 + 16 * hi + r;
-                    if (key >= kvlen) s[kb][r] = -INFINITY;
-                }
-        }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        if (__any(tmax > m_run)) {
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                o[0][e] *= alpha;
-                o[1][e] *= alpha;
-            }
-        }
-        const float mc = m_run * c2;
-
-        // ---- S(j+1) MFMAs (slot (j+1)%3; stale but harmless data after the last tile) in the SAME basic block as
-        //      the exponentials of tile j: independent registers, the scheduler interleaves them
-        f32x16 sn[2];
-        A3_SCORES(sn, (j + 1) % 3);
-        float psum = 0.0f;
-        uint32_t pw[2][8];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
-                const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1] * c2 - mc);
-                psum += p0 + p1;
-                pw[kb][r >> 1] = f5_pack2(p0, p1);
-            }
-        l_run += psum;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);  // 14 VALU
-        }
-
-        // ---- O^T += V(j)^T P(j)^T ---------------------------------------------------------------------
-        const bf16_t* sV = smem + (j % 3) * (2 * TILE) + TILE;
-#pragma unroll
-        for (int ks4 = 0; ks4 < 4; ++ks4) {
-            const int kb = ks4 >> 1, sp = ks4 & 1;
-            const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[kb][4 * sp], pw[kb][4 * sp + 1], pw[kb][4 * sp + 2], pw[kb][4 * sp + 3]});
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sV[attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp)]);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
-            }
-        }
-        s[0] = sn[0];
-        s[1] = sn[1];
+    // two tiles per trip so that the score registers ping-pong without copies
+    for (int j = 0; j < ntile; j += 2) {
+        A3_BODY(j, sa, sb);
+        if (j + 1 < ntile) A3_BODY(j + 1, sb, sa);
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -612,7 +640,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
     }
 }
 
-int f5_attn_version = 3;   // 1 = register-staged, 2 = global_load_lds ring, 3 = ring + in-wave software pipelining (bf16 default)
+int f5_attn_version = 2;   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower)
 int f5_attn_ablation = 0;  // timing experiments only
 
 int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {

@@ -59,10 +59,12 @@ __device__ inline void f5_split(float f, bf16_t& hi, bf16_t& lo) {
 }
 
 // pack two floats to bf16 pairs (element 0 in the low half); *_lo packs the rounding residuals
+typedef float f5_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 f5_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ inline uint32_t f5_pack2(float a, float b) {
-    const u16 x = __builtin_bit_cast(u16, static_cast<bf16_t>(a));
-    const u16 y = __builtin_bit_cast(u16, static_cast<bf16_t>(b));
-    return (uint32_t)x | ((uint32_t)y << 16);
+    // one v_cvt_pk_bf16_f32 (RNE); the scalar-cast form compiled to two converts + an SDWA or
+    const f5_f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f5_bf16x2));
 }
 __device__ inline uint32_t f5_pack2_lo(float a, float b) {
     const float ra = a - static_cast<float>(static_cast<bf16_t>(a));

@@ -11,4 +11,4 @@ for ver in (2, 3, 4, 3, 4, 2):
     mb.lib.f5_debug_set_attn_version(ver)
     print("version", ver, end=": ")
     mb.attn_case(64, 16, 937, 0)
-mb.lib.f5_debug_set_attn_version(3)
+mb.lib.f5_debug_set_attn_version(2)
