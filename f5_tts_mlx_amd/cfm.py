@@ -230,9 +230,21 @@ class F5TTS:
         vocab = {v: i for i, v in enumerate(Path(vocab_path).read_text().split("\n"))}
         if len(vocab) == 0:
             raise ValueError(f"Could not load vocab from {vocab_path}")
+        from safetensors.numpy import load_file
+
+        # duration predictor (cfm.py:425-442)
+        duration_predictor = None
+        duration_model_path = Path(path) / "duration_v2.safetensors"
+        if duration_model_path.exists():
+            from .duration import DurationPredictor, DurationTransformer
+            duration_predictor = DurationPredictor(
+                transformer=DurationTransformer(dim=512, depth=8, heads=8, text_dim=512, ff_mult=2, conv_layers=2,
+                                                text_num_embeds=len(vocab) - 1, precision=precision, device=device),
+                vocab_char_map=vocab)
+            duration_predictor.load_weights(load_file(str(duration_model_path)))
+
         convert_weights = default(convert_weights, True)
         model_path = Path(path) / "model_v1.safetensors"
-        from safetensors.numpy import load_file
         weights = load_file(str(model_path))
         if convert_weights:
             weights = convert_upstream_weights(weights)
@@ -241,6 +253,7 @@ class F5TTS:
             transformer=DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4,
                             text_num_embeds=len(vocab) - 1, text_mask_padding=True, precision=precision, device=device),
             vocab_char_map=vocab,
+            duration_predictor=duration_predictor,
         )
         f5tts.load_weights(weights)
         return f5tts

@@ -486,7 +486,7 @@ static int run_prep(const Ctx& c, int nfe) {
 
     // --- text path for both branches (dit.py:196-229, convnext_v2.py:46-54)
     RC(f5_launch_text_embed(c.p<int>(w.text), c.nt, c.a<float>(e->text_table), c.a<float>(e->text_pos), cf.text_max_pos,
-                            c.p<float>(w.te[0]), c.p<int>(w.ids), c.p<uint8_t>(w.keep), c.B, c.N, Dt, s));
+                            c.p<float>(w.te[0]), c.p<int>(w.ids), c.p<uint8_t>(w.keep), c.B, c.N, Dt, 1, s));
     int cur = 0;
     for (int i = 0; i < cf.conv_layers; ++i) {
         const TextBlockW& t = e->tblocks[i];
@@ -1020,7 +1020,44 @@ extern "C" int f5_op_grn(const float* g, const float* gamma, const float* beta, 
 
 extern "C" int f5_op_text_embed(const int32_t* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
                                 int32_t* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, void* stream) {
-    return f5_launch_text_embed(text, nt, table, pos_table, max_pos, out, ids_out, keep_out, B, seq_len, dim, (hipStream_t)stream);
+    return f5_launch_text_embed(text, nt, table, pos_table, max_pos, out, ids_out, keep_out, B, seq_len, dim, 1, (hipStream_t)stream);
+}
+extern "C" int f5_op_text_embed_nomask(const int32_t* text, int nt, const float* table, const float* pos_table, int max_pos,
+                                       float* out, int32_t* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, void* stream) {
+    return f5_launch_text_embed(text, nt, table, pos_table, max_pos, out, ids_out, keep_out, B, seq_len, dim, 0, (hipStream_t)stream);
+}
+// out = (resid + A W^T + bias) * keep[row]   (convnext_v2.py:53-54 + dit.py:225; keep may be NULL)
+extern "C" int f5_op_gemm_resid_keep(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                                     const float* resid, const uint8_t* rowkeep, float* out, int M, int N, int K, int lda, int ldw,
+                                     int ldo, int nseg, void* stream) {
+    F5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = (const bf16_t*)a_hi;
+    g.A[1] = (const bf16_t*)a_lo;
+    g.W[0] = (const bf16_t*)w_hi;
+    g.W[1] = (const bf16_t*)w_lo;
+    g.lda = lda;
+    g.ldw = ldw;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.nseg = nseg;
+    g.bias = bias;
+    g.resid = resid;
+    g.ldres = ldo;
+    g.rowkeep = rowkeep;
+    g.out_f32 = out;
+    g.ldo = ldo;
+    F5_REQUIRE(resid != nullptr && out != nullptr, "gemm_resid_keep: null resid / out");
+    return f5_launch_gemm(g, EPI_RESID_KEEP, (hipStream_t)stream);
+}
+extern "C" int f5_op_pack_bf16(const float* src, const uint8_t* rowkeep, void* out_hi, void* out_lo, int rows, int cols, int ld,
+                               int col0, void* stream) {
+    return f5_launch_pack_bf16(src, rowkeep, (bf16_t*)out_hi, (bf16_t*)out_lo, rows, cols, ld, col0, (hipStream_t)stream);
+}
+extern "C" int f5_op_duration_head(const float* x, const float* g, const float* w, const uint8_t* mask, float* out, int B,
+                                   int seq_len, int dim, float eps, void* stream) {
+    return f5_launch_duration_head(x, g, w, mask, out, B, seq_len, dim, eps, (hipStream_t)stream);
 }
 extern "C" int f5_op_text_pos_table(float* table, int max_pos, int dim, void* stream) {
     return f5_launch_text_pos_table(table, max_pos, dim, (hipStream_t)stream);

@@ -221,11 +221,12 @@ int f5_launch_grn(const float* g, const float* gamma, const float* beta, float* 
 __global__ __launch_bounds__(128) void text_embed_kernel(const int* __restrict__ text, int nt, const float* __restrict__ table,
                                                          const float* __restrict__ pos_table, int max_pos,
                                                          float* __restrict__ out, int* __restrict__ ids_out,
-                                                         uint8_t* __restrict__ keep_out, int B, int seq_len, int dim) {
+                                                         uint8_t* __restrict__ keep_out, int B, int seq_len, int dim,
+                                                         int mask_padding) {
     const int n = blockIdx.x, b = blockIdx.y, br = blockIdx.z;
     int id = 0;
     if (n < nt) id = text[(size_t)b * nt + n] + 1;   // text + 1, curtailed to seq_len, right-padded with 0
-    const bool keep = id != 0;                        // text_mask = (text == 0), taken BEFORE the drop
+    const bool keep = (id != 0) || !mask_padding;     // text_mask = (text == 0), taken BEFORE the drop; none when mask_padding=False
     const int emb_id = (br == 1) ? 0 : id;            // drop_text -> all-zero ids
     const int pos = n < max_pos ? n : max_pos - 1;
     if (threadIdx.x == 0) {
@@ -245,10 +246,10 @@ __global__ __launch_bounds__(128) void text_embed_kernel(const int* __restrict__
 }
 
 int f5_launch_text_embed(const int* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
-                         int* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, hipStream_t s) {
+                         int* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, int mask_padding, hipStream_t s) {
     F5_REQUIRE(dim % 4 == 0, "text_embed: dim must be a multiple of 4");
     hipLaunchKernelGGL(text_embed_kernel, dim3(seq_len, B, 2), dim3(128), 0, s, text, nt, table, pos_table, max_pos, out,
-                       ids_out, keep_out, B, seq_len, dim);
+                       ids_out, keep_out, B, seq_len, dim, mask_padding);
     F5_LAUNCH_CHECK();
     return 0;
 }
@@ -550,6 +551,75 @@ int f5_launch_im2col7(const float* x, bf16_t* out_hi, bf16_t* out_lo, int nbatch
     const size_t total = (size_t)nbatch * seq_len * 7 * 128;
     hipLaunchKernelGGL(im2col7_kernel, dim3(f5_cdiv((long)total, 256)), dim3(256), 0, s, x, out_hi, out_lo, seq_len, channels,
                        total);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// =================================================================================================
+// duration predictor helpers (duration.py)
+// =================================================================================================
+// fp32 [rows][cols] (optionally row-masked) -> bf16 (hi, lo) at column offset col0 of a [rows][ld] matrix
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, const uint8_t* __restrict__ rowkeep,
+                                                        bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int cols, int ld,
+                                                        int col0, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t row = i / cols;
+    const int c = (int)(i - row * cols);
+    float v = src[i];
+    if (rowkeep != nullptr && rowkeep[row] == 0) v = 0.0f;
+    bf16_t h, l;
+    f5_split(v, h, l);
+    out_hi[row * ld + col0 + c] = h;
+    if (out_lo) out_lo[row * ld + col0 + c] = l;
+}
+int f5_launch_pack_bf16(const float* src, const uint8_t* rowkeep, bf16_t* out_hi, bf16_t* out_lo, int rows, int cols, int ld,
+                        int col0, hipStream_t s) {
+    F5_REQUIRE(col0 >= 0 && col0 + cols <= ld, "pack_bf16: column range out of bounds");
+    const size_t total = (size_t)rows * cols;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(f5_cdiv((long)total, 256)), dim3(256), 0, s, src, rowkeep, out_hi, out_lo, cols, ld,
+                       col0, total);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// nn.RMSNorm (duration.py:137) + masked mean over the sequence (utils.py:82-90) + Linear(dim -> 1, no bias) + Softplus
+// (duration.py:188-190): one workgroup per batch element.  out[b] = softplus(sum_d w[d] * mean_n(mask * rms(x)[n,d] * g[d]))
+__global__ __launch_bounds__(256) void duration_head_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ w, const uint8_t* __restrict__ mask,
+                                                            float* __restrict__ out, int seq_len, int dim, float eps) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.0f;     // this wave's partial of sum_n mask[n] * sum_d (x[n,d] * rstd[n]) * g[d] * w[d]
+    int cnt = 0;
+    for (int n = wave; n < seq_len; n += 4) {
+        const float* xr = x + ((size_t)b * seq_len + n) * dim;
+        float ss = 0.0f, dot = 0.0f;
+        for (int d = lane; d < dim; d += 64) {
+            const float v = xr[d];
+            ss += v * v;
+            dot += v * g[d] * w[d];
+        }
+        ss = f5_wave_sum(ss);
+        dot = f5_wave_sum(dot);
+        if (mask[(size_t)b * seq_len + n]) {
+            acc += dot * rsqrtf(ss / (float)dim + eps);
+            cnt += 1;
+        }
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int n = 0; n < seq_len; ++n) total += mask[(size_t)b * seq_len + n] ? 1 : 0;
+        const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(total > 0 ? total : 1);
+        out[b] = mean > 20.0f ? mean : log1pf(expf(mean));
+    }
+}
+int f5_launch_duration_head(const float* x, const float* g, const float* w, const uint8_t* mask, float* out, int B, int seq_len,
+                            int dim, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(duration_head_kernel, dim3(B), dim3(256), 0, s, x, g, w, mask, out, seq_len, dim, eps);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -17,7 +17,7 @@ size_t f5_grn_partial_floats(int nbatch, int seq_len, int dim);
 
 // TextEmbedding index path + gather (dit.py:196-222): ids (+1, pad 0, mask, drop) -> emb + pos.
 int f5_launch_text_embed(const int* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
-                         int* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, hipStream_t s);
+                         int* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, int mask_padding, hipStream_t s);
 
 // pack A operand of the hoisted input projection: [cond(128, zero padded) | text_embed(dt)] for both branches
 int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, bf16_t* out_hi, bf16_t* out_lo,
@@ -73,3 +73,9 @@ int f5_launch_layernorm(const float* x, const float* w, const float* b, float* o
                         int rows, int dim, float eps, hipStream_t s);
 // im2col for Conv1d(k=7, pad=3) on channels-last input (c <= 128): out[b*n][7*128] bf16, tap-major, zero padded
 int f5_launch_im2col7(const float* x, bf16_t* out_hi, bf16_t* out_lo, int nbatch, int seq_len, int channels, hipStream_t s);
+
+// duration predictor helpers
+int f5_launch_pack_bf16(const float* src, const uint8_t* rowkeep, bf16_t* out_hi, bf16_t* out_lo, int rows, int cols, int ld,
+                        int col0, hipStream_t s);
+int f5_launch_duration_head(const float* x, const float* g, const float* w, const uint8_t* mask, float* out, int B, int seq_len,
+                            int dim, float eps, hipStream_t s);

@@ -128,7 +128,20 @@ int f5_op_grn(const float* g, const float* gamma, const float* beta, float* scra
 /* dit.py:196-222 (index path is bit exact) */
 int f5_op_text_embed(const int32_t* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
                      int32_t* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, void* stream);
+/* same with mask_padding=False (duration.py:116-118): filler positions keep their embedding */
+int f5_op_text_embed_nomask(const int32_t* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
+                            int32_t* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, void* stream);
 int f5_op_text_pos_table(float* table, int max_pos, int dim, void* stream);
+/* out = (resid + A W^T + bias) * keep[row]  (convnext_v2.py:53-54, dit.py:225); keep may be NULL */
+int f5_op_gemm_resid_keep(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                          const float* resid, const uint8_t* rowkeep, float* out, int M, int N, int K, int lda, int ldw, int ldo,
+                          int nseg, void* stream);
+/* fp32 [rows][cols] (rows with keep==0 zeroed) -> bf16 (hi, lo) columns [col0, col0+cols) of a [rows][ld] operand matrix */
+int f5_op_pack_bf16(const float* src, const uint8_t* rowkeep, void* out_hi, void* out_lo, int rows, int cols, int ld, int col0,
+                    void* stream);
+/* duration.py:137,188-190 + utils.py:82-90: RMSNorm -> masked mean over n -> Linear(dim->1) -> Softplus; out [B] seconds */
+int f5_op_duration_head(const float* x, const float* g, const float* w, const uint8_t* mask, float* out, int B, int seq_len,
+                        int dim, float eps, void* stream);
 /* dit.py:61-82, 267 small fp32 GEMM */
 int f5_op_time_sinus(const float* t, float* out, int n, int dim, void* stream);
 int f5_op_skinny_gemm(const float* a, const float* w, const float* b, float* out, int M, int N, int K, int silu_in,

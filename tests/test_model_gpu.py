@@ -263,3 +263,39 @@ def test_generate_end_to_end(tiny_weights, tmp_path):
     # two sentences -> per-sentence generation, concatenated (generate.py:199-233); needs a duration heuristic
     w2 = G.generate("One. Two.", estimate_duration=True, steps=2, method="euler", seed=0, f5tts=f5)
     assert w2.ndim == 1 and w2.shape[0] > 0
+
+
+@pytest.mark.parametrize("B,N,nt", [(1, 90, 30), (2, 64, 80)])
+def test_duration_predictor_parity(B, N, nt):
+    """DurationPredictor (duration.py) on the HIP ops vs the oracle; also wired through F5TTS.predict_duration."""
+    from oracle import duration_oracle as DO
+    from f5_tts_mlx_amd.duration import DurationPredictor, DurationTransformer, synthetic_duration_weights
+    kw = dict(dim=512, depth=3, text_num_embeds=70, text_dim=512, conv_layers=2, ff_mult=2)
+    w = synthetic_duration_weights(seed=5, **kw)
+    r = np.random.default_rng(B + N)
+    mel = torch.from_numpy((r.standard_normal((B, N, 100)) * 1.5 - 1.0).astype(np.float32))
+    text = torch.from_numpy(r.integers(0, 70, (B, nt)).astype(np.int32))
+    text[-1, nt - 5:] = -1
+    lens = torch.tensor([N] * B) if B == 1 else torch.tensor([N, N - 11])
+    want = DO.predict(w, mel, text, lens=lens, depth=3, dtype=torch.float64)
+    want_emu = DO.predict(w, mel, text, lens=lens, depth=3, dtype=torch.float64, emulate_bf16=True)
+    for prec, ref, tol in (("bf16x3", want, 2e-4), ("bf16", want_emu, 5e-3)):
+        tr = DurationTransformer(dim=512, depth=3, heads=8, text_dim=512, ff_mult=2, conv_layers=2, text_num_embeds=70,
+                                 precision=prec, device=DEV)
+        dp = DurationPredictor(tr)
+        dp.load_weights(w)
+        got = dp(mel, text, lens=lens)
+        torch.cuda.synchronize()
+        assert got.shape == (B,)
+        mx, _, refm = report(f"duration predictor [{prec}] B{B} N{N} nt{nt}", got.cpu(), ref)
+        assert mx <= tol * max(1.0, refm) and (got > 0).all()
+    # F5TTS.sample(duration=None) asks the predictor (cfm.py:307-308) and turns seconds into frames at 93 frames/s (:260)
+    cfg = TINY
+    model = DiT.from_config(cfg, precision="bf16", device=DEV)
+    model.load_weights(synthetic_weights(cfg, seed=2))
+    f5 = F5TTS(transformer=model, duration_predictor=dp)
+    text_small = torch.from_numpy(r.integers(0, cfg.text_num_embeds, (1, 12)).astype(np.int32))
+    d = f5.predict_duration(mel[:1], text_small, speed=1.0)
+    assert d.dtype == torch.int32 and d.shape == (1,)
+    out, _ = f5.sample(mel[:1], text_small, duration=None, steps=2, method="euler", seed=0)
+    assert out.shape[1] == max(int(d[0]), N + 1)
