@@ -20,7 +20,8 @@ import torch
 from .audio import MelSpec
 from .dit import DiT
 from .rng import mlx_like_normal
-from .utils import default, exists, fetch_from_hub, lens_to_mask, list_str_to_idx, list_str_to_tensor
+from .utils import (default, exists, fetch_from_hub, lens_to_mask, list_str_to_idx, list_str_to_tensor,
+                    mask_from_frac_lengths)
 from .weights import F5TTS_335M, convert_upstream_weights
 
 # ode solvers -- generic host versions with the reference's semantics (cfm.py:38-122); the engine has
@@ -104,7 +105,8 @@ def prepare_lengths(text: torch.Tensor, cond_seq_len: int, batch: int, duration,
 
 
 class F5TTS:
-    """Conditional flow matching wrapper (cfm.py:128-167).  Training (`__call__` loss) is out of scope."""
+    """Conditional flow matching wrapper (cfm.py:128-167).  `__call__` evaluates the training loss forward-only
+    (no autograd through the engine); the optimiser/trainer is out of scope."""
 
     def __init__(
         self,
@@ -134,8 +136,57 @@ class F5TTS:
     def eval(self):
         return self
 
-    def __call__(self, inp, text, *, lens=None):
-        raise NotImplementedError("training loss (cfm.py:169-251) is outside the inference engine's scope")
+    def __call__(self, inp, text, *, lens=None, rand: Optional[dict] = None, generator: Optional[torch.Generator] = None):
+        """cfm.py:169-251 — flow-matching loss (value only).  Extension: `rand` may inject any of the reference's random
+        draws {"frac_lengths" (b,), "span_rand" (b,), "x0" (b,n,d), "time" (b,), "rand_audio_drop", "rand_cond_drop"};
+        the rest come from torch's CPU generator (MLX's stream is not reproduced)."""
+        rand = dict(rand or {})
+        dev = self.transformer.device
+        inp = torch.as_tensor(inp)
+        if inp.ndim == 2:                                                     # :177-180
+            inp = self._mel_spec(inp)
+            inp = inp.transpose(1, 2)     # the reference's "b d n -> b n d" on an already (b, n, d) array: kept as is
+            assert inp.shape[-1] == self.num_channels
+        inp = inp.to(torch.float32)
+        batch, seq_len = inp.shape[:2]
+        if isinstance(text, list):                                            # :185-190
+            text = list_str_to_idx(text, self._vocab_char_map) if exists(self._vocab_char_map) else list_str_to_tensor(text)
+            assert text.shape[0] == batch
+        text = torch.as_tensor(text)
+        if not exists(lens):
+            lens = torch.full((batch,), seq_len, dtype=torch.int32)           # :193-194
+        lens = torch.as_tensor(lens).cpu()
+        mask = lens_to_mask(lens, length=seq_len)                             # :196
+
+        def draw(name, shape, lo=0.0, hi=1.0):
+            if name in rand:
+                return torch.as_tensor(rand[name], dtype=torch.float32).reshape(shape)
+            return torch.rand(shape, generator=generator) * (hi - lo) + lo
+
+        frac_lengths = draw("frac_lengths", (batch,), *self.frac_lengths_mask)                      # :199
+        rand_span_mask = mask_from_frac_lengths(lens, frac_lengths, max_length=seq_len,
+                                                rand=draw("span_rand", (batch,)))                   # :200
+        rand_span_mask = rand_span_mask & mask                                                      # :202-203
+        x1 = inp.to(dev)
+        x0 = (torch.as_tensor(rand["x0"], dtype=torch.float32) if "x0" in rand
+              else torch.randn(tuple(x1.shape), generator=generator)).to(dev)                       # :209
+        time = draw("time", (batch,))                                                               # :212
+        t = time.to(dev)[:, None, None]
+        phi = (1 - t) * x0 + t * x1                                                                 # :216
+        flow = x1 - x0
+        span = rand_span_mask.to(dev)
+        cond = torch.where(span[..., None], torch.zeros_like(x1), x1)                               # :220-224
+        rand_audio_drop = float(draw("rand_audio_drop", (1,)))                                      # :228-229
+        rand_cond_drop = float(draw("rand_cond_drop", (1,)))
+        drop_text = rand_cond_drop < self.cond_drop_prob
+        drop_audio_cond = (rand_audio_drop < self.audio_drop_prob) or drop_text                     # :232
+        pred = self.transformer(x=phi, cond=cond, text=text, time=time, drop_audio_cond=drop_audio_cond,
+                                drop_text=drop_text)                                                # :234-241
+        loss = torch.square(pred - flow)                                                            # :245
+        m = span[..., None].expand(-1, -1, self.num_channels)
+        masked = torch.where(m, loss, torch.zeros_like(loss))
+        loss = masked.sum() / torch.clamp(m.sum().to(torch.float32), min=1e-6)                      # :249
+        return loss.mean()
 
     def predict_duration(self, cond, text, speed: float = 1.0):
         """cfm.py:253-262."""

@@ -309,44 +309,81 @@ int f5_launch_time_sinus(const float* t, float* out, int n, int dim, hipStream_t
     return 0;
 }
 
-// one wave per output column; K % 256 == 0; a is small and L2 resident
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ a, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ out, int M, int N,
-                                                          int K, int silu_in, int silu_out) {
+// out[m][n] = act_out(sum_k act_in(a[m][k]) * w[n][k] + b[n]) for M <= 128 rows in exact fp32 on the matrix cores:
+// v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate, bitwise an fmaf chain).  One wave owns 32 output columns and all
+// rows (ceil(M/32) accumulator blocks); every lane streams 16 B of its W row per step, i.e. 8 k-values per 4 MFMAs:
+// MFMA e pairs k = k0 + e (lanes 0-31) with k = k0 + 4 + e (lanes 32-63) on both operands.  W (the 562 MB of adaLN
+// weights) is read exactly once; the small A operand stays in L2.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+template <int MBLK>
+__global__ __launch_bounds__(256) void skinny_gemm_mfma_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out, int M,
+                                                               int N, int K, int silu_in, int silu_out) {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    const int kc = K >> 8;  // float4 chunks per lane (<= 4)
-    f32x4 wv[4];
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    if (n0 >= N) return;
+    const int hi = lane >> 5, lj = lane & 31;
+    int wn = n0 + lj;
+    if (wn > N - 1) wn = N - 1;
+    const float* wrow = w + (size_t)wn * K + hi * 4;
+    const float* arow[MBLK];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < kc) wv[i] = *reinterpret_cast<const f32x4*>(w + (size_t)n * K + i * 256 + lane * 4);
-    const float bn = bias ? bias[n] : 0.0f;
-    for (int m = 0; m < M; ++m) {
-        float acc = 0.0f;
+    for (int mb = 0; mb < MBLK; ++mb) {
+        int m = mb * 32 + lj;
+        if (m > M - 1) m = M - 1;
+        arow[mb] = a + (size_t)m * K + hi * 4;
+    }
+    f32x16_t acc[MBLK];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < kc) {
-                f32x4 av = *reinterpret_cast<const f32x4*>(a + (size_t)m * K + i * 256 + lane * 4);
-                if (silu_in) {
+    for (int mb = 0; mb < MBLK; ++mb)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) av[e] = f5_silu(av[e]);
-                }
-                acc += (av[0] * wv[i][0] + av[1] * wv[i][1]) + (av[2] * wv[i][2] + av[3] * wv[i][3]);
+        for (int e = 0; e < 16; ++e) acc[mb][e] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k0);
+#pragma unroll
+        for (int mb = 0; mb < MBLK; ++mb) {
+            f32x4 av = *reinterpret_cast<const f32x4*>(arow[mb] + k0);
+            if (silu_in) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = f5_silu(av[e]);
             }
-        acc = f5_wave_sum(acc);
-        if (lane == 0) {
-            float r = acc + bn;
-            if (silu_out) r = f5_silu(r);
-            out[(size_t)m * N + n] = r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wv[e], acc[mb], 0, 0, 0);
         }
+    }
+    const int col = n0 + lj;
+    if (col < N) {
+        const float bn = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int mb = 0; mb < MBLK; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < M) {
+                    float v = acc[mb][r] + bn;
+                    if (silu_out) v = f5_silu(v);
+                    out[(size_t)m * N + col] = v;
+                }
+            }
     }
 }
 int f5_launch_skinny_gemm(const float* a, const float* w, const float* b, float* out, int M, int N, int K, int silu_in,
                           int silu_out, hipStream_t s) {
-    F5_REQUIRE(K % 256 == 0 && K <= 1024, "skinny_gemm: K must be a multiple of 256 and <= 1024 (got %d)", K);
-    hipLaunchKernelGGL(skinny_gemm_kernel, dim3(f5_cdiv(N, 4)), dim3(256), 0, s, a, w, b, out, M, N, K, silu_in, silu_out);
-    F5_LAUNCH_CHECK();
+    F5_REQUIRE(K % 8 == 0, "skinny_gemm: K must be a multiple of 8 (got %d)", K);
+    F5_REQUIRE(M >= 1 && N >= 1, "skinny_gemm: empty problem (M=%d N=%d)", M, N);
+    const dim3 grid(f5_cdiv(f5_cdiv(N, 32), 4)), block(256);
+    for (int m0 = 0; m0 < M; m0 += 128) {       // 128 rows (4 accumulator blocks) per pass over W
+        const int mc = M - m0 < 128 ? M - m0 : 128;
+        const float* ap = a + (size_t)m0 * K;
+        float* op = out + (size_t)m0 * N;
+        switch ((mc + 31) / 32) {
+            case 1: hipLaunchKernelGGL((skinny_gemm_mfma_kernel<1>), grid, block, 0, s, ap, w, b, op, mc, N, K, silu_in, silu_out); break;
+            case 2: hipLaunchKernelGGL((skinny_gemm_mfma_kernel<2>), grid, block, 0, s, ap, w, b, op, mc, N, K, silu_in, silu_out); break;
+            case 3: hipLaunchKernelGGL((skinny_gemm_mfma_kernel<3>), grid, block, 0, s, ap, w, b, op, mc, N, K, silu_in, silu_out); break;
+            default: hipLaunchKernelGGL((skinny_gemm_mfma_kernel<4>), grid, block, 0, s, ap, w, b, op, mc, N, K, silu_in, silu_out); break;
+        }
+        F5_LAUNCH_CHECK();
+    }
     return 0;
 }
 

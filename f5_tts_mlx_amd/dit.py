@@ -56,20 +56,40 @@ class DiT:
         self.engine.load_weights({k: np.asarray(v) for k, v in weights.items()})
 
     def __call__(self, x, cond, text, time, drop_audio_cond, drop_text, mask=None) -> torch.Tensor:
-        """dit.py:374-401 — one forward.  Only the two flag combinations the sampler uses exist in the
-        engine: (False, False) = conditional, (True, True) = null branch."""
-        if bool(drop_audio_cond) != bool(drop_text):
-            raise NotImplementedError("engine evaluates (drop_audio_cond, drop_text) = (False, False) or (True, True)")
+        """dit.py:374-401 — one forward.  The engine evaluates the conditional branch (False, False) and the null branch
+        (True, True).  (True, False) — audio conditioning dropped, text kept (training, cfm.py:222-225) — is the conditional
+        branch on a zeroed `cond` (dit.py:245-247); (False, True) never occurs in the reference (drop_text forces
+        drop_audio_cond, cfm.py:225).  `time` may be a scalar or a (b,) tensor; rows with different times run as separate
+        batch-1 forwards, which is exact when `mask is None` (no cross-utterance arithmetic in the DiT)."""
+        drop_audio_cond, drop_text = _flag(drop_audio_cond), _flag(drop_text)
+        if drop_text and not drop_audio_cond:
+            raise NotImplementedError("(drop_audio_cond, drop_text) = (False, True) is not a combination the reference uses")
         B, N, _ = x.shape
         x = x.to(self.device, torch.float32).contiguous()
         cond = cond.to(self.device, torch.float32).contiguous()
         text = text.to(self.device, torch.int32).contiguous()
-        t = float(time if not torch.is_tensor(time) else time.reshape(-1)[0])
+        if drop_audio_cond and not drop_text:
+            cond = torch.zeros_like(cond)
+        if torch.is_tensor(time) and time.numel() > 1:
+            times = [float(v) for v in time.reshape(-1).tolist()]
+            if len(times) != B:
+                raise ValueError(f"time has {len(times)} entries for a batch of {B}")
+        else:
+            times = [float(time if not torch.is_tensor(time) else time.reshape(-1)[0])] * B
+        if len(set(times)) > 1:
+            if mask is not None:
+                raise NotImplementedError("per-row times together with a key-padding mask")
+            outs = [self(x[i:i + 1], cond[i:i + 1], text[i:i + 1], times[i], drop_audio_cond, drop_text) for i in range(B)]
+            return torch.cat(outs, dim=0)
         if mask is not None:
             durations = mask.sum(dim=-1).to(torch.int32).tolist()
         else:
             durations = [N] * B
         # `cond` arrives already masked (step_cond), so the conditioning length is the full sequence
-        pred, null = self.engine.dit_forward(x, text, cond, [N] * B, durations, t, cfg_strength=2.0,
-                                             use_mask=mask is not None)
+        pred, null = self.engine.dit_forward(x, text, cond, [N] * B, durations, times[0],
+                                             cfg_strength=2.0 if drop_text else 0.0, use_mask=mask is not None)
         return null if drop_text else pred
+
+
+def _flag(v) -> bool:
+    return bool(v.reshape(-1)[0]) if torch.is_tensor(v) else bool(v)

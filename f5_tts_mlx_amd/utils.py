@@ -43,6 +43,30 @@ def pad_to_length(t: torch.Tensor, length: int, value=0) -> torch.Tensor:
     return t[..., :length]
 
 
+def mask_from_start_end_indices(seq_len: torch.Tensor, start: torch.Tensor, end: torch.Tensor,
+                                max_length: Optional[int] = None) -> torch.Tensor:
+    """utils.py:50-58 (`max_length` is used as given: the reference's default to seq_len.max() is commented out)."""
+    seq = torch.arange(max_length, dtype=torch.int32, device=start.device)
+    return (seq[None, :] >= start[:, None]) & (seq[None, :] < end[:, None])
+
+
+def mask_from_frac_lengths(seq_len: torch.Tensor, frac_lengths: torch.Tensor, max_length: Optional[int] = None,
+                           rand: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """utils.py:61-79.  Extension: `rand` injects the uniform draw of :68 (parity tests); index math in float32 -> int32
+    truncation exactly as `astype(mx.int32)`."""
+    seq_len = torch.as_tensor(seq_len)
+    lengths = (frac_lengths.to(torch.float32) * seq_len.to(torch.float32)).to(torch.int32)
+    max_start = seq_len.to(torch.int32) - lengths
+    if rand is None:
+        rand = torch.rand(frac_lengths.shape, generator=generator)
+    start = torch.clamp((max_start.to(torch.float32) * rand.to(torch.float32)).to(torch.int32), min=0)
+    end = start + lengths
+    out = mask_from_start_end_indices(seq_len, start, end, max_length)
+    if exists(max_length):
+        out = pad_to_length(out, max_length)
+    return out
+
+
 def pad_sequence(t: Sequence[torch.Tensor], padding_value=0) -> torch.Tensor:
     """utils.py:106-109."""
     max_len = max([i.shape[-1] for i in t])

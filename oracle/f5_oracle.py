@@ -510,3 +510,75 @@ def sample(
         return out, trajectory, dict(lens=lens, duration=duration, cond_mask=cond_mask[..., 0], mask=mask,
                                      step_cond=step_cond, t=t, text=text)
     return out, trajectory
+
+# ------------------------------------------------------------------------------------------------
+# F5TTS.__call__ — flow-matching training loss, forward only (cfm.py:169-251; utils.py:50-79)
+# ------------------------------------------------------------------------------------------------
+
+def mask_from_start_end_indices(seq_len: Tensor, start: Tensor, end: Tensor, max_length: int) -> Tensor:
+    """utils.py:50-58: `max_length` is used unconditionally (the default to seq_len.max() is commented out)."""
+    seq = torch.arange(max_length, dtype=torch.int32)
+    return (seq[None, :] >= start[:, None]) & (seq[None, :] < end[:, None])
+
+
+def mask_from_frac_lengths(seq_len: Tensor, frac_lengths: Tensor, rand: Tensor, max_length: int) -> Tensor:
+    """utils.py:61-79 with the uniform draw `rand` (:68) injected.  float32 products truncated toward zero (`astype(int32)`)."""
+    seq_len = torch.as_tensor(seq_len)
+    lengths = (frac_lengths.to(torch.float32) * seq_len.to(torch.float32)).to(torch.int32)          # :65
+    max_start = seq_len.to(torch.int32) - lengths                                                    # :66
+    start = torch.clamp((max_start.to(torch.float32) * rand.to(torch.float32)).to(torch.int32), min=0)   # :70
+    end = start + lengths                                                                            # :71
+    out = mask_from_start_end_indices(seq_len, start, end, max_length)                               # :73
+    return pad_to_length(out, max_length)                                                            # :75-76
+
+
+def cfm_loss(
+    dit: DiTOracle,
+    inp: Tensor,                       # mel (b, n, d)
+    text: Union[Tensor, List[str], List[List[str]]],
+    *,
+    lens: Optional[Tensor] = None,
+    x0: Tensor,                        # (b, n, d)  the gaussian draw of cfm.py:201
+    time: Tensor,                      # (b,)       uniform(0,1) draw of :204
+    frac_lengths: Tensor,              # (b,)       uniform(*frac_lengths_mask) draw of :190
+    span_rand: Tensor,                 # (b,)       uniform(0,1) draw inside mask_from_frac_lengths
+    rand_audio_drop: float,            # :220
+    rand_cond_drop: float,             # :221
+    audio_drop_prob: float = 0.3,
+    cond_drop_prob: float = 0.2,
+    vocab_char_map: Optional[Dict[str, int]] = None,
+    return_aux: bool = False,
+):
+    """Restatement of `F5TTS.__call__` with every random draw injected (the MLX PRNG is third-party).  Mel input only:
+    the raw-wave branch (:177-180) transposes an already (b, frames, mels) array and is dead code in the reference."""
+    dtype = dit.dtype
+    inp = torch.as_tensor(inp).to(dtype)
+    assert inp.ndim == 3 and inp.shape[-1] == dit.cfg.mel_dim
+    batch, seq_len = inp.shape[:2]
+    if isinstance(text, list):                                                # :185-190
+        text = list_str_to_idx(text, vocab_char_map) if vocab_char_map is not None else list_str_to_tensor(text)
+        assert text.shape[0] == batch
+    text = torch.as_tensor(text)
+    if lens is None:
+        lens = torch.full((batch,), seq_len, dtype=torch.int32)               # :193-194
+    lens = torch.as_tensor(lens)
+    mask = lens_to_mask(lens, length=seq_len)                                 # :196
+    rand_span_mask = mask_from_frac_lengths(lens, frac_lengths, span_rand, seq_len) & mask   # :199-203
+    x1 = inp
+    x0 = torch.as_tensor(x0).to(dtype)
+    time = torch.as_tensor(time).to(dtype)
+    t = time[:, None, None]
+    phi = (1 - t) * x0 + t * x1                                               # :210
+    flow = x1 - x0                                                            # :211
+    cond = torch.where(rand_span_mask[..., None], torch.zeros_like(x1), x1)   # :214-218
+    drop_text = bool(rand_cond_drop < cond_drop_prob)                         # :222-225
+    drop_audio_cond = bool(rand_audio_drop < audio_drop_prob) or drop_text
+    pred = dit.forward(phi, cond, text, time, drop_audio_cond, drop_text, None)   # :227-234 (no mask is passed)
+    loss = (pred - flow) ** 2                                                 # :238
+    m = rand_span_mask[..., None].expand(-1, -1, dit.cfg.mel_dim)             # :240
+    masked = torch.where(m, loss, torch.zeros_like(loss))
+    loss = masked.sum() / torch.clamp(m.sum().to(dtype), min=1e-6)            # :242
+    if return_aux:
+        return loss, dict(rand_span_mask=rand_span_mask, pred=pred, flow=flow, cond=cond, phi=phi,
+                          drop_audio_cond=drop_audio_cond, drop_text=drop_text)
+    return loss

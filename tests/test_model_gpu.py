@@ -82,8 +82,12 @@ def test_dit_call_signature(tiny_bf16, tiny_weights):
     null = tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=True, drop_text=True, mask=None)
     assert out.shape == (1, 40, cfg.mel_dim) and null.shape == out.shape
     assert float((out - null).abs().mean()) > 1e-4
+    # audio conditioning dropped, text kept (training combination) == conditional branch on a zero cond (dit.py:245-247)
+    a = tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=True, drop_text=False)
+    b = tiny_bf16(x=y0, cond=torch.zeros_like(sc), text=text, time=torch.tensor(0.5), drop_audio_cond=False, drop_text=False)
+    assert torch.equal(a, b) and float((a - out).abs().mean()) > 1e-4
     with pytest.raises(NotImplementedError):
-        tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=True, drop_text=False)
+        tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=False, drop_text=True)
 
 
 @pytest.mark.parametrize("method,steps", [("euler", 8), ("midpoint", 5), ("rk4", 4)])
@@ -352,3 +356,32 @@ def test_full_size_sample_parity_short_solve():
         assert l1 <= (MEL_L1_TOL if prec == "bf16x3" else 3e-2)
         del m
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("drops", [(0.9, 0.9), (0.1, 0.9), (0.9, 0.1)])     # (keep, keep) / audio dropped / both dropped
+def test_cfm_loss_forward_parity(tiny_weights, tiny_x3, drops):
+    """F5TTS.__call__ (cfm.py:169-251), forward only, every random draw injected identically into engine and oracle;
+    the span mask (int32 index math) must be bit-exact, the loss within fp32-class tolerance."""
+    cfg, B, N = TINY, 2, 96
+    g = torch.Generator().manual_seed(11)
+    mel = torch.randn((B, N, cfg.mel_dim), generator=g) * 2.0 - 1.0
+    text = torch.randint(0, cfg.text_num_embeds, (B, 20), generator=g, dtype=torch.int32)
+    text[1, 15:] = -1
+    lens = torch.tensor([N, 71], dtype=torch.int32)
+    rand = dict(frac_lengths=torch.tensor([0.73, 0.91]), span_rand=torch.tensor([0.42, 0.08]),
+                x0=torch.randn((B, N, cfg.mel_dim), generator=g), time=torch.tensor([0.31, 0.77]),
+                rand_audio_drop=drops[0], rand_cond_drop=drops[1])
+    orc = O.DiTOracle(cfg, tiny_weights)
+    ref, aux = O.cfm_loss(orc, mel, text, lens=lens, return_aux=True, **rand)
+    tts = F5TTS(tiny_x3)
+    from f5_tts_mlx_amd.utils import mask_from_frac_lengths
+    span = mask_from_frac_lengths(lens, rand["frac_lengths"], max_length=N, rand=rand["span_rand"]) & O.lens_to_mask(lens, N)
+    assert torch.equal(span, aux["rand_span_mask"])
+    got = float(tts(mel, text, lens=lens, rand=rand))
+    print(f"cfm loss drops={drops}: engine {got:.6f} oracle {float(ref):.6f} (drop_audio={aux['drop_audio_cond']}, "
+          f"drop_text={aux['drop_text']})")
+    assert abs(got - float(ref)) <= 2e-4 * max(1.0, abs(float(ref)))
+    # unseeded call: draws come from torch's generator, the value is finite and reproducible under the same generator
+    a = float(tts(mel, text, lens=lens, generator=torch.Generator().manual_seed(5)))
+    b = float(tts(mel, text, lens=lens, generator=torch.Generator().manual_seed(5)))
+    assert np.isfinite(a) and a == b

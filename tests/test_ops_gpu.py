@@ -341,6 +341,20 @@ def test_time_tables(lib):
         assert mx <= 1e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 96, 64), (33, 70, 256), (124, 1000, 1024), (200, 257, 128)])
+def test_skinny_gemm_shapes(lib, M, N, K):
+    """fp32 MFMA skinny GEMM at ragged row/column counts (row chunks of 128, partial 32-column groups)."""
+    r = rng(77)
+    a, w, b = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+    a_d, w_d, b_d = a.to(DEV), w.to(DEV), b.to(DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    E.check(lib.f5_op_skinny_gemm(P(a_d), P(w_d), P(b_d), P(out), M, N, K, 1, 0, stream()))
+    sync()
+    ref = F.silu(a.double()) @ w.double().T + b.double()
+    mx, _, _ = report(f"skinny gemm {M}x{N}x{K}", out.cpu(), ref)
+    assert mx <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_cfg_axpy(lib):
     r = rng(9)
     rows, mel = 77, 100
