@@ -451,6 +451,264 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 }
 
 // =================================================================================================
+// v2s: v2 with the KV range split across KS wave groups INSIDE the workgroup (small batches: B*H*ceil(N/128)
+// workgroups of 4 waves leave the 256 CUs with one wave per SIMD and the whole kernel is one workgroup's latency
+// chain over all KV tiles).  Group g (4 waves, the same 128 queries as the other groups) walks tiles g, g+KS, ...
+// with its own LDS ring; barriers are shared, so every group runs ceil(ntile/KS) iterations.  At the end groups
+// 1..KS-1 park (m, l, O^T) in LDS (the rings are dead by then) and group 0 merges them flash-decoding style:
+// m = max m_g, l = sum l_g 2^((m_g-m)c), O = sum O_g 2^((m_g-m)c) — the same numbers as one pass up to fp32 rounding.
+// =================================================================================================
+template <bool HP, int KS, int NST>
+__global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
+    constexpr int NP = HP ? 2 : 1;
+    constexpr int TILE = 64 * 64;
+    constexpr int RING = NST * NP * 2 * TILE;           // elements per group ring
+    static_assert(KS * RING * 2 <= 160 * 1024, "LDS budget");
+    static_assert((KS - 1) * 4 * 34 * 64 * 4 <= KS * RING * 2, "merge area must fit in the rings");
+    __shared__ __attribute__((aligned(16))) bf16_t smem_all[KS * RING];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave_all >> 2, wave = wave_all & 3;
+    const int tg = tid & 255;
+    bf16_t* smem = smem_all + grp * RING;
+    const int hi = lane >> 5, lq = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
+    const int ntile = (kvlen + 63) >> 6;
+    const int nit = (ntile + KS - 1) / KS;              // iterations of group 0 (the most)
+    const int ntg = ntile > grp ? (ntile - grp + KS - 1) / KS : 0;   // tiles of this group
+    const size_t rowbase = (size_t)b * p.seq_len;
+
+    bf16x8 qf[NP][4];
+    {
+        int qr = q0 + lq;
+        if (qr > p.seq_len - 1) qr = p.seq_len - 1;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                qf[pp][ks] = *reinterpret_cast<const bf16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+    }
+
+    const bf16_t* kptr[NP][2];
+    const bf16_t* vptr[NP][2];
+    int krow[2], kcol[2], ldsoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q_ = i * 256 + tg;
+        const int srow = q_ >> 3;
+        const int schunk = (q_ & 7) ^ ((srow >> 1) & 7);
+        krow[i] = attn_kperm(srow);
+        kcol[i] = p.dmodel + h * 64 + schunk * 8;
+        ldsoff[i] = (i * 256 + wave * 64) * 8;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            kptr[pp][i] = p.qk[pp] + (rowbase + grp * 64 + krow[i]) * p.ldqk + kcol[i];
+            vptr[pp][i] = p.vt[pp] + ((size_t)bh * 64 + srow) * p.npad + grp * 64 + schunk * 8;
+        }
+    }
+    const size_t kstep = (size_t)64 * KS * p.ldqk;
+    // jj_ = group-local tile number; the global tile is jj_*KS + grp
+#define A2S_ISSUE(jj_)                                                                                       \
+    {                                                                                                        \
+        bf16_t* st_ = smem + ((jj_) % NST) * (NP * 2 * TILE);                                                \
+        const int gt_ = (jj_) * KS + grp;                                                                    \
+        const bool tail_ = (gt_ * 64 + 63) > p.seq_len - 1;                                                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                              \
+                const bf16_t* ks_ = kptr[pp][i];                                                             \
+                if (tail_) {                                                                                 \
+                    int key_ = gt_ * 64 + krow[i];                                                           \
+                    if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                          \
+                    ks_ = p.qk[pp] + (rowbase + key_) * p.ldqk + kcol[i];                                    \
+                }                                                                                            \
+                attn_glds16(ks_, st_ + (pp * 2) * TILE + ldsoff[i]);                                         \
+                attn_glds16(vptr[pp][i], st_ + (pp * 2 + 1) * TILE + ldsoff[i]);                             \
+                kptr[pp][i] += kstep;                                                                        \
+                vptr[pp][i] += 64 * KS;                                                                      \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        o[0][e] = 0.0f;
+        o[1][e] = 0.0f;
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    if (ntg > 0) A2S_ISSUE(0);
+    if (NST == 3 && ntg > 1) A2S_ISSUE(1);
+
+    for (int jj = 0; jj < nit; ++jj) {
+        if (NST == 3 && jj + 1 < ntg) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (jj + NST - 1 < ntg) A2S_ISSUE(jj + NST - 1);
+        if (jj >= ntg) continue;                          // wave-uniform: this group has no tile left (still meets the barrier)
+
+        const bf16_t* st = smem + (jj % NST) * (NP * 2 * TILE);
+        const bf16_t* sK = st;
+        const bf16_t* sV = st + TILE;
+        const bf16_t* sKl = st + (NP - 1) * 2 * TILE;
+        const bf16_t* sVl = st + (NP - 1) * 2 * TILE + TILE;
+
+        f32x16 s[2];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kb][e] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = attn_swz(kb * 32 + lq, ks * 2 + hi);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sK[off]);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[kb], 0, 0, 0);
+                if (HP) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sKl[off]);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[0][ks], s[kb], 0, 0, 0);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+
+        const int key0 = (jj * KS + grp) * 64;
+        if (key0 + 64 > kvlen) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kb * 32 + 16 * hi + r;
+                    if (key >= kvlen) s[kb][r] = -INFINITY;
+                }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        if (__any(tmax > m_run)) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o[0][e] *= alpha;
+                o[1][e] *= alpha;
+            }
+        }
+        const float mc = m_run * c2;
+        float psum = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
+                s[kb][r] = pv;
+                psum += pv;
+            }
+        l_run += psum;
+
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ++ks4) {
+            const int kb = ks4 >> 1, sp = ks4 & 1;
+            uint32_t pw[4], pwl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p0 = s[kb][8 * sp + 2 * e], p1 = s[kb][8 * sp + 2 * e + 1];
+                pw[e] = f5_pack2(p0, p1);
+                if (HP) pwl[e] = f5_pack2_lo(p0, p1);
+            }
+            const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+            bf16x8 pbl = pb;
+            if (HP) pbl = __builtin_bit_cast(bf16x8, u32x4{pwl[0], pwl[1], pwl[2], pwl[3]});
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int voff = attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sV[voff]);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                if (HP) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sVl[voff]);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pb, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pbl, o[db], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+#undef A2S_ISSUE
+
+    // ---- merge the KS partial states (same lane of the same wave index in every group holds the same elements)
+    __syncthreads();                                     // every ring is dead
+    float* mrg = reinterpret_cast<float*>(smem_all);     // [KS-1][4 waves][34][64 lanes]
+    if (grp > 0) {
+        float* dst = mrg + (size_t)((grp - 1) * 4 + wave) * 34 * 64 + lane;
+        dst[0] = m_run;
+        dst[64] = l_run;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[(2 + db * 16 + e) * 64] = o[db][e];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+    float m_all = m_run;
+#pragma unroll
+    for (int g = 1; g < KS; ++g) m_all = fmaxf(m_all, mrg[(size_t)((g - 1) * 4 + wave) * 34 * 64 + lane]);
+    {
+        const float a0 = __builtin_amdgcn_exp2f((m_run - m_all) * c2);
+        l_run *= a0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            o[0][e] *= a0;
+            o[1][e] *= a0;
+        }
+    }
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+        const float* src = mrg + (size_t)((g - 1) * 4 + wave) * 34 * 64 + lane;
+        const float ag = __builtin_amdgcn_exp2f((src[0] - m_all) * c2);    // empty group: m = -inf -> 0
+        l_run += src[64] * ag;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[db][e] += src[(2 + db * 16 + e) * 64] * ag;
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + lq;
+    if (qr < p.seq_len) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = db * 32 + 8 * rg + 4 * hi;
+                const float v0 = o[db][rg * 4 + 0] * inv, v1 = o[db][rg * 4 + 1] * inv;
+                const float v2 = o[db][rg * 4 + 2] * inv, v3 = o[db][rg * 4 + 3] * inv;
+                const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
+                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+                if (HP && p.out[1])
+                    *reinterpret_cast<u32x2*>(p.out[1] + off) = u32x2{f5_pack2_lo(v0, v1), f5_pack2_lo(v2, v3)};
+            }
+    }
+}
+
+// =================================================================================================
 // v3 (bf16 only): v2 + software pipelining inside the wave.  Ablations of v2 (tools/attn_ablate.py) show that
 // QK^T MFMAs, softmax VALU and PV MFMAs each cost ~1/3 of the time and do not overlap: co-resident waves run the
 // same phase at the same time.  Here the 8 MFMAs of S(j+1) = K(j+1) Q^T are issued in the same basic block as the
@@ -642,6 +900,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
 
 int f5_attn_version = 2;   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower)
 int f5_attn_ablation = 0;  // timing experiments only
+int f5_attn_kvsplit = -1;  // -1 auto, 1 / 2 / 4 = force the in-workgroup KV split (debug hook)
 
 int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     F5_REQUIRE(a.B > 0 && a.H > 0 && a.seq_len > 0, "attention: bad shape");
@@ -649,6 +908,27 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     F5_REQUIRE(a.ldqk % 8 == 0 && a.ldo % 4 == 0, "attention: bad leading dims");
     F5_REQUIRE(a.qk[0] && a.vt[0] && a.out[0], "attention: null pointer");
     dim3 grid(f5_cdiv(a.seq_len, 128), a.B * a.H);
+    // small batches: fewer workgroups than ~2 per CU -> split the KV range over 2 or 4 wave groups inside the workgroup
+    int ks = f5_attn_kvsplit;
+    if (ks < 0) {
+        const long wgs = (long)grid.x * grid.y;
+        const int ntile = f5_cdiv(a.seq_len, 64);
+        // measured (tools/attn_split_bench.py, N = 937, 16 heads): 128 WGs 20.5 / 17.4 / 16.2 us for 1 / 2 / 4 groups,
+        // 256 WGs 21.4 / 19.1 / 20.1, 512 WGs 31.8 / 37.3 / 38.9
+        ks = (wgs <= 160 && ntile >= 8) ? 4 : ((wgs <= 320 && ntile >= 4) ? 2 : 1);
+    }
+    if (f5_attn_version == 2 && f5_attn_ablation == 0 && ks > 1) {
+        if (a.hp) {
+            F5_REQUIRE(a.qk[1] && a.vt[1] && a.out[1], "attention: bf16x3 needs lo buffers");
+            hipLaunchKernelGGL((f5_attn2s_kernel<true, 2, 2>), grid, dim3(512), 0, stream, a);
+        } else if (ks >= 4) {
+            hipLaunchKernelGGL((f5_attn2s_kernel<false, 4, 2>), grid, dim3(1024), 0, stream, a);
+        } else {
+            hipLaunchKernelGGL((f5_attn2s_kernel<false, 2, 3>), grid, dim3(512), 0, stream, a);
+        }
+        F5_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.hp) {
         F5_REQUIRE(a.qk[1] && a.vt[1] && a.out[1], "attention: bf16x3 needs lo buffers");
         if (f5_attn_version >= 2) hipLaunchKernelGGL((f5_attn2_kernel<true, 0>), grid, dim3(256), 0, stream, a);

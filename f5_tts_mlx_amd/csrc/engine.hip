@@ -858,6 +858,12 @@ extern "C" int f5_debug_set_attn_ablation(int v) {
     f5_attn_ablation = v;
     return 0;
 }
+extern int f5_attn_kvsplit;
+extern "C" int f5_debug_set_attn_kvsplit(int v) {
+    F5_REQUIRE(v == -1 || v == 1 || v == 2 || v == 4, "attention KV split must be -1 (auto), 1, 2 or 4");
+    f5_attn_kvsplit = v;
+    return 0;
+}
 extern int f5_gemm_big_kernel;
 extern int f5_gemm_v3_stagger;
 extern "C" int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles) {
@@ -884,7 +890,7 @@ extern "C" int f5_debug_set_gemm_flags(int v) {
 }
 extern int f5_gemm_tile_override;
 extern "C" int f5_debug_set_gemm_tile(int sel) {
-    F5_REQUIRE(sel >= 0 && sel <= 7, "gemm tile override must be 0 (auto) .. 7");
+    F5_REQUIRE(sel >= 0 && sel <= 11, "gemm tile override must be 0 (auto) .. 11");
     f5_gemm_tile_override = sel;
     return 0;
 }

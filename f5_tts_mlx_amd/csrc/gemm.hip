@@ -153,6 +153,19 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
 }
 
 // block tile = (64*MB) x (64*NB), 4 waves in a 2x2 grid, wave tile = (32*MB) x (32*NB)
+// Small-tile kernels: bf16-output epilogues go through the LDS-staged 16-byte-store path when the whole block tile lies
+// inside N (the direct path issues 2-byte stores, and for QKV strided 2-byte V^T stores).  Needs one barrier (the K ring
+// is dead afterwards) and, for the QKV head split, wave tiles that are whole heads (32*NB % 64 == 0).
+template <int EPI, int NB>
+__device__ __forceinline__ constexpr bool small_tile_staged() {
+    return (NB & (NB - 1)) == 0 &&
+           ((EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16) || (EPI == EPI_QKV_ROPE && NB % 2 == 0));
+}
+template <int NB>
+__device__ __forceinline__ constexpr int small_tile_stage_elems() {   // bf16 elements of LDS per wave
+    return 2 * 32 * (32 * NB + 8) > (32 * NB) * 40 ? 2 * 32 * (32 * NB + 8) : (32 * NB) * 40;
+}
+
 template <int EPI, int MB, int NB>
 __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
     constexpr int BMt = 64 * MB, BNt = 64 * NB;
@@ -258,6 +271,13 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
         __syncthreads();
     }
 
+    if (small_tile_staged<EPI, NB>() && n0 + BNt <= p.N && (p.debug_flags & 2) == 0) {
+        static_assert(!small_tile_staged<EPI, NB>() || 4 * small_tile_stage_elems<NB>() <= 2 * (BMt + BNt) * BK, "staging fits");
+        __syncthreads();
+        staged_epilogue_bf16<EPI, MB, NB>(p, acc, &smem[0][0] + wave * small_tile_stage_elems<NB>(), m0 + wm * (32 * MB),
+                                          n0 + wn * (32 * NB), lane);
+        return;
+    }
     gemm_epilogue<EPI, MB, NB>(p, acc, m0, n0, wm, wn, lane);
 }
 
@@ -363,24 +383,27 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
             __builtin_amdgcn_wave_barrier();
         }
     } else {
-        // ---- V: transposed staging, [W d-rows][64 tokens (+8 pad)] per pass of two 32-row blocks, hi then lo
-        constexpr int TLD = 72;
+        // ---- V: transposed staging, [W d-rows][32*MP tokens (+8 pad)] per pass of MP 32-row blocks, hi then lo
+        constexpr int MP = MBW >= 2 ? 2 : 1;
+        static_assert(MBW % MP == 0, "row blocks per pass");
+        constexpr int TLD = 32 * MP + 8;
+        constexpr int CPD = 4 * MP;           // 16-byte chunks per d-row
         const int head0 = (colbase - 2 * p.dmodel) >> 6;
         const bool two_v = p.vt[1] != nullptr;
 #pragma unroll
-        for (int mq = 0; mq < MBW / 2; ++mq) {
+        for (int mq = 0; mq < MBW / MP; ++mq) {
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
                 if (part == 1 && !two_v) break;
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
+                for (int mb = 0; mb < MP; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
                             float v[4];
 #pragma unroll
-                            for (int ri = 0; ri < 4; ++ri) v[ri] = acc[mq * 2 + mb][nb][rg * 4 + ri] + bcol[nb];
+                            for (int ri = 0; ri < 4; ++ri) v[ri] = acc[mq * MP + mb][nb][rg * 4 + ri] + bcol[nb];
                             const u32x2 pk = part == 0 ? u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])}
                                                        : u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
                             const int tok = mb * 32 + rg * 8 + 4 * hi;
@@ -389,10 +412,10 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
                 __builtin_amdgcn_wave_barrier();
                 u16* dstbase = reinterpret_cast<u16*>(p.vt[part]);
 #pragma unroll
-                for (int i = 0; i < W / 8; ++i) {
+                for (int i = 0; i < W * CPD / 64; ++i) {
                     const int c = i * 64 + lane;
-                    const int d = c >> 3, t0 = (c & 7) * 8;
-                    const int grow = row0 + mq * 64 + t0;
+                    const int d = c / CPD, t0 = (c % CPD) * 8;
+                    const int grow = row0 + mq * (32 * MP) + t0;
                     if (grow < p.M) {
                         const int b = grow / p.seq_len;
                         const int n = grow - b * p.seq_len;
@@ -669,13 +692,20 @@ static bool gemm_mfast(const F5GemmArgs& a) {
     return a_bytes <= (size_t)4 << 20;     // whole A operand fits in one XCD's 4 MB L2
 }
 
-template <int EPI, int MB, int NB, int NST>
-__global__ __launch_bounds__(256) void f5_gemm_ring_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
-    constexpr int BMt = 64 * MB, BNt = 64 * NB;
-    constexpr int NA = MB * 2, NW = NB * 2;
+template <int EPI, int MB, int NB, int NST, int WM = 2, int WN = 2, int KS = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
+    // WM x WN waves per K group, wave tile 32*MB x 32*NB; KS groups split the K tiles round-robin (group g owns tiles
+    // g, g+KS, ...; its own ring) and are summed in group order through LDS at the end: small-M problems are one round
+    // of workgroups whose run time is a single workgroup's chain of K steps, which KS cuts by KS.
+    constexpr int NTG = 64 * WM * WN;                   // threads per K group
+    constexpr int BMt = 32 * MB * WM, BNt = 32 * NB * WN;
+    constexpr int NA = BMt * 8 / NTG, NW = BNt * 8 / NTG;
+    static_assert(NA * NTG == BMt * 8 && NW * NTG == BNt * 8, "tile rows must divide over the threads");
     constexpr int G = NA + NW;                          // global_load_lds per thread per K tile
     constexpr int STAGE = (BMt + BNt) * BK;             // elements
-    __shared__ __attribute__((aligned(16))) bf16_t smem[NST * STAGE];
+    constexpr int RING = NST * STAGE;
+    static_assert(KS * RING * 2 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) bf16_t smem_all[KS * RING];
 
     const int bid = blockIdx.x;
     const int q = ntiles >> 3, r = ntiles & 7;
@@ -695,35 +725,42 @@ __global__ __launch_bounds__(256) void f5_gemm_ring_kernel(F5GemmArgs p, int til
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave_all / (WM * WN), wave = wave_all % (WM * WN);
+    const int tg = tid - grp * NTG;
+    const int wm = wave / WN, wn = wave % WN;
+    bf16_t* smem = smem_all + grp * RING;
 
     size_t a_src[NA], w_src[NW];
     int a_dst[NA], w_dst[NW];                           // wave-uniform LDS element offsets inside a stage
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int q_ = i * 256 + tid;
+        const int q_ = i * NTG + tg;
         const int row = q_ >> 3, chunk = (q_ & 7) ^ ((row >> 1) & 7);
         int gr = m0 + row;
         if (gr > p.M - 1) gr = p.M - 1;
         if (p.a_row_mod > 0) gr = gr % p.a_row_mod;
         a_src[i] = (size_t)gr * p.lda + chunk * 8;
-        a_dst[i] = (i * 256 + wave * 64) * 8;
+        a_dst[i] = (i * NTG + wave * 64) * 8;
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        const int q_ = i * 256 + tid;
+        const int q_ = i * NTG + tg;
         const int row = q_ >> 3, chunk = (q_ & 7) ^ ((row >> 1) & 7);
         w_src[i] = (size_t)(n0 + row) * p.ldw + chunk * 8;
-        w_dst[i] = BMt * BK + (i * 256 + wave * 64) * 8;
+        w_dst[i] = BMt * BK + (i * NTG + wave * 64) * 8;
     }
     const int kt = p.K / BK;
     const int T = kt * p.nseg;
-#define RING_ISSUE(tt_)                                                                                      \
+    const int Tg = T > grp ? (T - grp + KS - 1) / KS : 0;    // K tiles of this group
+    const int nit = (T + KS - 1) / KS;                       // iterations (= tiles of group 0)
+    // jj_ = group-local tile number; the global K tile is jj_*KS + grp
+#define RING_ISSUE(jj_)                                                                                      \
     {                                                                                                        \
-        const int seg_ = (tt_) / kt;                                                                         \
-        const int k0_ = ((tt_) - seg_ * kt) * BK;                                                            \
-        bf16_t* st_ = smem + ((tt_) % NST) * STAGE;                                                          \
+        const int tt_ = (jj_) * KS + grp;                                                                    \
+        const int seg_ = tt_ / kt;                                                                           \
+        const int k0_ = (tt_ - seg_ * kt) * BK;                                                              \
+        bf16_t* st_ = smem + ((jj_) % NST) * STAGE;                                                          \
         const bf16_t* Ap_ = (seg_ == 1) ? p.A[1] : p.A[0];                                                   \
         const bf16_t* Wp_ = (seg_ == 2) ? p.W[1] : p.W[0];                                                   \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) glds16(Ap_ + a_src[i] + k0_, st_ + a_dst[i]);         \
@@ -740,13 +777,13 @@ __global__ __launch_bounds__(256) void f5_gemm_ring_kernel(F5GemmArgs p, int til
 
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
-        if (st < T) RING_ISSUE(st);
+        if (st < Tg) RING_ISSUE(st);
 
     const int frow = lane & 31;
     const int fk = lane >> 5;
-    for (int tt = 0; tt < T; ++tt) {
-        // tile tt must have landed; up to NST-2 younger tiles may stay in flight (conservative vmcnt(0) at the tail)
-        if (tt + NST - 2 < T) {
+    for (int jj = 0; jj < nit; ++jj) {
+        // tile jj must have landed; up to NST-2 younger tiles may stay in flight (conservative vmcnt(0) at the tail)
+        if (jj + NST - 2 < Tg) {
             if (NST == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
             else if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -756,9 +793,10 @@ __global__ __launch_bounds__(256) void f5_gemm_ring_kernel(F5GemmArgs p, int til
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (tt + NST - 1 < T) RING_ISSUE(tt + NST - 1);   // refills the slot consumed in iteration tt-1
+        if (jj + NST - 1 < Tg) RING_ISSUE(jj + NST - 1);   // refills the slot consumed in iteration jj-1
+        if (KS > 1 && jj >= Tg) continue;                  // wave-uniform: no tile left for this group (barrier still met)
 
-        const bf16_t* sA = smem + (tt % NST) * STAGE;
+        const bf16_t* sA = smem + (jj % NST) * STAGE;
         const bf16_t* sB = sA + BMt * BK;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -776,6 +814,43 @@ __global__ __launch_bounds__(256) void f5_gemm_ring_kernel(F5GemmArgs p, int til
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
         }
     }
+#undef RING_ISSUE
+    constexpr int STG = small_tile_staged<EPI, NB>() ? WM * WN * small_tile_stage_elems<NB>() : 0;   // staging area (bf16 elements)
+    if (KS > 1) {
+        // partial sums of groups 1.. -> LDS (behind the epilogue staging area), added by group 0 in group order
+        constexpr int RED = MB * NB * 16 * 64;          // floats per wave
+        static_assert(KS == 1 || STG * 2 + (KS - 1) * WM * WN * RED * 4 <= KS * RING * 2, "reduction area fits in the rings");
+        float* red = reinterpret_cast<float*>(smem_all + STG);
+        __syncthreads();
+        if (grp > 0) {
+            float* dst = red + (size_t)((grp - 1) * (WM * WN) + wave) * RED + lane;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[((mb * NB + nb) * 16 + e) * 64] = acc[mb][nb][e];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g) {
+            const float* src = red + (size_t)((g - 1) * (WM * WN) + wave) * RED + lane;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mb][nb][e] += src[((mb * NB + nb) * 16 + e) * 64];
+        }
+    }
+    if (small_tile_staged<EPI, NB>() && n0 + BNt <= p.N && (p.debug_flags & 2) == 0) {
+        static_assert(STG <= RING, "staging fits");
+        if (KS == 1) __syncthreads();
+        staged_epilogue_bf16<EPI, MB, NB>(p, acc, smem_all + wave * small_tile_stage_elems<NB>(), m0 + wm * (32 * MB),
+                                          n0 + wn * (32 * NB), lane);
+        return;
+    }
     gemm_epilogue<EPI, MB, NB>(p, acc, m0, n0, wm, wn, lane);
 }
 
@@ -787,6 +862,36 @@ static int launch_ring(const F5GemmArgs& a, hipStream_t stream) {
     // ring depth: keep TWO workgroups per CU (<= 80 KB of LDS each): 64x64 tiles take 4 stages (64 KB), 64x128 take 3 (72 KB)
     constexpr int NST = (MB + NB) * 8 * 4 <= 80 ? 4 : 3;
     hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, NB, NST>), dim3(ntiles), dim3(256), 0, stream, a, order, ntiles);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+// 8-wave ring kernel for ONE round of workgroups on a small-M problem (M = 2*937 rows at batch 1): 4 x 2 waves, wave tile
+// 32 x 32*NB, block tile 128 x 64*NB (NB = 3: 128x192 -> 15 x 16 = 240 workgroups for the QKV projection, NB = 2: 128x128 ->
+// 240 for FF1).  One workgroup per CU with 8 waves and 3-4 K tiles in flight moves a third less L2->LDS traffic than the
+// 64x128 tiles (the bound there: tools/b1_decompose.py) without leaving CUs idle.
+// in-workgroup split-K ring kernels (tile overrides 10 / 11): 64x128 tile, 2 x (2x2 waves, wave tile 32x64), 3 stages per group
+// (out-proj / FF2 at batch 1: 240 workgroups, K chain halved); 128x128 tile, 2 x (2x2 waves, wave tile 64x64), 2 stages
+template <int EPI, int MB>
+static int launch_ring_ks2(const F5GemmArgs& a, hipStream_t stream) {
+    constexpr int BMt = 64 * MB, BNt = 128;
+    const int tiles_m = f5_cdiv(a.M, BMt), tiles_n = f5_cdiv(a.N, BNt);
+    const int ntiles = tiles_m * tiles_n;
+    const int order = gemm_mfast(a) ? -tiles_m : tiles_n;
+    constexpr int NST = MB == 1 ? 3 : 2;
+    hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, 2, NST, 2, 2, 2>), dim3(ntiles), dim3(512), 0, stream, a, order, ntiles);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int EPI, int NB>
+static int launch_ring8(const F5GemmArgs& a, hipStream_t stream) {
+    constexpr int BMt = 128, BNt = 64 * NB;
+    const int tiles_m = f5_cdiv(a.M, BMt), tiles_n = a.N / BNt;
+    const int ntiles = tiles_m * tiles_n;
+    const int order = gemm_mfast(a) ? -tiles_m : tiles_n;
+    constexpr int NST = (BMt + BNt) * 64 * 2 * 4 <= 128 * 1024 ? 4 : 3;
+    hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, 1, NB, NST, 4, 2>), dim3(ntiles), dim3(512), 0, stream, a, order, ntiles);
     F5_LAUNCH_CHECK();
     return 0;
 }
@@ -953,7 +1058,8 @@ static int launch_cfg(const F5GemmArgs& a, hipStream_t stream) {
 
 // tile shape: the largest of 128x128 / 64x128 / 64x64 that still gives the 256 CUs >= 1.5 workgroups each
 // (small-batch shapes such as M = 1874 are otherwise a fraction of one wave of tiles)
-int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 v2, 5 = 64x128 ring, 6 = 64x64 ring
+int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 v2, 5 = 64x128 ring, 6 = 64x64 ring,
+                                // 7 = 128x256 v3, 8 = 128x192 8-wave ring, 9 = 128x128 8-wave ring, 10 / 11 = 64x128 / 128x128 split-K ring
 int f5_gemm_debug_flags = 0;
 int f5_gemm_big_kernel = 2;       // auto mode, large shapes: 2 = 256x256 (1 WG/CU), 3 = 128x256 (2 WG/CU, overlapped epilogue)
 int f5_gemm_ring_default = 1;   // auto mode: small tiles use the global_load_lds ring kernel
@@ -971,6 +1077,20 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     if (sel == 4 || (sel == 0 && v2ok && t256 >= 512)) {
         F5_REQUIRE(v2ok, "gemm: the 256x256 kernel needs N %% 256 == 0 and M >= 256");
         return launch_v2<EPI>(a, stream);
+    }
+    if (sel == 10) return launch_ring_ks2<EPI, 1>(a, stream);
+    if (sel == 11) return launch_ring_ks2<EPI, 2>(a, stream);
+    if (sel == 8 || sel == 9) {
+        const int bn = sel == 8 ? 192 : 128;
+        if (a.N % bn == 0) return sel == 8 ? launch_ring8<EPI, 3>(a, stream) : launch_ring8<EPI, 2>(a, stream);
+        sel = 0;
+    }
+    if (sel == 0 && f5_gemm_ring_default) {
+        // one round of 8-wave workgroups (measured at M = 937 / 1874, tools/ring8_bench.py): 128x128 tiles when they fill
+        // 70-100 % of the CUs (FF1 at batch 1: 15.0 vs 17.5 us), else 64x128 tiles with the K tiles split over two wave
+        // groups (out-proj 12.4 vs 13.4 us, FF2 18.2 vs 20-21 us)
+        if (a.N % 128 == 0 && t128 >= 176 && t128 <= 256) return launch_ring8<EPI, 2>(a, stream);
+        if (t64x128 >= 176 && t64x128 <= 256) return launch_ring_ks2<EPI, 1>(a, stream);
     }
     if (sel == 0 || sel == 4 || sel == 7) sel = t128 >= 384 ? 1 : (t64x128 >= 384 ? 2 : 3);
     if (EPI == EPI_QKV_ROPE && sel == 3) sel = 2;

@@ -178,6 +178,8 @@ int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles);
 int f5_debug_set_attn_version(int v);
 /* timing-only ablations of the attention kernel (results are wrong unless 0) */
 int f5_debug_set_attn_ablation(int v);
+/* in-workgroup KV split of the attention kernel: -1 auto (by grid size), 1 none, 2 / 4 wave groups */
+int f5_debug_set_attn_kvsplit(int v);
 
 /* ---- audio (audio.py:115-210; vocoder = vocos_mlx, third party) -------------------------------- */
 /* log-mel spectrogram of one waveform: wave dev [L] fp32 -> out dev [L/256][n_mels] */

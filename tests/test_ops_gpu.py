@@ -438,14 +438,29 @@ def test_attention_other_kernel_versions(lib, ver):
         E.check(lib.f5_debug_set_attn_version(2))
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("ks", [1, 2, 4])
+def test_attention_kv_split(lib, ks):
+    """in-workgroup KV split (small-batch kernel): every split factor gives the one-pass result, including groups that
+    own no tile (N < 64*ks), ragged key lengths and the online-softmax merge across groups"""
+    E.check(lib.f5_debug_set_attn_kvsplit(ks))
+    try:
+        _attention_case(lib, 1, 2, 50, None, 1, seed=1)            # one KV tile: groups 1.. are empty
+        _attention_case(lib, 2, 2, 333, [333, 100], 1, seed=5)
+        _attention_case(lib, 3, 2, 200, [200, 130, 1], 3, seed=7)
+        _attention_case(lib, 1, 2, 937, None, 1, seed=8)
+        _attention_case(lib, 1, 2, 937, None, 3, seed=9)
+    finally:
+        E.check(lib.f5_debug_set_attn_kvsplit(-1))
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("nseg", [1, 3])
 def test_gemm_resid_gate(lib, tile, nseg):
     """x += gate * ((A W^T + b) * keep[row])  (dit.py:172-173, 319, 323) on both GEMM kernels."""
     E.check(lib.f5_debug_set_gemm_tile(tile))
     try:
         r = rng(31 + tile)
-        M, N, K = 700, 512, 256
+        M, N, K = 700, (384 if tile == 8 else 512), 256
         a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
         gate, x0 = randn(r, N), randn(r, M, N)
         keep = torch.from_numpy((r.random(M) > 0.3).astype(np.uint8))
@@ -479,6 +494,32 @@ def test_gemm_all_small_tile_kernels(lib, tile):
             out3, _, _ = _gemm(lib, a, w, bias, 0, 3)
             ref32 = a.double() @ w.double().T + bias.double()
             assert float((out3.double() - ref32).abs().max()) <= 5e-5 * max(1.0, float(ref32.abs().max()))
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))
+
+
+@pytest.mark.parametrize("tile", [8, 9, 10, 11])
+def test_gemm_ring8_kernels(lib, tile):
+    """8-wave ring kernels (128x192 / 128x128 block tiles; 64x128 / 128x128 with the K tiles split over two wave groups
+    and summed through LDS), one workgroup per CU at batch 1: plain, bf16x3, the fused
+    epilogues and the QKV + RoPE + head-split epilogue whose 96-column wave tiles straddle head boundaries"""
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        for (M, N, K) in ((1, 384, 64), (333, 384, 192), (1874, 768, 1024), (130, 1152, 2048)):
+            r = rng(M + N + K + tile)
+            a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+            refbf = (bf16r(a).double() @ bf16r(w).double().T) + bias.double()
+            out, _, _ = _gemm(lib, a, w, bias, 0, 1)
+            mx, _, _ = report(f"gemm tile={tile} {M}x{N}x{K}", out, refbf)
+            assert mx <= 2e-4 * max(1.0, float(refbf.abs().max()))
+            out3, _, _ = _gemm(lib, a, w, bias, 0, 3)
+            ref32 = a.double() @ w.double().T + bias.double()
+            assert float((out3.double() - ref32).abs().max()) <= 5e-5 * max(1.0, float(ref32.abs().max()))
+            _, hi, lo = _gemm(lib, a, w, bias, 2, 3)
+            refg = F.gelu(ref32, approximate="tanh")
+            assert float((join(hi, lo).double() - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))
+        _attention_case(lib, 2, 4, 300, [300, 211], 1, seed=21)     # D = 256, N = 768 = 4 x 192 = 6 x 128
+        _attention_case(lib, 1, 6, 130, None, 3, seed=22)           # D = 384, N = 1152
     finally:
         E.check(lib.f5_debug_set_gemm_tile(0))
 
