@@ -228,7 +228,7 @@ __device__ __forceinline__ int attn_swz(int row, int chunk) { return row * 64 + 
 __device__ __forceinline__ int attn_kperm(int i) { return (i & 32) | ((i & 3) + 4 * ((i >> 3) & 3) + 16 * ((i >> 2) & 1)); }
 
 // ABL = timing-only ablation (results are wrong unless ABL == 0): 1 no exp2, 2 no barrier/vmcnt wait, 3 no PV MFMAs,
-// 4 no S MFMAs, 5 no softmax VALU at all (debug hook f5_debug_set_attn_ablation; CDNA4 guide: ablate before optimising)
+// 4 no S MFMAs, 5 no softmax VALU at all, 6 no K/V loads after the prologue, 7 no LDS fragment reads (debug hook f5_debug_set_attn_ablation; CDNA4 guide: ablate before optimising)
 template <bool HP, int ABL>
 __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p) {
     constexpr int NP = HP ? 2 : 1;
@@ -311,7 +311,9 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
     for (int j = 0; j < ntile; ++j) {
         // wait for tile j (own loads), then make every wave's part visible; tile j+1 may stay in flight (NST == 3)
         if (ABL != 2) {
-            if (NST == 3 && j + 1 < ntile) {
+            if (ABL == 6) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (NST == 3 && j + 1 < ntile) {
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        if (j + NST - 1 < ntile) A2_ISSUE(j + NST - 1);   // slot consumed in iteration j-1: every wave is past it
+        if (ABL != 6 && j + NST - 1 < ntile) A2_ISSUE(j + NST - 1);   // slot consumed in iteration j-1: every wave is past it
 
         const bf16_t* st = smem + (j % NST) * (NP * 2 * TILE);
         const bf16_t* sK = st;
@@ -337,7 +339,9 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = attn_swz(kb * 32 + lq, ks * 2 + hi);
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sK[off]);
+                bf16x8 a;
+                if (ABL == 7) a = qf[0][ks ^ 1];
+                else a = *reinterpret_cast<const bf16x8*>(&sK[off]);
                 if (ABL == 4) {
                     asm volatile("" ::"v"(a));
                     s[kb][ks] += (float)ks;
@@ -414,7 +418,9 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const int voff = attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp);
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sV[voff]);
+                bf16x8 a;
+                if (ABL == 7) a = qf[0][(ks4 + db) & 3];
+                else a = *reinterpret_cast<const bf16x8*>(&sV[voff]);
                 if (ABL == 3) {
                     asm volatile("" ::"v"(a), "v"(pb));
                     o[db][ks4] += 1.0f;
@@ -945,6 +951,8 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
                 case 3: hipLaunchKernelGGL((f5_attn2_kernel<false, 3>), grid, dim3(256), 0, stream, a); break;
                 case 4: hipLaunchKernelGGL((f5_attn2_kernel<false, 4>), grid, dim3(256), 0, stream, a); break;
                 case 5: hipLaunchKernelGGL((f5_attn2_kernel<false, 5>), grid, dim3(256), 0, stream, a); break;
+                case 6: hipLaunchKernelGGL((f5_attn2_kernel<false, 6>), grid, dim3(256), 0, stream, a); break;
+                case 7: hipLaunchKernelGGL((f5_attn2_kernel<false, 7>), grid, dim3(256), 0, stream, a); break;
                 default: hipLaunchKernelGGL((f5_attn2_kernel<false, 0>), grid, dim3(256), 0, stream, a); break;
             }
         }

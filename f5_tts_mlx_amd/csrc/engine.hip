@@ -864,6 +864,13 @@ extern "C" int f5_debug_set_attn_kvsplit(int v) {
     f5_attn_kvsplit = v;
     return 0;
 }
+extern "C" int f5_debug_set_gemm_streamk(int v) {
+    F5_REQUIRE(v >= 0 && v <= 2, "stream-K switch must be 0 (off), 1 (full) or 2 (hybrid)");
+    if (v != 0) RC(f5_gemm_streamk_init());   // scratch on the CURRENT device; call outside of any stream capture
+    f5_gemm_streamk = v;
+    return 0;
+}
+extern "C" int f5_debug_gemm_streamk_error() { return f5_gemm_streamk_error(); }
 extern int f5_gemm_big_kernel;
 extern int f5_gemm_v3_stagger;
 extern "C" int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles) {

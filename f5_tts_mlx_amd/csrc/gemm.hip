@@ -494,21 +494,97 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
+// SK = stream-K scheduling: the grid is one persistent workgroup per CU and workgroup `rid` owns the contiguous range
+// [rid*W/P, (rid+1)*W/P) of the W = ntiles*T K-steps (tile-major).  A range is: the HEAD of a tile that the next range
+// finishes (done FIRST: partial sums -> sk_part[rid], flag), the TAIL of a tile begun by the previous range (waits for
+// that partial, adds it in fixed order head + tail, runs the epilogue), and whole tiles.  Because the first spans differ
+// in length from CU to CU, the epilogues (bursts of HBM writes: x += ... is 8 B per output) of different CUs no longer
+// coincide and run under other CUs' main loops; the last round is also perfectly balanced.  Results are deterministic
+// (fixed summation order); they differ from the data-parallel schedule only in fp32 summation order of split tiles.
+template <int EPI, bool SK>
+__global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles_n, int ntiles, float* sk_part, int* sk_flag,
+                                                         int* sk_err, int sk_hybrid) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * V2_HALF_ELEMS];   // [dbuf][A0,A1,B0,B1][128*64]
 
     const int bid = blockIdx.x;
-    const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * 256, n0 = tn * 256;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    const int kt = p.K / BK;
+    const int T = kt * p.nseg;
+
+    // ---- this workgroup's K-step range -> spans.  Positions index the tiles of this XCD's chunk (the same contiguous
+    // chunk of tile ids the one-tile-per-workgroup launch gives an XCD) in COLUMN-major order of the ragged matrix
+    // [round][CU]: position idx*R + k is tile chunk + k*cpx + idx, so the CUs of an XCD sit on neighbouring tiles at any
+    // time (shared A / W panels stay in the 4 MB L2) exactly like successive rounds of the plain launch.
+    int rid = 0, chunk0 = 0, chunk_sk = 0, cpx = 1, Rr = 0, rem = 0, ndp = 0;
+    long w0, w1;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        chunk0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        if (SK) {
+            cpx = gridDim.x >> 3;                      // CUs (workgroups) per XCD; ntiles >= gridDim.x (host-checked)
+            int nx = q + (xcd < r ? 1 : 0);            // tiles in this XCD's chunk
+            // hybrid: whole rounds run one tile per workgroup in lockstep (CUs of an XCD stream the same K slices of shared
+            // panels through the L2 together); only the last 1..2 rounds' worth of tiles is split stream-K for balance
+            ndp = sk_hybrid ? (nx / cpx - 1) : 0;
+            if (ndp < 0) ndp = 0;
+            nx -= ndp * cpx;
+            chunk_sk = chunk0 + ndp * cpx;
+            Rr = nx / cpx;
+            rem = nx - Rr * cpx;
+            rid = xcd * cpx + idx;
+            const long Wx = (long)nx * T;
+            w0 = (long)idx * Wx / cpx;
+            w1 = (long)(idx + 1) * Wx / cpx;
+        } else {
+            w0 = (long)idx * T;
+            w1 = w0 + T;
+        }
+    }
+    const int first_pos = (int)(w0 / T), t_first = (int)(w0 - (long)first_pos * T);   // tail span [t_first, T) when t_first != 0
+    const int last_pos = (int)(w1 / T), t_last = (int)(w1 - (long)last_pos * T);      // head span [0, t_last) when t_last != 0
+    const int nh = (SK && t_last != 0) ? 1 : 0, nt = (SK && t_first != 0) ? 1 : 0;
+    const int full_begin = first_pos + nt;
+    const int nspan = ndp + nh + nt + (last_pos - full_begin);
+
+    const int frow = lane & 31;
+    const int fk = lane >> 5;
+    for (int sp = 0; sp < nspan; ++sp) {
+    int kind, pos, t0, t1;                            // kind: 0 whole tile, 1 head (publish partial), 2 tail (consume partial)
+    const int ss = sp - ndp;
+    if (ss < 0) {
+        kind = 0; pos = 0; t0 = 0; t1 = T;            // lockstep round sp: tile chunk0 + sp*cpx + idx
+    } else if (ss < nh) {
+        kind = 1; pos = last_pos; t0 = 0; t1 = t_last;
+    } else if (ss < nh + nt) {
+        kind = 2; pos = first_pos; t0 = t_first; t1 = T;
+    } else {
+        kind = 0; pos = full_begin + (ss - nh - nt); t0 = 0; t1 = T;
+    }
+    int tile = chunk0 + pos;
+    if (SK && ss < 0) {
+        tile = chunk0 + sp * cpx + idx;
+    } else if (SK) {                                         // column-major position -> (column c, round k) of the ragged [round][CU] matrix
+        int c, k;
+        if (pos < rem * (Rr + 1)) {
+            c = pos / (Rr + 1);
+            k = pos - c * (Rr + 1);
+        } else {
+            const int p2 = pos - rem * (Rr + 1);
+            c = p2 / Rr;
+            k = p2 - c * Rr;
+            c += rem;
+        }
+        tile = chunk_sk + k * cpx + c;
+    }
+    if (sp > 0) __syncthreads();                      // the previous span's epilogue staging is done with the LDS
+    int ln = lane;                                    // opaque per span: keeps the epilogue / partial-tile address math from
+    if (SK) asm volatile("" : "+v"(ln));              // being hoisted out of the span loop (hundreds of spilled VGPRs)
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
 
     // ---- staging addresses: 2 chunks per thread per half tile -----------------------------------
     // linear chunk q_ = j*512 + tid of the [128][8] half-tile image; row = q_>>3, slot = q_&7,
@@ -530,9 +606,6 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             srcB[h][j] = (size_t)(n0 + h * 128 + row) * p.ldw + chunk * 8;
         }
     }
-
-    const int kt = p.K / BK;
-    const int T = kt * p.nseg;
 
     // issue one half tile (A half h / B half h) of K-tile `tt` into its slot (slots: A0,A1,B0,B1 per K-tile parity)
 #define V2_ISSUE_A(tt_, h_)                                                                         \
@@ -569,23 +642,21 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     // ---- prologue: tile 0 (4 halves) + B halves of tile 1 -----------------------------------------
-    V2_ISSUE_A(0, 0);
-    V2_ISSUE_A(0, 1);
-    V2_ISSUE_B(0, 0);
-    V2_ISSUE_B(0, 1);
-    if (T > 1) {
-        V2_ISSUE_B(1, 0);
-        V2_ISSUE_B(1, 1);
+    V2_ISSUE_A(t0, 0);
+    V2_ISSUE_A(t0, 1);
+    V2_ISSUE_B(t0, 0);
+    V2_ISSUE_B(t0, 1);
+    if (t0 + 1 < t1) {
+        V2_ISSUE_B(t0 + 1, 0);
+        V2_ISSUE_B(t0 + 1, 1);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     V2_BARRIER();
 
-    const int frow = lane & 31;
-    const int fk = lane >> 5;
     // fragment read offsets inside a half tile (elements): row r, chunk c -> r*64 + ((c ^ ((r>>1)&7))<<3)
-    for (int tt = 0; tt < T; ++tt) {
+    for (int tt = t0; tt < t1; ++tt) {
         const bf16_t* base = smem + (tt & 1) * 4 * V2_HALF_ELEMS;
         const bf16_t* sA = base + wm * V2_HALF_ELEMS;                  // this wave's A half (128 rows)
         const bf16_t* sB = base + (2 + (wn >> 1)) * V2_HALF_ELEMS;     // this wave's B half
@@ -599,7 +670,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             for (int mb = 0; mb < 2; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(mb * 32 + frow, ks * 2 + fk)]);
             bfr[0][ks] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(brow0 + frow, ks * 2 + fk)]);
         }
-        if (tt + 1 < T) V2_ISSUE_A(tt + 1, 0);
+        if (tt + 1 < t1) V2_ISSUE_A(tt + 1, 0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -611,7 +682,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         // ---- phase 2: B(nq=1); quadrant (0,1); issue A1(t+1)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bfr[1][ks] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(brow0 + 32 + frow, ks * 2 + fk)]);
-        if (tt + 1 < T) V2_ISSUE_A(tt + 1, 1);
+        if (tt + 1 < t1) V2_ISSUE_A(tt + 1, 1);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -626,7 +697,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(64 + mb * 32 + frow, ks * 2 + fk)]);
-        if (tt + 2 < T) V2_ISSUE_B(tt + 2, 0);
+        if (tt + 2 < t1) V2_ISSUE_B(tt + 2, 0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -637,7 +708,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         V2_BARRIER();   // every wave has finished reading the A halves of this tile
 
         // ---- phase 4: quadrant (1,0) from registers; issue B1(t+2)
-        if (tt + 2 < T) V2_ISSUE_B(tt + 2, 1);
+        if (tt + 2 < t1) V2_ISSUE_B(tt + 2, 1);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -646,7 +717,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
                 acc[2 + mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[0][ks], acc[2 + mb][0], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         // next tile's operands: everything but the two B halves just issued for tile t+2 must have landed
-        if (tt + 2 < T) {
+        if (tt + 2 < t1) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -654,27 +725,108 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         V2_BARRIER();
     }
 
+    // Partial tiles cross XCDs, whose L2s are not coherent.  No agent-scope fences here: a release fence writes back and an
+    // acquire fence invalidates the WHOLE L2 of the XCD (measured: the operand panels of all 32 CUs get refetched and the
+    // kernel runs 1.65x slower).  Instead the payload and the flag use relaxed agent-scope atomics, i.e. plain sc1
+    // (write-through / L2-bypassing) stores and loads, ordered by s_waitcnt vmcnt(0) + the workgroup barrier.
+    if (SK && kind == 1) {
+        float* dst = sk_part + (size_t)rid * 65536 + (size_t)wave * 8192 + ln;   // [wave][acc block][reg][lane] fp32
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __hip_atomic_store(dst + ((i * 2 + j) * 16 + e) * 64, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&sk_flag[rid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+    }
+    if (SK && kind == 2) {
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&sk_flag[rid - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 20)) {             // never hang the GPU: flag the error, results will be wrong
+                    atomicExch(sk_err, 1);
+                    break;
+                }
+            }
+            __hip_atomic_store(&sk_flag[rid - 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        }
+        __syncthreads();
+        const float* src = sk_part + (size_t)(rid - 1) * 65536 + (size_t)wave * 8192 + ln;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float part[16];                        // 16 loads in flight at a time (all 128 at once would spill)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    part[e] = __hip_atomic_load(src + ((i * 2 + j) * 16 + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = part[e] + acc[i][j][e];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
     if (p.debug_flags & 1) {   // timing experiment: main loop only
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
+        continue;
     }
     if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
-        staged_epilogue_bf16<EPI, 4, 2>(p, acc, smem + wave * 8192, m0 + wm * 128, n0 + wn * 64, lane);
+        staged_epilogue_bf16<EPI, 4, 2>(p, acc, smem + wave * 8192, m0 + wm * 128, n0 + wn * 64, ln);
     } else if (EPI == EPI_RESID_GATE) {
-        staged_epilogue_resid<4, 2>(p, acc, reinterpret_cast<float*>(smem + wave * 8192), m0 + wm * 128, n0 + wn * 64, lane);
+        staged_epilogue_resid<4, 2>(p, acc, reinterpret_cast<float*>(smem + wave * 8192), m0 + wm * 128, n0 + wn * 64, ln);
     } else {
-        gemm_epilogue<EPI, 4, 2>(p, acc, m0, n0, wm, wn, lane);
+        gemm_epilogue<EPI, 4, 2>(p, acc, m0, n0, wm, wn, ln);
     }
+    }   // spans
 }
-
+// stream-K scratch (process-wide, one device): partial tiles [P][256*256] fp32, flags, error word.  Allocated outside of
+// any stream capture by f5_gemm_streamk_init(), which the debug hook calls when the schedule is switched on.
+static float* g_sk_part = nullptr;
+static int* g_sk_flag = nullptr;
+static int g_sk_P = 0;
+int f5_gemm_streamk = 0;          // large shapes: 0 = one tile per workgroup, 1 = stream-K over all K-steps, 2 = hybrid (lockstep
+                                  // rounds + stream-K tail)
+int f5_gemm_streamk_init() {
+    if (g_sk_part) return 0;
+    int dev = 0, cus = 0;
+    F5_HIP_CHECK(hipGetDevice(&dev));
+    F5_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus -= cus % 8;
+    F5_REQUIRE(cus >= 8, "stream-K: unexpected CU count %d", cus);
+    float* part = nullptr;
+    int* flag = nullptr;
+    F5_HIP_CHECK(hipMalloc(&part, (size_t)cus * 65536 * sizeof(float)));
+    F5_HIP_CHECK(hipMalloc(&flag, (size_t)(cus + 64) * sizeof(int)));
+    F5_HIP_CHECK(hipMemset(flag, 0, (size_t)(cus + 64) * sizeof(int)));
+    g_sk_part = part;
+    g_sk_flag = flag;
+    g_sk_P = cus;
+    return 0;
+}
+int f5_gemm_streamk_error() {      // 1 if a consumer ever timed out waiting for a partial tile (results invalid)
+    if (!g_sk_flag) return 0;
+    int v = 0;
+    if (hipMemcpy(&v, g_sk_flag + g_sk_P, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
 template <int EPI>
 static int launch_v2(const F5GemmArgs& a, hipStream_t stream) {
     const int tiles_m = f5_cdiv(a.M, 256), tiles_n = a.N / 256;
     const int ntiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((f5_gemm256_kernel<EPI>), dim3(ntiles), dim3(512), 0, stream, a, tiles_n, ntiles);
+    if (f5_gemm_streamk && g_sk_part && ntiles >= g_sk_P) {
+        hipLaunchKernelGGL((f5_gemm256_kernel<EPI, true>), dim3(g_sk_P), dim3(512), 0, stream, a, tiles_n, ntiles, g_sk_part,
+                           g_sk_flag, g_sk_flag + g_sk_P, f5_gemm_streamk == 2 ? 1 : 0);
+    } else {
+        hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false>), dim3(ntiles), dim3(512), 0, stream, a, tiles_n, ntiles,
+                           (float*)nullptr, (int*)nullptr, (int*)nullptr, 0);
+    }
     F5_LAUNCH_CHECK();
     return 0;
 }

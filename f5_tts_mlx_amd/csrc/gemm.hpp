@@ -40,3 +40,9 @@ struct F5GemmArgs {
 };
 
 int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
+
+// stream-K schedule of the 256x256 kernel (large shapes): device scratch for partial tiles; must be initialised outside of a
+// stream capture (engine creation does it).  f5_gemm_streamk_error() != 0 means a consumer timed out (results invalid).
+int f5_gemm_streamk_init();
+int f5_gemm_streamk_error();
+extern int f5_gemm_streamk;

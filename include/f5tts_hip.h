@@ -166,7 +166,8 @@ int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scra
 
 /* debug / benchmarking hook: force the GEMM block tile (0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 global_load_lds kernel) */
 int f5_debug_set_gemm_tile(int sel);
-/* bit 0: skip GEMM epilogues (timing experiments only; results are garbage) */
+/* bit 0: skip GEMM epilogues of the 256x256 / 128x256 kernels (timing experiments only; results are garbage);
+ * bit 1: small-tile kernels use the direct (2-byte store) epilogue instead of the LDS-staged one */
 int f5_debug_set_gemm_flags(int v);
 /* small-tile GEMM tile numbering: 0 auto, 1 n fastest, 2 m fastest */
 int f5_debug_set_gemm_order(int v);
@@ -174,6 +175,11 @@ int f5_debug_set_gemm_order(int v);
 int f5_debug_set_gemm_ring(int v);
 /* large-shape GEMM kernel in auto mode: 2 = 256x256 (one workgroup per CU), 3 = 128x256 (two per CU); stagger < 0 = auto */
 int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles);
+/* large-shape GEMM schedule: 0 = one tile per workgroup (default), 1 = stream-K (persistent workgroup per CU over contiguous
+ * K-step ranges), 2 = hybrid (lockstep rounds + stream-K tail);
+ * f5_debug_gemm_streamk_error() returns 1 if a partial-tile hand-off ever timed out (results invalid) */
+int f5_debug_set_gemm_streamk(int v);
+int f5_debug_gemm_streamk_error(void);
 /* 1 = register-staged attention kernel, 2 = global_load_lds ring (default) */
 int f5_debug_set_attn_version(int v);
 /* timing-only ablations of the attention kernel (results are wrong unless 0) */

@@ -524,6 +524,55 @@ def test_gemm_ring8_kernels(lib, tile):
         E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+def test_gemm_streamk_schedule(lib):
+    """256x256 kernel under the stream-K schedule (>= one tile per CU): split tiles are handed over through the partial-tile
+    scratch; every epilogue; bitwise run-to-run determinism; agreement with the one-tile-per-workgroup schedule."""
+    r = rng(4242)
+    M, N, K = 4200, 4096, 192                      # 17 x 16 = 272 tiles of 3 K-steps over 256 CUs -> most tiles are split
+    a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+    refbf = (bf16r(a).double() @ bf16r(w).double().T) + bias.double()
+    ref32 = a.double() @ w.double().T + bias.double()
+    outs = {}
+    for sk in (1, 2, 0, 1, 2):
+        E.check(lib.f5_debug_set_gemm_streamk(sk))
+        try:
+            out, _, _ = _gemm(lib, a, w, bias, 0, 1)
+            mx, _, _ = report(f"gemm stream-K={sk} {M}x{N}x{K}", out, refbf)
+            assert mx <= 2e-4 * max(1.0, float(refbf.abs().max()))
+            if sk in outs:
+                assert torch.equal(out, outs[sk]), "stream-K schedule must be bitwise reproducible"
+            outs[sk] = out
+            out3, _, _ = _gemm(lib, a, w, bias, 0, 3)
+            assert float((out3.double() - ref32).abs().max()) <= 5e-5 * max(1.0, float(ref32.abs().max()))
+            _, hi, lo = _gemm(lib, a, w, bias, 2, 3)
+            refg = F.gelu(ref32, approximate="tanh")
+            assert float((join(hi, lo).double() - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))
+        finally:
+            E.check(lib.f5_debug_set_gemm_streamk(0))
+    assert float((outs[0] - outs[2]).abs().max()) <= 1e-5 * max(1.0, float(refbf.abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * max(1.0, float(refbf.abs().max()))
+    # fused residual epilogue + QKV epilogue under the hybrid schedule
+    E.check(lib.f5_debug_set_gemm_streamk(2))
+    gate, x0 = randn(r, N), randn(r, M, N)
+    keep = torch.from_numpy((r.random(M) > 0.3).astype(np.uint8))
+    a_hi, a_lo = split_bf16(a.to(DEV))
+    w_hi, w_lo = split_bf16(w.to(DEV))
+    bias_d, gate_d, keep_d, x = bias.to(DEV), gate.to(DEV), keep.to(DEV), x0.to(DEV).clone()
+    E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(a_lo), P(w_hi), P(w_lo), P(bias_d), P(gate_d), P(keep_d), P(x), M, N, K, K, K, N, 3,
+                                      stream()), "gemm_resid_gate")
+    sync()
+    ref = x0.double() + gate.double() * (ref32 * keep.double()[:, None])
+    assert float((x.cpu().double() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max()))
+    # QKV + RoPE + head split + attention on top: D = 1280 (N = 3840 = 15 tiles), M = 5 x 900 -> 18 x 15 = 270 tiles
+    try:
+        _attention_case(lib, 5, 20, 900, [900, 850, 900, 411, 77], 1, seed=33)
+        E.check(lib.f5_debug_set_gemm_streamk(1))
+        _attention_case(lib, 5, 20, 900, [900, 850, 900, 411, 77], 1, seed=34)
+    finally:
+        E.check(lib.f5_debug_set_gemm_streamk(0))
+    assert lib.f5_debug_gemm_streamk_error() == 0
+
+
 @pytest.fixture
 def force_v3(lib):
     E.check(lib.f5_debug_set_gemm_tile(7))

@@ -16,6 +16,6 @@ f=glob.glob('$OUT/prof/*kernel_stats.csv')[0]
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 print('total ms', tot/1e6)
-for r in rows[:14]:
+for r in rows[:26]:
     print(f"{r['Name'][:60]:60s} calls={r['Calls']:>6s} {100*float(r['TotalDurationNs'])/tot:5.1f}% avg_us={float(r['AverageNs'])/1e3:9.1f}")
 PY
