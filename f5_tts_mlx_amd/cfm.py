@@ -22,7 +22,7 @@ from .dit import DiT
 from .rng import mlx_like_normal
 from .utils import (default, exists, fetch_from_hub, lens_to_mask, list_str_to_idx, list_str_to_tensor,
                     mask_from_frac_lengths)
-from .weights import F5TTS_335M, convert_upstream_weights
+from .weights import F5TTS_335M, convert_upstream_weights, dequantize_mlx_checkpoint
 
 # ode solvers -- generic host versions with the reference's semantics (cfm.py:38-122); the engine has
 # the same three schemes fused with the CFG combine (csrc/rowops.hip: ode_stage_kernel)
@@ -268,12 +268,14 @@ class F5TTS:
 
     @classmethod
     def from_pretrained(cls, hf_model_name_or_path: str, convert_weights=None, quantization_bits: int | None = None,
-                        precision: str = "bf16", device: str = "cuda:0") -> "F5TTS":
-        """cfm.py:404-520.  Loads `model_v1.safetensors` + `vocab.txt` from a local directory or the HF hub
-        (network required).  MLX int4/int8 checkpoints (`quantization_bits`) are MLX-specific and not
-        loadable here."""
-        if exists(quantization_bits):
-            raise NotImplementedError("MLX group-quantized checkpoints (model_v1_{4,8}b) are not supported")
+                        precision: str = "bf16", device: str = "cuda:0",
+                        vocoder_name_or_path: str | None = "lucasnewman/vocos-mel-24khz") -> "F5TTS":
+        """cfm.py:404-520.  Loads `model_v1.safetensors` (or `model_v1_{4,8}b.safetensors`) + `vocab.txt` (+ the duration
+        predictor `duration_v2.safetensors` when present) from a local directory or the HF hub (network required), and the
+        Vocos vocoder (cfm.py:446) from `vocoder_name_or_path`, `$F5_VOCOS_PATH`, or the hub.  MLX int4/int8 checkpoints are
+        expanded to fp32 on load (weights.dequantize_mlx_checkpoint) and run on the bf16 path.  If the vocoder cannot be
+        found the model is returned WITHOUT one (sample() then returns mel frames) and a warning is printed; the
+        reference would raise from `Vocos.from_pretrained`."""
         path = fetch_from_hub(hf_model_name_or_path, quantization_bits=quantization_bits)
         if path is None:
             raise ValueError(f"Could not find model {hf_model_name_or_path}")
@@ -294,16 +296,40 @@ class F5TTS:
                 vocab_char_map=vocab)
             duration_predictor.load_weights(load_file(str(duration_model_path)))
 
-        convert_weights = default(convert_weights, True)
-        model_path = Path(path) / "model_v1.safetensors"
-        weights = load_file(str(model_path))
+        # vocoder (cfm.py:446, 471)
+        vocoder = None
+        import os
+        from .vocos import Vocos
+        for cand in (vocoder_name_or_path, os.environ.get("F5_VOCOS_PATH")):
+            if cand and Path(cand).exists():
+                vocoder = Vocos.from_pretrained(cand, precision=precision, device=device).decode
+                break
+        if vocoder is None and vocoder_name_or_path:
+            try:
+                from huggingface_hub import snapshot_download
+                vdir = snapshot_download(repo_id=vocoder_name_or_path, allow_patterns=["*.safetensors", "*.yaml", "*.json"])
+                vocoder = Vocos.from_pretrained(vdir, precision=precision, device=device).decode
+            except Exception as exc:                                       # offline: keep going without a vocoder
+                print(f"[f5_tts_mlx_amd] vocoder {vocoder_name_or_path!r} unavailable ({type(exc).__name__}); "
+                      f"sample() will return mel frames.  Set F5_VOCOS_PATH to a local vocos-mel-24khz directory.")
+
+        model_filename = "model_v1.safetensors"                            # cfm.py:448-453
+        if exists(quantization_bits):
+            model_filename = f"model_v1_{quantization_bits}b.safetensors"
+            convert_weights = False
+        else:
+            convert_weights = default(convert_weights, True)
+        weights = load_file(str(Path(path) / model_filename))
         if convert_weights:
             weights = convert_upstream_weights(weights)
+        if exists(quantization_bits):
+            weights = dequantize_mlx_checkpoint(weights, quantization_bits)
         weights = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
         f5tts = cls(
             transformer=DiT(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4,
                             text_num_embeds=len(vocab) - 1, text_mask_padding=True, precision=precision, device=device),
             vocab_char_map=vocab,
+            vocoder=vocoder,
             duration_predictor=duration_predictor,
         )
         f5tts.load_weights(weights)

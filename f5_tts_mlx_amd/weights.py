@@ -175,6 +175,62 @@ def convert_upstream_weights(weights: Dict[str, np.ndarray]) -> Dict[str, np.nda
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# MLX group-quantized checkpoints (`model_v1_{4,8}b.safetensors`, cfm.py:450-452, 510-515)
+# ----------------------------------------------------------------------------------------------
+# `nn.quantize(bits, group_size=64)` replaces every Linear whose input width is a multiple of 64 by (weight: uint32
+# words, scales, biases).  MLX's affine scheme (mlx docs, `mx.quantize`; third-party, NOT verifiable in this container):
+# per group of 64 consecutive input elements  w ~= scale * q + bias  with q in [0, 2^bits), bias = group minimum and
+# scale = (max - min) / (2^bits - 1); the q of 32/bits consecutive elements are packed into one uint32, the first
+# element in the LEAST significant bits.  The engine has no int4/int8 GEMM: such checkpoints are expanded to fp32 here
+# and then run through the same bf16 / bf16x3 path as a full-precision checkpoint.
+
+def quantize_mlx_affine(w: np.ndarray, bits: int, group_size: int = 64):
+    """Restatement of MLX's affine group quantisation (used by the tests and by tools that write such checkpoints)."""
+    assert bits in (2, 4, 8) and w.ndim == 2 and w.shape[1] % group_size == 0
+    out_f, in_f = w.shape
+    g = np.asarray(w, np.float32).reshape(out_f, in_f // group_size, group_size)
+    lo, hi = g.min(axis=-1, keepdims=True), g.max(axis=-1, keepdims=True)
+    levels = float((1 << bits) - 1)
+    scale = np.maximum((hi - lo) / levels, 1e-7).astype(np.float32)
+    q = np.clip(np.rint((g - lo) / scale), 0, levels).astype(np.uint32).reshape(out_f, in_f)
+    per = 32 // bits
+    packed = np.zeros((out_f, in_f // per), np.uint32)
+    for i in range(per):
+        packed |= q[:, i::per] << np.uint32(bits * i)
+    return packed, scale[..., 0], lo[..., 0].astype(np.float32)
+
+
+def dequantize_mlx_affine(packed: np.ndarray, scales: np.ndarray, biases: np.ndarray, bits: int, group_size: int = 64) -> np.ndarray:
+    packed = np.asarray(packed).astype(np.uint32)
+    per = 32 // bits
+    out_f, words = packed.shape
+    in_f = words * per
+    q = np.empty((out_f, in_f), np.float32)
+    mask = np.uint32((1 << bits) - 1)
+    for i in range(per):
+        q[:, i::per] = ((packed >> np.uint32(bits * i)) & mask).astype(np.float32)
+    s = np.repeat(np.asarray(scales, np.float32), group_size, axis=1)
+    b = np.repeat(np.asarray(biases, np.float32), group_size, axis=1)
+    if s.shape != q.shape:
+        raise ValueError(f"quantised tensor {packed.shape} does not match scales {np.shape(scales)} at {bits} bits")
+    return q * s + b
+
+
+def dequantize_mlx_checkpoint(weights: Dict[str, np.ndarray], bits: int, group_size: int = 64) -> Dict[str, np.ndarray]:
+    """Expand every (X.weight uint32, X.scales, X.biases) triple to a dense fp32 X.weight; other tensors pass through."""
+    out: Dict[str, np.ndarray] = {}
+    for k, v in weights.items():
+        if k.endswith(".scales") or k.endswith(".biases"):
+            continue
+        base = k[: -len(".weight")] if k.endswith(".weight") else None
+        if base is not None and base + ".scales" in weights:
+            out[k] = dequantize_mlx_affine(v, weights[base + ".scales"], weights[base + ".biases"], bits, group_size)
+        else:
+            out[k] = v
+    return out
+
+
 def check_weights(cfg: DiTConfig, weights: Dict[str, np.ndarray], ignore: Iterable[str] = ("transformer.rotary_embed.inv_freq",)) -> None:
     """Raise ValueError when `weights` does not match the parameter inventory of `cfg`."""
     want = {n: s for n, s, _ in param_specs(cfg)}

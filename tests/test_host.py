@@ -208,3 +208,24 @@ def test_generate_helpers(tmp_path):
     b, sr2 = G.read_wav(str(p))
     assert sr2 == 24000 and np.allclose(b, np.linspace(-0.5, 0.5, 1000), atol=1e-6)
     assert G.DEFAULT_REF_TEXT == "Some call me nature, others call me mother nature."
+
+
+def test_mlx_affine_quantisation_roundtrip():
+    """weights.{quantize,dequantize}_mlx_affine / dequantize_mlx_checkpoint: packing order, group layout, error bound."""
+    from f5_tts_mlx_amd.weights import dequantize_mlx_affine, dequantize_mlx_checkpoint, quantize_mlx_affine
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((24, 192)).astype(np.float32)
+    for bits in (4, 8):
+        pk, sc, bi = quantize_mlx_affine(w, bits)
+        assert pk.dtype == np.uint32 and pk.shape == (24, 192 * bits // 32) and sc.shape == (24, 3) == bi.shape
+        d = dequantize_mlx_affine(pk, sc, bi, bits)
+        step = (w.reshape(24, 3, 64).max(-1) - w.reshape(24, 3, 64).min(-1)) / (2 ** bits - 1)
+        assert np.all(np.abs(d - w).reshape(24, 3, 64).max(-1) <= 0.5 * step * (1 + 1e-5) + 1e-7)
+        # first element of a word sits in the least significant bits
+        q0 = np.rint((w[0, 0] - bi[0, 0]) / sc[0, 0])
+        assert (int(pk[0, 0]) & ((1 << bits) - 1)) == int(q0)
+    ck = {"a.weight": pk, "a.scales": sc, "a.biases": bi, "a.bias": np.ones(24, np.float32), "n.weight": np.ones(5, np.float32)}
+    out = dequantize_mlx_checkpoint(ck, 8)
+    assert set(out) == {"a.weight", "a.bias", "n.weight"} and out["a.weight"].shape == (24, 192)
+    with pytest.raises(ValueError):
+        dequantize_mlx_affine(pk, sc[:, :2], bi[:, :2], 8)

@@ -385,3 +385,68 @@ def test_cfm_loss_forward_parity(tiny_weights, tiny_x3, drops):
     a = float(tts(mel, text, lens=lens, generator=torch.Generator().manual_seed(5)))
     b = float(tts(mel, text, lens=lens, generator=torch.Generator().manual_seed(5)))
     assert np.isfinite(a) and a == b
+
+
+def test_from_pretrained_local_checkpoints(tmp_path):
+    """F5TTS.from_pretrained (cfm.py:404-520) on a local directory holding a synthetic 335M checkpoint: the full-precision
+    file, an MLX-style 8-bit group-quantised file (expanded on load), vocab, duration predictor and a local Vocos.  The
+    loaded models must reproduce a directly constructed model bit for bit."""
+    from safetensors.numpy import save_file
+    from f5_tts_mlx_amd.duration import synthetic_duration_weights
+    from f5_tts_mlx_amd.vocos import synthetic_vocos_weights
+    from f5_tts_mlx_amd.weights import dequantize_mlx_checkpoint, quantize_mlx_affine
+    vocab_text = open(str(E.library_path().parent.parent / "assets" / "vocab.txt")).read()
+    vocab = {v: i for i, v in enumerate(vocab_text.split("\n"))}
+    import dataclasses
+    cfg = dataclasses.replace(F5TTS_335M, text_num_embeds=len(vocab) - 1)
+    w = {k: v.astype(np.float16) for k, v in synthetic_weights(cfg, seed=5).items()}      # fp16 on disk, like a release
+    mdir, vdir = tmp_path / "model", tmp_path / "vocos"
+    mdir.mkdir(); vdir.mkdir()
+    (mdir / "vocab.txt").write_text(vocab_text)
+    save_file(w, str(mdir / "model_v1.safetensors"))
+    q = {}
+    for k, v in w.items():                               # nn.quantize: every Linear whose input width is a multiple of 64
+        if k.endswith(".weight") and v.ndim == 2 and v.shape[1] % 64 == 0 and "text_embed.text_embed" not in k:
+            pk, sc, bi = quantize_mlx_affine(v.astype(np.float32), 8)
+            q[k], q[k[:-7] + ".scales"], q[k[:-7] + ".biases"] = pk, sc.astype(np.float16), bi.astype(np.float16)
+        else:
+            q[k] = v
+    assert "transformer.input_embed.proj.scales" not in q and "transformer.transformer_blocks.0.attn.to_q.scales" in q
+    save_file(q, str(mdir / "model_v1_8b.safetensors"))
+    save_file(synthetic_duration_weights(seed=11, text_num_embeds=len(vocab) - 1), str(mdir / "duration_v2.safetensors"))
+    save_file(synthetic_vocos_weights(seed=7), str(vdir / "model.safetensors"))
+
+    g = torch.Generator().manual_seed(3)
+    wave = (torch.randn((1, 24000), generator=g) * 0.1)
+    text = ["hello there"]
+
+    def run(model):
+        out, _ = model.sample(wave, text=text, duration=150, steps=2, method="euler", seed=1)
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    f5 = F5TTS.from_pretrained(str(mdir), convert_weights=False, vocoder_name_or_path=str(vdir), device=str(DEV))
+    assert f5._duration_predictor is not None and f5._vocoder is not None
+    got = run(f5)
+    assert got.ndim == 1 and got.shape[0] == 256 * 149 and torch.isfinite(got).all()
+    direct = DiT.from_config(cfg, precision="bf16", device=DEV)
+    direct.load_weights({k: v.astype(np.float32) for k, v in w.items()})
+    ref = run(F5TTS(transformer=direct, vocab_char_map=vocab, vocoder=f5._vocoder))
+    assert torch.equal(got, ref)
+    assert int(f5.sample(wave, text=text, duration=None, steps=2, method="euler", seed=1)[0].shape[0]) > 0     # duration predictor path
+    del f5, direct
+    torch.cuda.empty_cache()
+
+    f8 = F5TTS.from_pretrained(str(mdir), quantization_bits=8, vocoder_name_or_path=str(vdir), device=str(DEV))
+    got8 = run(f8)
+    deq = DiT.from_config(cfg, precision="bf16", device=DEV)
+    deq.load_weights({k: np.asarray(v, np.float32) for k, v in dequantize_mlx_checkpoint(q, 8).items()})
+    ref8 = run(F5TTS(transformer=deq, vocab_char_map=vocab, vocoder=f8._vocoder))
+    assert torch.equal(got8, ref8)
+    rel = float((got8 - got).abs().mean() / got.abs().mean())
+    print(f"8-bit checkpoint vs full precision: relative wave L1 {rel:.3e}")
+    assert rel < 0.5
+    # no vocoder anywhere -> model still loads, sample returns mel frames (documented difference)
+    fm = F5TTS.from_pretrained(str(mdir), convert_weights=False, vocoder_name_or_path=None, device=str(DEV))
+    mel, _ = fm.sample(wave, text=text, duration=150, steps=2, method="euler", seed=1)
+    assert tuple(mel.shape) == (1, 150, 100)
