@@ -457,6 +457,205 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 }
 
 // =================================================================================================
+// v2w (bf16, large grids): v2 with TWO 32-query blocks per wave (workgroup = 256 queries).  Every K / V^T fragment read
+// from LDS and every staged tile now feeds twice the MFMAs: the v2 ablations (tools/attn_abl_b1.py) show the tile staging
+// (-19 %), the LDS fragment reads (-15 %) and the barrier (-4 %) as additive costs next to the MFMAs and the softmax, and
+// those three halve per flop here.  Price: ~230 VGPRs => 2 workgroups per CU instead of 3.  Measured 597 -> 649 TF at
+// B = 32 (tools/attn_wide_bench.py).  The running-max rescale is branch-free here (+3 %).  A variant that software-pipelines the
+// two query blocks against each other with sched_group_barrier (S(q1) under softmax(q0), PV(q0) under softmax(q1)) measured
+// 515 TF (spills at 256 VGPRs, re-read fragments) and was dropped, like the in-wave pipelining of v3 / v4.
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
+    constexpr int NST = 3;
+    constexpr int TILE = 64 * 64;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NST * 2 * TILE];   // [stage][K | V^T][64*64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lq = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
+    const int ntile = (kvlen + 63) >> 6;
+    const size_t rowbase = (size_t)b * p.seq_len;
+
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = q0 + qb * 32 + lq;
+        if (qr > p.seq_len - 1) qr = p.seq_len - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[qb][ks] = *reinterpret_cast<const bf16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+    }
+
+    const bf16_t* kptr[2];
+    const bf16_t* vptr[2];
+    int krow[2], kcol[2], ldsoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q_ = i * 256 + tid;
+        const int srow = q_ >> 3;
+        const int schunk = (q_ & 7) ^ ((srow >> 1) & 7);
+        krow[i] = attn_kperm(srow);
+        kcol[i] = p.dmodel + h * 64 + schunk * 8;
+        ldsoff[i] = (i * 256 + wave * 64) * 8;
+        kptr[i] = p.qk[0] + (rowbase + krow[i]) * p.ldqk + kcol[i];
+        vptr[i] = p.vt[0] + ((size_t)bh * 64 + srow) * p.npad + schunk * 8;
+    }
+    const size_t kstep = (size_t)64 * p.ldqk;
+#define A2W_ISSUE(j_)                                                                                        \
+    {                                                                                                        \
+        bf16_t* st_ = smem + ((j_) % NST) * (2 * TILE);                                                      \
+        const bool tail_ = ((j_) * 64 + 63) > p.seq_len - 1;                                                 \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            const bf16_t* ks_ = kptr[i];                                                                     \
+            if (tail_) {                                                                                     \
+                int key_ = (j_) * 64 + krow[i];                                                              \
+                if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                              \
+                ks_ = p.qk[0] + (rowbase + key_) * p.ldqk + kcol[i];                                         \
+            }                                                                                                \
+            attn_glds16(ks_, st_ + ldsoff[i]);                                                               \
+            attn_glds16(vptr[i], st_ + TILE + ldsoff[i]);                                                    \
+            kptr[i] += kstep;                                                                                \
+            vptr[i] += 64;                                                                                   \
+        }                                                                                                    \
+    }
+
+    f32x16 o[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            o[qb][0][e] = 0.0f;
+            o[qb][1][e] = 0.0f;
+        }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    A2W_ISSUE(0);
+    if (ntile > 1) A2W_ISSUE(1);
+
+    for (int j = 0; j < ntile; ++j) {
+        if (j + 1 < ntile) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + NST - 1 < ntile) A2W_ISSUE(j + NST - 1);
+
+        const bf16_t* sK = smem + (j % NST) * (2 * TILE);
+        const bf16_t* sV = sK + TILE;
+
+        f32x16 s[2][2];                                   // [query block][key block]
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[qb][kb][e] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sK[attn_swz(kb * 32 + lq, ks * 2 + hi)]);
+                s[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[0][kb], 0, 0, 0);
+                s[1][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[1][ks], s[1][kb], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+
+        const int key0 = j * 64;
+        if (key0 + 64 > kvlen) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + kb * 32 + 16 * hi + r;
+                        if (key >= kvlen) s[qb][kb][r] = -INFINITY;
+                    }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[qb][kb][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            {
+                const float m_new = fmaxf(m_run[qb], tmax);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c2);
+                m_run[qb] = m_new;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    o[qb][0][e] *= alpha;
+                    o[qb][1][e] *= alpha;
+                }
+            }
+            const float mc = m_run[qb] * c2;
+            float psum = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r] * c2 - mc);
+                    s[qb][kb][r] = pv;
+                    psum += pv;
+                }
+            l_run[qb] += psum;
+        }
+
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ++ks4) {
+            const int kb = ks4 >> 1, sp = ks4 & 1;
+            bf16x8 pb[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                uint32_t pw[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pw[e] = f5_pack2(s[qb][kb][8 * sp + 2 * e], s[qb][kb][8 * sp + 2 * e + 1]);
+                pb[qb] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sV[attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp)]);
+                o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[0], o[0][db], 0, 0, 0);
+                o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[1], o[1][db], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+#undef A2W_ISSUE
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qr = q0 + qb * 32 + lq;
+        if (qr < p.seq_len) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d = db * 32 + 8 * rg + 4 * hi;
+                    const float v0 = o[qb][db][rg * 4 + 0] * inv, v1 = o[qb][db][rg * 4 + 1] * inv;
+                    const float v2 = o[qb][db][rg * 4 + 2] * inv, v3 = o[qb][db][rg * 4 + 3] * inv;
+                    const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
+                    *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+                }
+        }
+    }
+}
+
+// =================================================================================================
 // v2s: v2 with the KV range split across KS wave groups INSIDE the workgroup (small batches: B*H*ceil(N/128)
 // workgroups of 4 waves leave the 256 CUs with one wave per SIMD and the whole kernel is one workgroup's latency
 // chain over all KV tiles).  Group g (4 waves, the same 128 queries as the other groups) walks tiles g, g+KS, ...
@@ -906,6 +1105,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
 
 int f5_attn_version = 2;   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower)
 int f5_attn_ablation = 0;  // timing experiments only
+int f5_attn_wide = -1;     // -1 auto (>= 1024 workgroups), 0 off, 1 force: 256-query workgroups, two query blocks per wave (bf16)
 int f5_attn_kvsplit = -1;  // -1 auto, 1 / 2 / 4 = force the in-workgroup KV split (debug hook)
 
 int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
@@ -922,6 +1122,13 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
         // measured (tools/attn_split_bench.py, N = 937, 16 heads): 128 WGs 20.5 / 17.4 / 16.2 us for 1 / 2 / 4 groups,
         // 256 WGs 21.4 / 19.1 / 20.1, 512 WGs 31.8 / 37.3 / 38.9
         ks = (wgs <= 160 && ntile >= 8) ? 4 : ((wgs <= 320 && ntile >= 4) ? 2 : 1);
+    }
+    // large grids (bf16): two query blocks per wave (256 queries per workgroup)
+    if (f5_attn_version == 2 && f5_attn_ablation == 0 && !a.hp && ks <= 1 &&
+        (f5_attn_wide >= 1 || (f5_attn_wide < 0 && (long)f5_cdiv(a.seq_len, 256) * grid.y >= 512))) {
+        hipLaunchKernelGGL(f5_attn2w_kernel, dim3(f5_cdiv(a.seq_len, 256), a.B * a.H), dim3(256), 0, stream, a);
+        F5_LAUNCH_CHECK();
+        return 0;
     }
     if (f5_attn_version == 2 && f5_attn_ablation == 0 && ks > 1) {
         if (a.hp) {

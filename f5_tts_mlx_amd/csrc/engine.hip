@@ -858,6 +858,12 @@ extern "C" int f5_debug_set_attn_ablation(int v) {
     f5_attn_ablation = v;
     return 0;
 }
+extern int f5_attn_wide;
+extern "C" int f5_debug_set_attn_wide(int v) {
+    F5_REQUIRE(v >= -1 && v <= 1, "attention wide-workgroup switch must be -1 (auto), 0 or 1");
+    f5_attn_wide = v;
+    return 0;
+}
 extern int f5_attn_kvsplit;
 extern "C" int f5_debug_set_attn_kvsplit(int v) {
     F5_REQUIRE(v == -1 || v == 1 || v == 2 || v == 4, "attention KV split must be -1 (auto), 1, 2 or 4");

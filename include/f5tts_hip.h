@@ -184,6 +184,8 @@ int f5_debug_gemm_streamk_error(void);
 int f5_debug_set_attn_version(int v);
 /* timing-only ablations of the attention kernel (results are wrong unless 0) */
 int f5_debug_set_attn_ablation(int v);
+/* 256-query workgroups with two query blocks per wave (bf16, large grids): -1 auto, 0 off, 1 force */
+int f5_debug_set_attn_wide(int v);
 /* in-workgroup KV split of the attention kernel: -1 auto (by grid size), 1 none, 2 / 4 wave groups */
 int f5_debug_set_attn_kvsplit(int v);
 

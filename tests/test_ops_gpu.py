@@ -438,6 +438,22 @@ def test_attention_other_kernel_versions(lib, ver):
         E.check(lib.f5_debug_set_attn_version(2))
 
 
+def test_attention_wide_workgroups(lib, mode=1):
+    """256-query workgroups, two query blocks per wave (the large-grid bf16 kernel), forced on small problems: ragged key
+    lengths, sequence tails inside the second query block, one-tile sequences"""
+    E.check(lib.f5_debug_set_attn_wide(mode))
+    E.check(lib.f5_debug_set_attn_kvsplit(1))
+    try:
+        _attention_case(lib, 1, 2, 50, None, 1, seed=1)
+        _attention_case(lib, 2, 2, 333, [333, 100], 1, seed=5)
+        _attention_case(lib, 3, 2, 200, [200, 130, 1], 1, seed=7)
+        _attention_case(lib, 1, 2, 937, None, 1, seed=8)
+        _attention_case(lib, 2, 4, 300, [300, 211], 1, seed=21)
+    finally:
+        E.check(lib.f5_debug_set_attn_wide(-1))
+        E.check(lib.f5_debug_set_attn_kvsplit(-1))
+
+
 @pytest.mark.parametrize("ks", [1, 2, 4])
 def test_attention_kv_split(lib, ks):
     """in-workgroup KV split (small-batch kernel): every split factor gives the one-pass result, including groups that
