@@ -13,6 +13,9 @@ for kv in args[:split]:
     elif k == "attn": lib.f5_debug_set_attn_version(v)
     elif k == "big": lib.f5_debug_set_gemm_big_kernel(v, -1)
     elif k == "ring": lib.f5_debug_set_gemm_ring(v)
+    elif k == "wide": lib.f5_debug_set_attn_wide(v)
+    elif k == "kvsplit": lib.f5_debug_set_attn_kvsplit(v)
+    elif k == "streamk": lib.f5_debug_set_gemm_streamk(v)
     else: raise SystemExit(f"unknown flag {k}")
 sys.argv = ["bench.py"] + args[split + 1:]
 runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), run_name="__main__")
