@@ -104,3 +104,27 @@ __device__ inline float f5_wave_max(float v) {
 }
 
 static inline int f5_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- MX (OCP microscaling) helpers: e4m3 elements, one E8M0 scale per 32 consecutive elements -------------------------
+// scale exponent e = ceil(log2(amax / 448)) so that amax / 2^e lies in (224, 448]: no element saturates (the OCP
+// reference rule floor(log2(amax)) - 8 clips elements in (448, 512) * 2^e instead).  Returned as the biased E8M0 byte.
+__device__ __forceinline__ int f5_mx_scale_byte(float amax) {
+    const float y = amax * 0x1.24924ap-9f;            // amax / 448 with the fp32-rounded reciprocal (oracle uses the same constant)
+    const uint32_t b = __float_as_uint(y);
+    int e = (int)((b >> 23) & 255u) + ((b & 0x7FFFFFu) ? 1 : 0);    // biased exponent of the next power of two >= y
+    if ((b >> 23) == 0) e = 0;                        // zero / denormal block
+    return e > 254 ? 254 : e;
+}
+__device__ __forceinline__ float f5_mx_inv_scale(int e8) {          // 2^(127 - e8): multiply elements by this before the cast
+    return __uint_as_float((uint32_t)(254 - e8) << 23);              // e8 in [0, 254] -> exponent field 254..0 (2^-127 flushes: block is zero)
+}
+__device__ __forceinline__ uint32_t f5_pack4_fp8(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.0f), 448.0f);              // v_cvt_pk_fp8_f32 does not saturate (probe: 500 -> NaN)
+    b = fminf(fmaxf(b, -448.0f), 448.0f);
+    c = fminf(fmaxf(c, -448.0f), 448.0f);
+    d = fminf(fmaxf(d, -448.0f), 448.0f);
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}

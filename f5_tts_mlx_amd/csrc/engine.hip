@@ -934,6 +934,41 @@ extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, 
     return f5_launch_gemm(g, epi, (hipStream_t)stream);
 }
 
+// MX-fp8 GEMM: A8/W8 e4m3 [rows][ld] + E8M0 scales [rows][K/32].  epi 0: out_f32 = acc + bias; 1: out_bf = bf16(acc + bias);
+// 2: (out8, out8s) = MX-fp8(gelu_tanh(acc + bias)); 4: out_f32 += gate * ((acc + bias) * keep[row])
+extern "C" int f5_op_gemm_f8(const void* a8, const void* a_scales, const void* w8, const void* w_scales, const float* bias,
+                             const float* gate, const uint8_t* rowkeep, float* out_f32, void* out_bf, void* out8, void* out8_scales,
+                             int M, int N, int K, int lda8, int ldw8, int ldo, int epi, void* stream) {
+    F5_REQUIRE(epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU_TANH || epi == EPI_RESID_GATE,
+               "f5_op_gemm_f8 supports epilogues 0, 1, 2 and 4");
+    F5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A8 = (const uint8_t*)a8;
+    g.As = (const uint8_t*)a_scales;
+    g.W8 = (const uint8_t*)w8;
+    g.Ws = (const uint8_t*)w_scales;
+    g.lda8 = lda8;
+    g.ldw8 = ldw8;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.nseg = 1;
+    g.bias = bias;
+    g.gate = gate;
+    g.rowkeep = rowkeep;
+    g.out_f32 = out_f32;
+    g.ldo = ldo;
+    g.out_bf[0] = (bf16_t*)out_bf;
+    g.ldob = ldo;
+    g.out8 = (uint8_t*)out8;
+    g.out8s = (uint8_t*)out8_scales;
+    g.ldo8 = ldo;
+    return f5_launch_gemm_f8(g, epi, (hipStream_t)stream);
+}
+extern "C" int f5_op_quantize_mx(const float* x, int ldx, void* q, int ldq, void* scales, int rows, int cols, void* stream) {
+    return f5_launch_quantize_mx(x, ldx, (uint8_t*)q, ldq, (uint8_t*)scales, rows, cols, (hipStream_t)stream);
+}
+
 extern "C" int f5_op_attention(const void* qk_hi, const void* qk_lo, const void* vt_hi, const void* vt_lo, void* out_hi,
                                void* out_lo, const int32_t* kv_len, int B, int H, int seq_len, int npad, int dmodel, float scale,
                                int hp, void* stream) {

@@ -37,6 +37,15 @@ struct F5GemmArgs {
     int seq_len, npad, heads, dmodel;
     bf16_t* vt[2];            // [B*heads][64][npad]
     int debug_flags;          // bit 0: skip the epilogue (timing experiments only)
+    // ---- MX-fp8 path (f5_launch_gemm_f8): e4m3 operands with one E8M0 scale per 32 consecutive K elements
+    const uint8_t* A8;        // [a_rows][lda8] bytes
+    const uint8_t* W8;        // [>=ceil256(N)][ldw8] bytes
+    const uint8_t* As;        // [a_rows][K/32] E8M0
+    const uint8_t* Ws;        // [>=ceil256(N)][K/32] E8M0
+    int lda8, ldw8;
+    uint8_t* out8;            // EPI_GELU_TANH: fp8 output [M][ldo8] + scales [M][N/32]
+    uint8_t* out8s;
+    int ldo8;
 };
 
 int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
@@ -46,3 +55,9 @@ int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
 int f5_gemm_streamk_init();
 int f5_gemm_streamk_error();
 extern int f5_gemm_streamk;
+
+// MX-fp8 GEMM (256x256x128 tiles, v_mfma_scale_f32_32x32x64_f8f6f4): M >= 1, N % 256 == 0, K % 128 == 0.
+// epi: EPI_F32, EPI_BF16, EPI_GELU_TANH (fp8 + scales out), EPI_RESID_GATE, EPI_QKV_ROPE.
+int f5_launch_gemm_f8(const F5GemmArgs& a, int epi, hipStream_t stream);
+// rows of fp32 -> e4m3 + E8M0 block scales (scale = 2^ceil(log2(amax/448)), round to nearest even, no saturation needed)
+int f5_launch_quantize_mx(const float* x, int ldx, uint8_t* q, int ldq, uint8_t* sc, int rows, int cols, hipStream_t stream);

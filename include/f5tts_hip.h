@@ -189,6 +189,17 @@ int f5_debug_set_attn_wide(int v);
 /* in-workgroup KV split of the attention kernel: -1 auto (by grid size), 1 none, 2 / 4 wave groups */
 int f5_debug_set_attn_kvsplit(int v);
 
+/* ---- MX-fp8 path (BASELINE configs[4]; gfx950 v_mfma_scale_f32_32x32x64_f8f6f4): OCP e4m3 elements, one E8M0 scale per 32
+ * consecutive K elements (scale = 2^ceil(log2(amax/448))).  No reference counterpart (the reference's reduced-precision mode
+ * is MLX int4/int8 weight quantisation, cfm.py:510-515). ---------------------------------------------------------------- */
+/* rows of fp32 [rows][ldx] -> e4m3 [rows][ldq] + E8M0 [rows][cols/32]; cols % 32 == 0 */
+int f5_op_quantize_mx(const float* x, int ldx, void* q, int ldq, void* scales, int rows, int cols, void* stream);
+/* C = A W^T on MX-fp8 operands (N % 256 == 0, K % 128 == 0).  epi 0: out_f32 = acc + bias; 1: out_bf = bf16(acc + bias);
+ * 2: (out8, out8_scales) = MX-fp8(gelu_tanh(acc + bias)); 4: out_f32 += gate * ((acc + bias) * keep[row]) */
+int f5_op_gemm_f8(const void* a8, const void* a_scales, const void* w8, const void* w_scales, const float* bias,
+                  const float* gate, const uint8_t* rowkeep, float* out_f32, void* out_bf, void* out8, void* out8_scales,
+                  int M, int N, int K, int lda8, int ldw8, int ldo, int epi, void* stream);
+
 /* ---- audio (audio.py:115-210; vocoder = vocos_mlx, third party) -------------------------------- */
 /* log-mel spectrogram of one waveform: wave dev [L] fp32 -> out dev [L/256][n_mels] */
 int f5_mel_spectrogram(const float* wave, int64_t L, const float* window, const float* filterbank, int n_fft, int hop,
