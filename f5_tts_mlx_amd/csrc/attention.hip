@@ -216,6 +216,27 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
 // 16-byte XOR swizzle chunk ^= (row>>1)&7 is applied to the SOURCE address and again on every read.  The
 // O rescale is skipped when no lane's running max moved (exact: alpha == 1 for every lane).
 // =================================================================================================
+// O^T accumulators of one 32-query block -> MX-fp8: the 64 head dims are two MX blocks (db = 0, 1); a lane holds 16 values of
+// each (the other 16 sit in lane ^ 32), 4 consecutive d per accumulator row group -> one 4-byte store each.
+__device__ __forceinline__ void attn_store_f8(const F5AttnArgs& p, const f32x16 (&o)[2], float inv, size_t row, int h, int hi) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        float am = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(o[db][e] * inv));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        const int e8 = f5_mx_scale_byte(am);
+        const float sc = inv * f5_mx_inv_scale(e8);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int d = db * 32 + 8 * rg + 4 * hi;
+            *reinterpret_cast<uint32_t*>(p.out8 + row * p.ldo8 + h * 64 + d) =
+                f5_pack4_fp8(o[db][rg * 4 + 0] * sc, o[db][rg * 4 + 1] * sc, o[db][rg * 4 + 2] * sc, o[db][rg * 4 + 3] * sc);
+        }
+        if (hi == 0) p.out8s[row * (size_t)(p.dmodel >> 5) + h * 2 + db] = (uint8_t)e8;
+    }
+}
+
 __device__ __forceinline__ void attn_glds16(const bf16_t* gptr, bf16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
@@ -440,7 +461,9 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qr = q0 + lq;
-    if (qr < p.seq_len) {
+    if (!HP && p.out8) {
+        if (qr < p.seq_len) attn_store_f8(p, o, inv, rowbase + qr, h, hi);
+    } else if (qr < p.seq_len) {
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -640,7 +663,9 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
         const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = 1.0f / l_tot;
         const int qr = q0 + qb * 32 + lq;
-        if (qr < p.seq_len) {
+        if (p.out8) {
+            if (qr < p.seq_len) attn_store_f8(p, o[qb], inv, rowbase + qr, h, hi);
+        } else if (qr < p.seq_len) {
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -897,7 +922,9 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qr = q0 + lq;
-    if (qr < p.seq_len) {
+    if (!HP && p.out8) {
+        if (qr < p.seq_len) attn_store_f8(p, o, inv, rowbase + qr, h, hi);
+    } else if (qr < p.seq_len) {
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1112,7 +1139,9 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     F5_REQUIRE(a.B > 0 && a.H > 0 && a.seq_len > 0, "attention: bad shape");
     F5_REQUIRE(a.npad % 64 == 0 && a.npad >= a.seq_len, "attention: npad must be a multiple of 64 and >= seq_len");
     F5_REQUIRE(a.ldqk % 8 == 0 && a.ldo % 4 == 0, "attention: bad leading dims");
-    F5_REQUIRE(a.qk[0] && a.vt[0] && a.out[0], "attention: null pointer");
+    F5_REQUIRE(a.qk[0] && a.vt[0] && (a.out[0] || a.out8), "attention: null pointer");
+    F5_REQUIRE(!a.out8 || (!a.hp && a.out8s && f5_attn_version == 2 && f5_attn_ablation == 0 && a.ldo8 % 4 == 0),
+               "attention: fp8 output needs the bf16 ring kernels");
     dim3 grid(f5_cdiv(a.seq_len, 128), a.B * a.H);
     // small batches: fewer workgroups than ~2 per CU -> split the KV range over 2 or 4 wave groups inside the workgroup
     int ks = f5_attn_kvsplit;

@@ -9,6 +9,10 @@ struct F5AttnArgs {
     int B, H, seq_len, npad, ldqk, ldo, dmodel;
     int hp;               // 0 bf16, 1 bf16x3
     float scale;
+    // MX-fp8 output (bf16 kernels only): e4m3 [B*seq_len][ldo8] + E8M0 [B*seq_len][dmodel/32] (one scale per head half)
+    uint8_t* out8;
+    uint8_t* out8s;
+    int ldo8;
 };
 
 int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream);

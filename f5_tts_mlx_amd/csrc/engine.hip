@@ -59,8 +59,13 @@ struct TensorDst {      // where (part of) a reference tensor goes
     bool loaded = false;
 };
 
+struct MatF8 {          // MX-fp8 matrix in the arena: e4m3 [rows_pad][ld] + E8M0 [rows_pad][ld/32]
+    size_t q = 0, s = 0;
+    int rows = 0, ld = 0;
+};
 struct BlockW {
     MatBF qkv, o, ff1, ff2;
+    MatF8 qkv8, o8, ff1_8, ff2_8;  // precision mxfp8 only (quantised from the bf16 copies at finalize)
     size_t bqkv, bo, bff1, bff2;  // fp32
 };
 struct TextBlockW {
@@ -79,6 +84,7 @@ struct Workspace {
     size_t tln[2], tg2[2], ct[2];
     size_t hc, x;
     size_t xb[2], c1[2], h[2], qk[2], vt[2], ao[2], ffh[2];
+    size_t h8, h8s, ao8, ao8s, ffh8, ffh8s;   // precision mxfp8: block-GEMM A operands as e4m3 + E8M0
     size_t vt_bytes;
 };
 
@@ -120,6 +126,16 @@ static MatBF alloc_mat(Bump& b, int rows, int ld, int np) {
     const int rows_pad = (rows + 127) / 128 * 128;  // GEMM reads whole 128-row weight tiles
     m.hi = b.take((size_t)rows_pad * ld * 2);
     m.lo = np == 2 ? b.take((size_t)rows_pad * ld * 2) : 0;
+    return m;
+}
+
+static MatF8 alloc_f8(Bump& b, int rows, int ld) {
+    MatF8 m;
+    m.rows = rows;
+    m.ld = ld;
+    const int rows_pad = (rows + 255) / 256 * 256;  // the MX GEMM reads whole 256-row weight tiles
+    m.q = b.take((size_t)rows_pad * ld);
+    m.s = b.take((size_t)rows_pad * (ld / 32));
     return m;
 }
 
@@ -217,6 +233,12 @@ static int build_arena_plan(f5_engine* e) {
         w.o = alloc_mat(b, D, D, np);
         w.ff1 = alloc_mat(b, FF, D, np);
         w.ff2 = alloc_mat(b, D, FF, np);
+        if (e->prec == F5_PREC_MXFP8) {
+            w.qkv8 = alloc_f8(b, 3 * D, D);
+            w.o8 = alloc_f8(b, D, D);
+            w.ff1_8 = alloc_f8(b, FF, D);
+            w.ff2_8 = alloc_f8(b, D, FF);
+        }
         w.bqkv = b.take((size_t)3 * D * 4);
         w.bo = b.take((size_t)D * 4);
         w.bff1 = b.take((size_t)FF * 4);
@@ -248,7 +270,8 @@ static int build_arena_plan(f5_engine* e) {
 extern "C" int f5_engine_create(const f5_config* cfg, int precision, f5_engine** out) {
     F5_REQUIRE(cfg && out, "f5_engine_create: null argument");
     const f5_config& c = *cfg;
-    F5_REQUIRE(precision == F5_PREC_BF16 || precision == F5_PREC_BF16X3, "unknown precision %d", precision);
+    F5_REQUIRE(precision == F5_PREC_BF16 || precision == F5_PREC_BF16X3 || precision == F5_PREC_MXFP8, "unknown precision %d", precision);
+    F5_REQUIRE(precision != F5_PREC_MXFP8 || (cfg->ff_dim % 256 == 0 && cfg->dim % 256 == 0), "mxfp8 needs dim and ff_dim to be multiples of 256");
     F5_REQUIRE(c.dim_head == 64, "dim_head must be 64 (got %d)", c.dim_head);
     F5_REQUIRE(c.heads * c.dim_head == c.dim, "heads * dim_head must equal dim (%d * %d != %d)", c.heads, c.dim_head, c.dim);
     F5_REQUIRE(c.dim % 256 == 0 && c.dim <= 1024, "dim must be a multiple of 256 and <= 1024 (got %d)", c.dim);
@@ -342,6 +365,19 @@ extern "C" int f5_finalize_weights(f5_engine* e, void* stream) {
         for (auto& d : kv.second) F5_REQUIRE(d.loaded, "tensor '%s' was never loaded", kv.first.c_str());
     int rc = f5_launch_text_pos_table((float*)(e->arena + e->text_pos), e->cfg.text_max_pos, e->cfg.text_dim, (hipStream_t)stream);
     if (rc) return rc;
+    if (e->prec == F5_PREC_MXFP8) {
+        // MX-fp8 copies of the four block matrices, from the bf16 copies (pad rows of the arena are zero -> scale 0, bytes 0)
+        for (const BlockW& w : e->blocks) {
+            const MatBF* src[4] = {&w.qkv, &w.o, &w.ff1, &w.ff2};
+            const MatF8* dst[4] = {&w.qkv8, &w.o8, &w.ff1_8, &w.ff2_8};
+            for (int k = 0; k < 4; ++k) {
+                rc = f5_launch_quantize_mx_bf16((const bf16_t*)(e->arena + src[k]->hi), src[k]->ld, (uint8_t*)(e->arena + dst[k]->q),
+                                                dst[k]->ld, (uint8_t*)(e->arena + dst[k]->s), src[k]->rows, src[k]->ld,
+                                                (hipStream_t)stream);
+                if (rc) return rc;
+            }
+        }
+    }
     F5_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     e->finalized = true;
     return 0;
@@ -399,6 +435,15 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
         w.vt[p] = p < np ? b.take(w.vt_bytes) : 0;
         w.ao[p] = p < np ? b.take(M2 * D * 2) : 0;
         w.ffh[p] = p < np ? b.take(M2 * FF * 2) : 0;
+    }
+    w.h8 = w.h8s = w.ao8 = w.ao8s = w.ffh8 = w.ffh8s = 0;
+    if (e->prec == F5_PREC_MXFP8) {
+        w.h8 = b.take(M2 * D);
+        w.h8s = b.take(M2 * (D / 32));
+        w.ao8 = b.take(M2 * D);
+        w.ao8s = b.take(M2 * (D / 32));
+        w.ffh8 = b.take(M2 * FF);
+        w.ffh8s = b.take(M2 * (FF / 32));
     }
     w.total = b.off;
     return w;
@@ -571,7 +616,80 @@ static int run_dit(const Ctx& c, int j) {
     cp.out_f32 = c.p<float>(w.x);
     RC(f5_launch_convpos(cp, s));
 
-    for (int i = 0; i < L; ++i) {
+    for (int i = 0; i < L && e->prec == F5_PREC_MXFP8; ++i) {
+        // MX-fp8 block: the four GEMMs run on e4m3 operands with E8M0 block scales (v_mfma_scale_f32_32x32x64_f8f6f4); their A
+        // operands are produced directly in that format by the LN kernel, the attention epilogue and the GELU epilogue.
+        // q / k / V^T and the attention itself stay bf16, the residual stream fp32.
+        const BlockW& bw = e->blocks[i];
+        const float* m6 = mod + (size_t)i * 6 * D;
+        auto f8args = [&](const uint8_t* a8, const uint8_t* as, int lda, const MatF8& wm, int N_, int K_, const float* bias) {
+            F5GemmArgs g;
+            memset(&g, 0, sizeof(g));
+            g.A8 = a8;
+            g.As = as;
+            g.lda8 = lda;
+            g.W8 = (const uint8_t*)(e->arena + wm.q);
+            g.Ws = (const uint8_t*)(e->arena + wm.s);
+            g.ldw8 = wm.ld;
+            g.M = M;
+            g.N = N_;
+            g.K = K_;
+            g.nseg = 1;
+            g.bias = bias;
+            return g;
+        };
+        RC(f5_launch_ln_modulate_f8(c.p<float>(w.x), m6 + D, m6, c.p<uint8_t>(w.h8), c.p<uint8_t>(w.h8s), M, D, 1e-6f, s));
+        F5GemmArgs gq = f8args(c.p<uint8_t>(w.h8), c.p<uint8_t>(w.h8s), D, bw.qkv8, 3 * D, D, c.a<float>(bw.bqkv));
+        gq.out_bf[0] = c.pb(w.qk, 0);
+        gq.ldob = 2 * D;
+        gq.rope_cos = c.p<float>(w.rope_cos);
+        gq.rope_sin = c.p<float>(w.rope_sin);
+        gq.seq_len = c.N;
+        gq.npad = c.npad;
+        gq.heads = H;
+        gq.dmodel = D;
+        gq.vt[0] = c.pb(w.vt, 0);
+        RC(f5_launch_gemm_f8(gq, EPI_QKV_ROPE, s));
+
+        F5AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.qk[0] = c.pb(w.qk, 0);
+        at.vt[0] = c.pb(w.vt, 0);
+        at.out8 = c.p<uint8_t>(w.ao8);
+        at.out8s = c.p<uint8_t>(w.ao8s);
+        at.ldo8 = D;
+        at.kv_len = kvlen;
+        at.B = c.nb * c.B;
+        at.H = H;
+        at.seq_len = c.N;
+        at.npad = c.npad;
+        at.ldqk = 2 * D;
+        at.ldo = D;
+        at.dmodel = D;
+        at.hp = 0;
+        at.scale = 1.0f / sqrtf((float)cf.dim_head);
+        RC(f5_launch_attention(at, s));
+
+        F5GemmArgs go = f8args(c.p<uint8_t>(w.ao8), c.p<uint8_t>(w.ao8s), D, bw.o8, D, D, c.a<float>(bw.bo));
+        go.out_f32 = c.p<float>(w.x);
+        go.ldo = D;
+        go.gate = m6 + 2 * D;
+        go.rowkeep = rowkeep;
+        RC(f5_launch_gemm_f8(go, EPI_RESID_GATE, s));
+
+        RC(f5_launch_ln_modulate_f8(c.p<float>(w.x), m6 + 4 * D, m6 + 3 * D, c.p<uint8_t>(w.h8), c.p<uint8_t>(w.h8s), M, D, 1e-6f, s));
+        F5GemmArgs g1 = f8args(c.p<uint8_t>(w.h8), c.p<uint8_t>(w.h8s), D, bw.ff1_8, FF, D, c.a<float>(bw.bff1));
+        g1.out8 = c.p<uint8_t>(w.ffh8);
+        g1.out8s = c.p<uint8_t>(w.ffh8s);
+        g1.ldo8 = FF;
+        RC(f5_launch_gemm_f8(g1, EPI_GELU_TANH, s));
+        F5GemmArgs g2 = f8args(c.p<uint8_t>(w.ffh8), c.p<uint8_t>(w.ffh8s), FF, bw.ff2_8, D, FF, c.a<float>(bw.bff2));
+        g2.out_f32 = c.p<float>(w.x);
+        g2.ldo = D;
+        g2.gate = m6 + 5 * D;
+        RC(f5_launch_gemm_f8(g2, EPI_RESID_GATE, s));
+    }
+    for (int i = 0; i < L && e->prec != F5_PREC_MXFP8; ++i) {
         const BlockW& bw = e->blocks[i];
         const float* m6 = mod + (size_t)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         RC(f5_launch_ln_modulate(c.p<float>(w.x), m6 + D, m6, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));

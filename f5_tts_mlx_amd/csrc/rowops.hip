@@ -62,6 +62,92 @@ int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift
     return 0;
 }
 
+// MX-fp8 variant: same math, output as e4m3 + one E8M0 scale per 32 columns (8 lanes x 4 columns = one block)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_modulate_f8_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, uint8_t* __restrict__ q,
+                                                             uint8_t* __restrict__ qs, int rows, float eps) {
+    constexpr int DIM = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * DIM;
+    f32x4 v[NV];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = f5_wave_sum(sum) * (1.0f / DIM);
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            sq += d * d;
+        }
+    const float var = f5_wave_sum(sq) * (1.0f / DIM);
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
+        float am = fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])));
+        am = fmaxf(am, __shfl_xor(am, 1, 64));
+        am = fmaxf(am, __shfl_xor(am, 2, 64));
+        am = fmaxf(am, __shfl_xor(am, 4, 64));
+        const int e8 = f5_mx_scale_byte(am);
+        const float inv = f5_mx_inv_scale(e8);
+        *reinterpret_cast<uint32_t*>(q + (size_t)row * DIM + c) = f5_pack4_fp8(y[0] * inv, y[1] * inv, y[2] * inv, y[3] * inv);
+        if ((lane & 7) == 0) qs[(size_t)row * (DIM / 32) + (c >> 5)] = (uint8_t)e8;
+    }
+}
+int f5_launch_ln_modulate_f8(const float* x, const float* scale, const float* shift, uint8_t* q, uint8_t* qs, int rows, int dim,
+                             float eps, hipStream_t s) {
+    F5_REQUIRE(dim % 256 == 0 && dim >= 256 && dim <= 1024, "ln_modulate_f8: dim must be 256/512/768/1024 (got %d)", dim);
+    const dim3 grid(f5_cdiv(rows, 4)), block(256);
+    switch (dim / 256) {
+        case 1: hipLaunchKernelGGL((ln_modulate_f8_kernel<1>), grid, block, 0, s, x, scale, shift, q, qs, rows, eps); break;
+        case 2: hipLaunchKernelGGL((ln_modulate_f8_kernel<2>), grid, block, 0, s, x, scale, shift, q, qs, rows, eps); break;
+        case 3: hipLaunchKernelGGL((ln_modulate_f8_kernel<3>), grid, block, 0, s, x, scale, shift, q, qs, rows, eps); break;
+        default: hipLaunchKernelGGL((ln_modulate_f8_kernel<4>), grid, block, 0, s, x, scale, shift, q, qs, rows, eps); break;
+    }
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+// bf16 rows -> MX-fp8 (weights at finalize time; the bf16 copy is the source so both precisions see the same rounding)
+__global__ __launch_bounds__(256) void quantize_mx_bf16_kernel(const bf16_t* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq,
+                                                               uint8_t* __restrict__ sc, int rows, int cols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    for (int c0 = lane * 4; c0 < cols; c0 += 256) {
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(x + (size_t)row * ldx + c0);
+        const float v0 = __uint_as_float(raw[0] << 16), v1 = __uint_as_float(raw[0] & 0xFFFF0000u);
+        const float v2 = __uint_as_float(raw[1] << 16), v3 = __uint_as_float(raw[1] & 0xFFFF0000u);
+        float am = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+        am = fmaxf(am, __shfl_xor(am, 1, 64));
+        am = fmaxf(am, __shfl_xor(am, 2, 64));
+        am = fmaxf(am, __shfl_xor(am, 4, 64));
+        const int e8 = f5_mx_scale_byte(am);
+        const float inv = f5_mx_inv_scale(e8);
+        *reinterpret_cast<uint32_t*>(q + (size_t)row * ldq + c0) = f5_pack4_fp8(v0 * inv, v1 * inv, v2 * inv, v3 * inv);
+        if ((lane & 7) == 0) sc[(size_t)row * (cols >> 5) + (c0 >> 5)] = (uint8_t)e8;
+    }
+}
+int f5_launch_quantize_mx_bf16(const bf16_t* x, int ldx, uint8_t* q, int ldq, uint8_t* sc, int rows, int cols, hipStream_t stream) {
+    F5_REQUIRE(rows > 0 && cols > 0 && cols % 32 == 0 && ldx % 4 == 0 && ldq % 4 == 0, "quantize_mx_bf16: cols must be a multiple of 32");
+    hipLaunchKernelGGL(quantize_mx_bf16_kernel, dim3(f5_cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, q, ldq, sc, rows, cols);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 // =================================================================================================
 // depthwise conv (k=7, pad=3, per batch element zero padding) + bias + LayerNorm(affine)
 // one wave per token; lane owns dim/64 channels as float4 chunks (dim = NV*256)

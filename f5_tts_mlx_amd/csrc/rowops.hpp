@@ -79,3 +79,7 @@ int f5_launch_pack_bf16(const float* src, const uint8_t* rowkeep, bf16_t* out_hi
                         int col0, hipStream_t s);
 int f5_launch_duration_head(const float* x, const float* g, const float* w, const uint8_t* mask, float* out, int B, int seq_len,
                             int dim, float eps, hipStream_t s);
+// MX-fp8 variants (engine precision mxfp8): LN + modulation straight to e4m3 + E8M0 scales; bf16 rows -> MX-fp8 (weights)
+int f5_launch_ln_modulate_f8(const float* x, const float* scale, const float* shift, uint8_t* q, uint8_t* qs, int rows, int dim,
+                             float eps, hipStream_t s);
+int f5_launch_quantize_mx_bf16(const bf16_t* x, int ldx, uint8_t* q, int ldq, uint8_t* sc, int rows, int cols, hipStream_t stream);

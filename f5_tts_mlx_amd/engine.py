@@ -20,7 +20,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libf5tts_hip.so"
 _lib = None
 
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2}
-PRECISIONS = {"bf16": 0, "bf16x3": 1}
+PRECISIONS = {"bf16": 0, "bf16x3": 1, "mxfp8": 2}     # mxfp8: MX-fp8 block GEMMs (gfx950 scaled MFMA), everything else bf16
 
 
 class F5Config(C.Structure):

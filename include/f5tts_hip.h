@@ -42,7 +42,7 @@ typedef struct f5_config {
     int32_t text_max_pos;    /* 4096 */
 } f5_config;
 
-enum { F5_PREC_BF16 = 0, F5_PREC_BF16X3 = 1 };           /* MFMA operand encoding */
+enum { F5_PREC_BF16 = 0, F5_PREC_BF16X3 = 1, F5_PREC_MXFP8 = 2 };   /* MFMA operand encoding (2: MX-fp8 block GEMMs, rest bf16) */
 enum { F5_EULER = 0, F5_MIDPOINT = 1, F5_RK4 = 2 };       /* cfm.py:38-122 */
 
 const char* f5_last_error(void);

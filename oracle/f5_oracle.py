@@ -205,10 +205,15 @@ class DiTOracle:
     conv_pos_kernel, conv_pos_groups, freq_embed_dim, text_max_pos (see weights.DiTConfig).
     """
 
-    def __init__(self, cfg, weights: Dict[str, np.ndarray], dtype=torch.float32, emulate_bf16: bool = False):
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], dtype=torch.float32, emulate_bf16: bool = False,
+                 emulate_mxfp8: bool = False):
+        """emulate_bf16: GEMM / attention operands rounded to bf16 like the engine's `bf16` mode.  emulate_mxfp8: the engine's
+        `mxfp8` mode (BASELINE configs[4], no reference counterpart): as bf16, except that both operands of the four
+        per-block linears (to_q/k/v, to_out, ff.0, ff.2) are MX-fp8 (oracle/mx_oracle.py), weights from their bf16 copies."""
         self.cfg = cfg
         self.dtype = dtype
-        self.emu = emulate_bf16
+        self.emu = emulate_bf16 or emulate_mxfp8
+        self.mx = emulate_mxfp8
         self.w = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in weights.items()}
         self._wb: Dict[str, Tensor] = {}
         self.freqs_cis = precompute_freqs_cis(cfg.text_dim, cfg.text_max_pos).to(dtype)   # dit.py:191
@@ -229,6 +234,12 @@ class DiTOracle:
 
     def linear(self, x: Tensor, name: str, lowp: bool = True) -> Tensor:
         """nn.Linear: x @ W.T + b, W (out, in)."""
+        if lowp and self.mx and ".transformer_blocks." in name and (".attn.to_" in name or ".ff.ff." in name):
+            from . import mx_oracle as MX
+            key = name + ".weight#mx"
+            if key not in self._wb:
+                self._wb[key] = MX.mx_round(_bf16(self.w[name + ".weight"]).float()).to(self.dtype)
+            return MX.mx_round(x.float()).to(self.dtype) @ self._wb[key].T + self.w[name + ".bias"]
         if lowp:
             return self._A(x) @ self._W(name + ".weight").T + self.w[name + ".bias"]
         return x @ self.w[name + ".weight"].T + self.w[name + ".bias"]

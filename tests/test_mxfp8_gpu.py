@@ -112,3 +112,91 @@ def test_gemm_f8_epilogues(lib):
     got = MX.mx_dequantize(o8.cpu(), o8s.cpu())
     step = torch.pow(2.0, o8s.cpu().double() - 127 + 5).repeat_interleave(32, dim=1)     # top-binade step of the block
     assert torch.all((got - g).abs() <= 0.51 * step + 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# model level: engine precision "mxfp8" vs the oracle with the same MX operand rounding
+# ------------------------------------------------------------------------------------------------
+from f5test import O, TINY, F5TTS_335M, synth_inputs, synthetic_weights   # noqa: E402
+from f5_tts_mlx_amd.cfm import F5TTS                                      # noqa: E402
+from f5_tts_mlx_amd.dit import DiT                                        # noqa: E402
+
+
+def _pad_cond(cond, N):
+    B, n_ref, mel = cond.shape
+    out = torch.zeros((B, N, mel))
+    out[:, :n_ref] = cond
+    return out
+
+
+@pytest.mark.parametrize("B,N,ragged", [(1, 150, False), (2, 200, True)])
+def test_dit_forward_mxfp8(B, N, ragged):
+    cfg = TINY
+    w = synthetic_weights(cfg, seed=42)
+    cond, text, durations, y0 = synth_inputs(cfg, B, N, nt=24, n_ref=30, seed=B * 100 + N, ragged=ragged)
+    sc = _pad_cond(cond, N)
+    mask = O.lens_to_mask(torch.tensor(durations), N) if B > 1 else None
+    t = 0.37
+    m = DiT.from_config(cfg, precision="mxfp8", device=DEV)
+    m.load_weights(w)
+    pred, null = m.engine.dit_forward(y0.to(DEV), text.to(DEV), sc.to(DEV), [N] * B, durations, t)
+    torch.cuda.synchronize()
+    emu = O.DiTOracle(cfg, w, emulate_mxfp8=True)
+    fp32 = O.DiTOracle(cfg, w)
+    for name, got, flags in (("cond", pred, (False, False)), ("null", null, (True, True))):
+        want = emu.forward(y0, sc, text, torch.tensor(t), flags[0], flags[1], mask)
+        full = fp32.forward(y0, sc, text, torch.tensor(t), flags[0], flags[1], mask)
+        _, mean, refm = report(f"mxfp8 forward [{name}] B{B} N{N} vs oracle[mxfp8 emulation]", got.cpu(), want)
+        _, drift, _ = report(f"mxfp8 forward [{name}] drift vs oracle[fp32]", got.cpu(), full)
+        # same operand rounding on both sides: what remains are fp8 rounding flips caused by fp32-level differences upstream
+        assert mean <= 1.5e-2 * max(1.0, refm)
+        assert drift <= 0.15 * max(1.0, refm)
+
+
+def test_sample_mxfp8_midpoint_with_vocoder():
+    """BASELINE configs[4] in miniature: MX-fp8 weights/activations, midpoint solver, Vocos on top"""
+    from f5_tts_mlx_amd.vocos import Vocos, synthetic_vocos_weights
+    cfg = TINY
+    w = synthetic_weights(cfg, seed=42)
+    B, N = 2, 160
+    cond, text, durations, y0 = synth_inputs(cfg, B, N, nt=24, n_ref=40, seed=9)
+    m = DiT.from_config(cfg, precision="mxfp8", device=DEV)
+    m.load_weights(w)
+    voc = Vocos(synthetic_vocos_weights(seed=7), device=DEV)
+    tts = F5TTS(m, vocoder=voc.decode)
+    mel_model = F5TTS(m)
+    out_mel, traj = mel_model.sample(cond.to(DEV), text=text.to(DEV), duration=torch.tensor(durations), steps=5, method="midpoint",
+                                     y0=y0.to(DEV))
+    torch.cuda.synchronize()
+    emu = O.DiTOracle(cfg, w, emulate_mxfp8=True)
+    want, _ = O.sample(emu, cond, text, torch.tensor(durations), steps=5, method="midpoint", y0=y0)
+    _, mean, refm = report("mxfp8 5-point midpoint sample vs oracle[mxfp8 emulation]", out_mel.cpu(), want)
+    assert mean <= 3e-2 * max(1.0, refm)
+    wave, _ = tts.sample(cond.to(DEV), text=text.to(DEV), duration=torch.tensor(durations), steps=5, method="midpoint", y0=y0.to(DEV))
+    torch.cuda.synchronize()
+    assert wave.shape[0] == B and torch.isfinite(wave).all()
+    # graph replay == eager, bitwise
+    a, _ = mel_model.sample(cond.to(DEV), text=text.to(DEV), duration=torch.tensor(durations), steps=5, method="midpoint", y0=y0.to(DEV),
+                            use_graph=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a, out_mel)
+
+
+def test_full_size_forward_mxfp8_drift():
+    """335M, N=937: one CFG evaluation; reports the drift of the MX-fp8 mode against the fp32 oracle"""
+    cfg = F5TTS_335M
+    w = synthetic_weights(cfg, seed=42)
+    N = 937
+    cond, text, durations, y0 = synth_inputs(cfg, 1, N, nt=160, n_ref=281, seed=1)
+    sc = _pad_cond(cond, N)
+    m = DiT.from_config(cfg, precision="mxfp8", device=DEV)
+    m.load_weights(w)
+    pred, null = m.engine.dit_forward(y0.to(DEV), text.to(DEV), sc.to(DEV), [N], durations, 0.25)
+    torch.cuda.synchronize()
+    emu = O.DiTOracle(cfg, w, emulate_mxfp8=True)
+    want = emu.forward(y0, sc, text, torch.tensor(0.25), False, False, None)
+    full = O.DiTOracle(cfg, w).forward(y0, sc, text, torch.tensor(0.25), False, False, None)
+    _, mean, refm = report("full-size mxfp8 forward vs oracle[mxfp8 emulation]", pred.cpu(), want)
+    _, drift, _ = report("full-size mxfp8 forward drift vs oracle[fp32]", pred.cpu(), full)
+    assert mean <= 3e-2 * max(1.0, refm)
+    assert drift <= 0.3 * max(1.0, refm)
