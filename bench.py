@@ -74,6 +74,8 @@ def gemm_roofline(model: DiT, B: int, iters: int = 20):
     npad = (N_FRAMES + 63) // 64 * 64
     nseg = 3 if model.precision == "bf16x3" else 1
     g = torch.Generator(device="cpu").manual_seed(0)
+    if model.precision == "mxfp8":
+        return gemm_roofline_f8(lib, E, dev, M, D, g, iters)
     # operand statistics of the real workload (activations ~N(0,1), weights ~N(0,1/fan_in)): data toggling sets the
     # DVFS clock, so a microbenchmark on hotter random data would not agree with the in-graph rocprof average
     mk = lambda std, *s: (torch.randn(*s, generator=g) * std).to(dev).to(torch.bfloat16)
@@ -110,6 +112,40 @@ def gemm_roofline(model: DiT, B: int, iters: int = 20):
                 avg_launch_ms=ms, achieved=achieved, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / BF16_PEAK_TFLOPS,
                 traffic=traffic, traffic_unit="bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                 algorithmic_bytes=2 * M * D + 2 * 3 * D * D + 2 * M * 3 * D)
+
+
+FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (MX) MFMA peak, MI355X_MICROARCH.md
+
+
+def gemm_roofline_f8(lib, E, dev, M, D, g, iters):
+    """mxfp8 mode: the QKV projection runs on f5_gemm256f8_kernel (MX-fp8 operands, v_mfma_scale_f32_32x32x64_f8f6f4).  Timed
+    here through f5_op_gemm_f8 with the plain bf16-output epilogue (same main loop and output bytes; the RoPE / head-split
+    epilogue of the in-engine launch is not exported as an op), operands quantised from workload-like data."""
+    a = (torch.randn(M, D, generator=g)).to(dev)
+    w = (torch.randn(3 * D, D, generator=g) * D ** -0.5).to(dev)
+    a8, asc = torch.empty(M, D, dtype=torch.uint8, device=dev), torch.empty(M, D // 32, dtype=torch.uint8, device=dev)
+    w8, wsc = torch.empty(3 * D, D, dtype=torch.uint8, device=dev), torch.empty(3 * D, D // 32, dtype=torch.uint8, device=dev)
+    st = E.stream_ptr(dev)
+    E.check(lib.f5_op_quantize_mx(E.ptr(a), D, E.ptr(a8), D, E.ptr(asc), M, D, st))
+    E.check(lib.f5_op_quantize_mx(E.ptr(w), D, E.ptr(w8), D, E.ptr(wsc), 3 * D, D, st))
+    bias = torch.zeros(3 * D, device=dev)
+    out = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev)
+    def run():
+        E.check(lib.f5_op_gemm_f8(E.ptr(a8), E.ptr(asc), E.ptr(w8), E.ptr(wsc), E.ptr(bias), E.ptr(None), E.ptr(None), E.ptr(None),
+                                  E.ptr(out), E.ptr(None), E.ptr(None), M, 3 * D, D, D, D, 3 * D, 1, E.stream_ptr(dev)))
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    achieved = 2.0 * M * D * 3 * D / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", kernel="QKV-shaped MX-fp8 GEMM + bias, bf16 out (f5_gemm256f8_kernel<EPI_BF16>)", shape=f"M={M} N={3 * D} K={D}",
+                avg_launch_ms=ms, achieved=achieved, peak=FP8_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / FP8_PEAK_TFLOPS,
+                traffic=None, traffic_unit="bytes/launch", algorithmic_bytes=M * D + 3 * D * D + (M + 3 * D) * D // 32 + 2 * M * 3 * D)
 
 
 def cpu_baseline(weights, budget_s: float = 25.0):
@@ -157,12 +193,19 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU (BASELINE configs[1] = 1, configs[2] = 32)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "mxfp8"])
+    ap.add_argument("--vocoder", action="store_true", help="include the Vocos vocoder (random-init) in the timed region: mel -> waveform")
+    ap.add_argument("--config", default=None, choices=["c5"],
+                    help="c5 = BASELINE configs[4]: MX-fp8 block GEMMs + Vocos, 16-point midpoint, batch 32")
     ap.add_argument("--method", default="euler")
     ap.add_argument("--ode-points", type=int, default=ODE_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
+    if args.config == "c5":
+        args.precision, args.vocoder, args.method, args.ode_points = "mxfp8", True, "midpoint", 16
+        if args.batch == 1:
+            args.batch = 32
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +232,11 @@ def main():
         bcast_ms = None
     load_s = time.perf_counter() - t_w
 
-    f5 = F5TTS(transformer=model)
+    vocoder = None
+    if args.vocoder:
+        from f5_tts_mlx_amd.vocos import Vocos, synthetic_vocos_weights
+        vocoder = Vocos(synthetic_vocos_weights(seed=7), device=device).decode
+    f5 = F5TTS(transformer=model, vocoder=vocoder)
     cond, text, y0 = synth_batch(B, first=rank * B, device=device)
     kw = dict(duration=N_FRAMES, steps=args.ode_points, method=args.method, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0,
               use_graph=not args.no_graph)
@@ -226,10 +273,13 @@ def main():
         rec = {
             "metric": "mel_frames_per_sec", "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (split-bf16 operands, fp32-class)",
+            "vs_baseline": None,
+            "dtype": {"bf16": "bf16", "bf16x3": "bf16x3 (split-bf16 operands, fp32-class)",
+                      "mxfp8": "mxfp8 (OCP e4m3 + E8M0 block scales for the four per-block GEMMs; attention and the rest bf16)"}[args.precision],
             "data": "synthetic (seeded random-init 335M weights, white-noise reference audio, random token ids)",
             "config": {"workload": f"F5-TTS 335M, {args.ode_points}-point {args.method} (={n_fwd} DiT forwards, CFG), "
-                                   f"batch {B}/GPU x 10 s (N=937) utterances, hipGraph={not args.no_graph}",
+                                   f"batch {B}/GPU x 10 s (N=937) utterances, hipGraph={not args.no_graph}"
+                                   + (", + Vocos vocoder (mel -> waveform) in the timed region" if args.vocoder else ""),
                        "global_batch": world * B, "seq_len": N_FRAMES, "parallelism": f"dp{world} (utterance sharding)"},
             "rtf": world * B * 10.0 / (ms_per_step * 1e-3),
             "per_gpu_value": value / world,
