@@ -282,6 +282,8 @@ def main():
                                    + (", + Vocos vocoder (mel -> waveform) in the timed region" if args.vocoder else ""),
                        "global_batch": world * B, "seq_len": N_FRAMES, "parallelism": f"dp{world} (utterance sharding)"},
             "rtf": world * B * 10.0 / (ms_per_step * 1e-3),
+            # the reference's own definition (generate.py:183-189): seconds of GENERATED audio (reference trimmed off) per second
+            "rtf_generated_only": world * B * (N_FRAMES - REF_SAMPLES // 256) * 256 / 24000.0 / (ms_per_step * 1e-3),
             "per_gpu_value": value / world,
             "executed_tflop_per_step": exec_tflop, "reference_tflop_per_step": ref_tflop,
             "whole_path_tflops": exec_tflop / (ms_per_step * 1e-3),

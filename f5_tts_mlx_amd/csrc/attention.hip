@@ -237,6 +237,25 @@ __device__ __forceinline__ void attn_store_f8(const F5AttnArgs& p, const f32x16 
     }
 }
 
+// p = exp2(s * c2 - mc) for a 16-register accumulator block, in place, returning the partial row sum: the scale / subtract and the
+// sum run as packed v_pk_fma_f32 / v_pk_add_f32 (two values per VALU issue; MFMA and VALU time add on a SIMD, so every VALU
+// instruction saved is kernel time, tools/probes/coissue.hip)
+typedef float attn_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ attn_f32x2 attn_exp_block(f32x16& s, float c2, float mc, attn_f32x2 sum2) {
+    const attn_f32x2 c2v = {c2, c2}, mcv = {mc, mc};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        attn_f32x2 t = {s[r], s[r + 1]};
+        t = t * c2v - mcv;
+        t[0] = __builtin_amdgcn_exp2f(t[0]);
+        t[1] = __builtin_amdgcn_exp2f(t[1]);
+        s[r] = t[0];
+        s[r + 1] = t[1];
+        sum2 += t;
+    }
+    return sum2;
+}
+
 __device__ __forceinline__ void attn_glds16(const bf16_t* gptr, bf16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
@@ -409,17 +428,23 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
         }
         const float mc = m_run * c2;
         float psum = 0.0f;
+        if (ABL == 0 || ABL == 2 || ABL == 3 || ABL == 4 || ABL == 6 || ABL == 7) {
+            attn_f32x2 ps2 = {0.0f, 0.0f};
+            ps2 = attn_exp_block(s[0], c2, mc, ps2);
+            ps2 = attn_exp_block(s[1], c2, mc, ps2);
+            psum = ps2[0] + ps2[1];
+        } else {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv;
-                if (ABL == 5) pv = s[kb][r];
-                else if (ABL == 1) pv = s[kb][r] * c2 - mc;
-                else pv = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
-                s[kb][r] = pv;
-                if (ABL != 5) psum += pv;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    float pv;
+                    if (ABL == 5) pv = s[kb][r];
+                    else pv = s[kb][r] * c2 - mc;
+                    s[kb][r] = pv;
+                    if (ABL != 5) psum += pv;
+                }
+        }
         l_run += psum;
 
 #pragma unroll
@@ -623,16 +648,10 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
                 }
             }
             const float mc = m_run[qb] * c2;
-            float psum = 0.0f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[qb][kb][r] * c2 - mc);
-                    s[qb][kb][r] = pv;
-                    psum += pv;
-                }
-            l_run[qb] += psum;
+            attn_f32x2 ps2 = {0.0f, 0.0f};
+            ps2 = attn_exp_block(s[qb][0], c2, mc, ps2);
+            ps2 = attn_exp_block(s[qb][1], c2, mc, ps2);
+            l_run[qb] += ps2[0] + ps2[1];
         }
 
 #pragma unroll
@@ -841,16 +860,10 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
             }
         }
         const float mc = m_run * c2;
-        float psum = 0.0f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[kb][r] * c2 - mc);
-                s[kb][r] = pv;
-                psum += pv;
-            }
-        l_run += psum;
+        attn_f32x2 ps2 = {0.0f, 0.0f};
+        ps2 = attn_exp_block(s[0], c2, mc, ps2);
+        ps2 = attn_exp_block(s[1], c2, mc, ps2);
+        l_run += ps2[0] + ps2[1];
 
 #pragma unroll
         for (int ks4 = 0; ks4 < 4; ++ks4) {
