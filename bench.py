@@ -64,6 +64,27 @@ def synth_batch(B: int, first: int, device):
     return cond, text, y0
 
 
+def _time_launches(run, dev, iters: int) -> float:
+    """Average duration (ms) of `iters` back-to-back launches of `run`, replayed from a hipGraph (as the kernel runs inside
+    sample(): no host launch gaps), timed with HIP events on the stream the graph is launched on."""
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(iters):
+            run()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def gemm_roofline(model: DiT, B: int, iters: int = 20):
     """Live HIP-event timing of the dominant kernel (QKV projection GEMM, f5_gemm_kernel<EPI_QKV_ROPE>) at the
     bench shape: M = 2*B*N rows (cond + null), K = 1024, N = 3072."""
@@ -89,15 +110,7 @@ def gemm_roofline(model: DiT, B: int, iters: int = 20):
         E.check(lib.f5_op_qkv_rope(E.ptr(a_hi), E.ptr(lo(a_lo)), E.ptr(w_hi), E.ptr(lo(w_lo)), E.ptr(bias), E.ptr(cos_t),
                                    E.ptr(sin_t), E.ptr(qk[0]), E.ptr(lo(qk[1])), E.ptr(vt[0]), E.ptr(lo(vt[1])), 2 * B, N_FRAMES,
                                    npad, H, D, nseg, E.stream_ptr(dev)))
-    for _ in range(3):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms = _time_launches(run, dev, iters)
     flops = 2.0 * M * D * 3 * D                      # algorithmic: one (hi*hi) pass, whatever the precision mode
     achieved = flops / (ms * 1e-3) / 1e12
     shape = f"M={M} N={3 * D} K={D}"
@@ -133,15 +146,7 @@ def gemm_roofline_f8(lib, E, dev, M, D, g, iters):
     def run():
         E.check(lib.f5_op_gemm_f8(E.ptr(a8), E.ptr(asc), E.ptr(w8), E.ptr(wsc), E.ptr(bias), E.ptr(None), E.ptr(None), E.ptr(None),
                                   E.ptr(out), E.ptr(None), E.ptr(None), M, 3 * D, D, D, D, 3 * D, 1, E.stream_ptr(dev)))
-    for _ in range(3):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms = _time_launches(run, dev, iters)
     achieved = 2.0 * M * D * 3 * D / (ms * 1e-3) / 1e12
     return dict(bound="mfma", kernel="QKV-shaped MX-fp8 GEMM + bias, bf16 out (f5_gemm256f8_kernel<EPI_BF16>)", shape=f"M={M} N={3 * D} K={D}",
                 avg_launch_ms=ms, achieved=achieved, peak=FP8_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / FP8_PEAK_TFLOPS,
