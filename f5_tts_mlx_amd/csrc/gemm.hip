@@ -607,25 +607,25 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         }
     }
 
-    // issue one half tile (A half h / B half h) of K-tile `tt` into its slot (slots: A0,A1,B0,B1 per K-tile parity)
-#define V2_ISSUE_A(tt_, h_)                                                                         \
+    // issue one half tile (A half h / B half h) of K-tile `tt` into its slot (slots: A0,A1,B0,B1 per K-tile parity); the operand
+    // (bf16x3 segment) pointer and the K offset of the tile are running values, not recomputed (tt / kt is ~20 SALU instructions
+    // and sat in front of every one of the four issue points of a K step)
+#define V2_ISSUE_A(tt_, h_, Ap_, k0_)                                                               \
     {                                                                                               \
-        const int seg_ = (tt_) / kt;                                                                \
-        const int k0_ = ((tt_) - seg_ * kt) * BK;                                                   \
         bf16_t* dst_ = smem + (((tt_) & 1) * 4 + (h_)) * V2_HALF_ELEMS;                             \
-        const bf16_t* Ap_ = (seg_ == 1) ? p.A[1] : p.A[0];                                          \
-        glds16(Ap_ + srcA[(h_)][0] + k0_, dst_ + ldsoff[0]);                                        \
-        glds16(Ap_ + srcA[(h_)][1] + k0_, dst_ + ldsoff[1]);                                        \
+        glds16((Ap_) + srcA[(h_)][0] + (k0_), dst_ + ldsoff[0]);                                    \
+        glds16((Ap_) + srcA[(h_)][1] + (k0_), dst_ + ldsoff[1]);                                    \
     }
-#define V2_ISSUE_B(tt_, h_)                                                                         \
+#define V2_ISSUE_B(tt_, h_, Wp_, k0_)                                                               \
     {                                                                                               \
-        const int seg_ = (tt_) / kt;                                                                \
-        const int k0_ = ((tt_) - seg_ * kt) * BK;                                                   \
         bf16_t* dst_ = smem + (((tt_) & 1) * 4 + 2 + (h_)) * V2_HALF_ELEMS;                         \
-        const bf16_t* Wp_ = (seg_ == 2) ? p.W[1] : p.W[0];                                          \
-        glds16(Wp_ + srcB[(h_)][0] + k0_, dst_ + ldsoff[0]);                                        \
-        glds16(Wp_ + srcB[(h_)][1] + k0_, dst_ + ldsoff[1]);                                        \
+        glds16((Wp_) + srcB[(h_)][0] + (k0_), dst_ + ldsoff[0]);                                    \
+        glds16((Wp_) + srcB[(h_)][1] + (k0_), dst_ + ldsoff[1]);                                    \
     }
+    // (segment, K offset) of K-tile tt: segment 0 = A.hi W.hi, 1 = A.lo W.hi, 2 = A.hi W.lo
+#define V2_SEGK(tt_, seg_, k0_)              \
+    const int seg_ = (tt_) / kt;             \
+    const int k0_ = ((tt_) - seg_ * kt) * BK;
 #define V2_BARRIER()                                   \
     {                                                  \
         asm volatile("" ::: "memory");                 \
@@ -642,13 +642,33 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     // ---- prologue: tile 0 (4 halves) + B halves of tile 1 -----------------------------------------
-    V2_ISSUE_A(t0, 0);
-    V2_ISSUE_A(t0, 1);
-    V2_ISSUE_B(t0, 0);
-    V2_ISSUE_B(t0, 1);
+    int a_seg, a_k0, b_seg, b_k0;                     // running state: tile tt+1 (A halves) and tile tt+2 (B halves)
+    {
+        V2_SEGK(t0, s0_, k00_);
+        const bf16_t* Ap0 = s0_ == 1 ? p.A[1] : p.A[0];
+        const bf16_t* Wp0 = s0_ == 2 ? p.W[1] : p.W[0];
+        V2_ISSUE_A(t0, 0, Ap0, k00_);
+        V2_ISSUE_A(t0, 1, Ap0, k00_);
+        V2_ISSUE_B(t0, 0, Wp0, k00_);
+        V2_ISSUE_B(t0, 1, Wp0, k00_);
+        a_seg = s0_;
+        a_k0 = k00_ + BK;
+        if (a_k0 == p.K) {
+            a_k0 = 0;
+            ++a_seg;
+        }
+        b_seg = a_seg;
+        b_k0 = a_k0;
+    }
     if (t0 + 1 < t1) {
-        V2_ISSUE_B(t0 + 1, 0);
-        V2_ISSUE_B(t0 + 1, 1);
+        const bf16_t* Wp1 = b_seg == 2 ? p.W[1] : p.W[0];
+        V2_ISSUE_B(t0 + 1, 0, Wp1, b_k0);
+        V2_ISSUE_B(t0 + 1, 1, Wp1, b_k0);
+        b_k0 += BK;
+        if (b_k0 == p.K) {
+            b_k0 = 0;
+            ++b_seg;
+        }
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -670,7 +690,9 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             for (int mb = 0; mb < 2; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(mb * 32 + frow, ks * 2 + fk)]);
             bfr[0][ks] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(brow0 + frow, ks * 2 + fk)]);
         }
-        if (tt + 1 < t1) V2_ISSUE_A(tt + 1, 0);
+        const bf16_t* Apn = a_seg == 1 ? p.A[1] : p.A[0];
+        const bf16_t* Wpn = b_seg == 2 ? p.W[1] : p.W[0];
+        if (tt + 1 < t1) V2_ISSUE_A(tt + 1, 0, Apn, a_k0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -682,7 +704,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         // ---- phase 2: B(nq=1); quadrant (0,1); issue A1(t+1)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bfr[1][ks] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(brow0 + 32 + frow, ks * 2 + fk)]);
-        if (tt + 1 < t1) V2_ISSUE_A(tt + 1, 1);
+        if (tt + 1 < t1) V2_ISSUE_A(tt + 1, 1, Apn, a_k0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -697,7 +719,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(64 + mb * 32 + frow, ks * 2 + fk)]);
-        if (tt + 2 < t1) V2_ISSUE_B(tt + 2, 0);
+        if (tt + 2 < t1) V2_ISSUE_B(tt + 2, 0, Wpn, b_k0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -708,7 +730,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         V2_BARRIER();   // every wave has finished reading the A halves of this tile
 
         // ---- phase 4: quadrant (1,0) from registers; issue B1(t+2)
-        if (tt + 2 < t1) V2_ISSUE_B(tt + 2, 1);
+        if (tt + 2 < t1) V2_ISSUE_B(tt + 2, 1, Wpn, b_k0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -723,6 +745,16 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         V2_BARRIER();
+        a_k0 += BK;
+        if (a_k0 == p.K) {
+            a_k0 = 0;
+            ++a_seg;
+        }
+        b_k0 += BK;
+        if (b_k0 == p.K) {
+            b_k0 = 0;
+            ++b_seg;
+        }
     }
 
     // Partial tiles cross XCDs, whose L2s are not coherent.  No agent-scope fences here: a release fence writes back and an
