@@ -494,6 +494,13 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
     }
 }
 
+// a wave-uniform pointer the compiler can see is uniform (SGPR pair): lets global_load_lds use the "SGPR base + 32-bit VGPR
+// offset" addressing form, i.e. no per-load 64-bit VALU add
+__device__ __forceinline__ const char* v2_uniform_ptr(const void* ptr) {
+    const uint64_t u = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
 // SK = stream-K scheduling: the grid is one persistent workgroup per CU and workgroup `rid` owns the contiguous range
 // [rid*W/P, (rid+1)*W/P) of the W = ntiles*T K-steps (tile-major).  A range is: the HEAD of a tile that the next range
 // finishes (done FIRST: partial sums -> sk_part[rid], flag), the TAIL of a tile begun by the previous range (waits for
@@ -504,7 +511,7 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
 template <int EPI, bool SK>
 __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles_n, int ntiles, float* sk_part, int* sk_flag,
                                                          int* sk_err, int sk_hybrid) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * V2_HALF_ELEMS];   // [dbuf][A0,A1,B0,B1][128*64]
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * V2_HALF_ELEMS];   // [A0,A1,B0,B1][ring buffer][128*64]
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
@@ -552,6 +559,18 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
 
     const int frow = lane & 31;
     const int fk = lane >> 5;
+    // fragment read pointers, one per 16-wide K sub-step: everything else (ring buffer, row block, quadrant) is a compile-time
+    // offset that lands in the ds_read offset field, so the main loop spends no VALU instruction on LDS addressing (on this
+    // chip nothing else issues on a SIMD while an MFMA is in flight, tools/probes/coissue.hip: every non-MFMA instruction of
+    // the loop is paid in full)
+    // (LDS layout [A0,A1,B0,B1][ring buffer][128 x 64]: the ring-buffer offset, 16 KB, is an immediate as well)
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        pa[ks] = smem + (wm * 2) * V2_HALF_ELEMS + swz_off(frow, ks * 2 + fk);
+        pb[ks] = smem + ((2 + (wn >> 1)) * 2) * V2_HALF_ELEMS + swz_off((wn & 1) * 64 + frow, ks * 2 + fk);
+    }
     for (int sp = 0; sp < nspan; ++sp) {
     int kind, pos, t0, t1;                            // kind: 0 whole tile, 1 head (publish partial), 2 tail (consume partial)
     const int ss = sp - ndp;
@@ -589,7 +608,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     // ---- staging addresses: 2 chunks per thread per half tile -----------------------------------
     // linear chunk q_ = j*512 + tid of the [128][8] half-tile image; row = q_>>3, slot = q_&7,
     // source chunk = slot ^ ((row>>1)&7)
-    size_t srcA[2][2], srcB[2][2];   // [half][j] element offsets (without k0)
+    uint32_t srcA[2][2], srcB[2][2];   // [half][j] BYTE offsets (without k0): 32-bit, added to a uniform pointer (saddr form)
     int ldsoff[2];                   // [j] element offset of this WAVE's 1 KB destination inside a half tile
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -602,25 +621,30 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             int gr = m0 + h * 128 + row;
             if (gr > p.M - 1) gr = p.M - 1;
             if (p.a_row_mod > 0) gr = gr % p.a_row_mod;
-            srcA[h][j] = (size_t)gr * p.lda + chunk * 8;
-            srcB[h][j] = (size_t)(n0 + h * 128 + row) * p.ldw + chunk * 8;
+            srcA[h][j] = ((uint32_t)gr * (uint32_t)p.lda + chunk * 8) * 2u;
+            srcB[h][j] = ((uint32_t)(n0 + h * 128 + row) * (uint32_t)p.ldw + chunk * 8) * 2u;
         }
     }
 
-    // issue one half tile (A half h / B half h) of K-tile `tt` into its slot (slots: A0,A1,B0,B1 per K-tile parity); the operand
+    // issue one half tile (A half h / B half h) into ring buffer `par` (K tiles alternate buffers, the first tile of a span uses
+    // buffer 0, so the parity is a compile-time constant in the 2x unrolled loop); the operand
     // (bf16x3 segment) pointer and the K offset of the tile are running values, not recomputed (tt / kt is ~20 SALU instructions
     // and sat in front of every one of the four issue points of a K step)
-#define V2_ISSUE_A(tt_, h_, Ap_, k0_)                                                               \
+#define V2_ISSUE_A(par_, h_, Ap_, k0_)                                                              \
     {                                                                                               \
-        bf16_t* dst_ = smem + (((tt_) & 1) * 4 + (h_)) * V2_HALF_ELEMS;                             \
-        glds16((Ap_) + srcA[(h_)][0] + (k0_), dst_ + ldsoff[0]);                                    \
-        glds16((Ap_) + srcA[(h_)][1] + (k0_), dst_ + ldsoff[1]);                                    \
+        bf16_t* dst_ = smem + ((h_) * 2 + (par_)) * V2_HALF_ELEMS;                                  \
+        const char* src_ = reinterpret_cast<const char*>(Ap_);                                      \
+        const uint32_t kb_ = (uint32_t)(k0_) * 2u;                                                  \
+        glds16(reinterpret_cast<const bf16_t*>(src_ + (srcA[(h_)][0] + kb_)), dst_ + ldsoff[0]);    \
+        glds16(reinterpret_cast<const bf16_t*>(src_ + (srcA[(h_)][1] + kb_)), dst_ + ldsoff[1]);    \
     }
-#define V2_ISSUE_B(tt_, h_, Wp_, k0_)                                                               \
+#define V2_ISSUE_B(par_, h_, Wp_, k0_)                                                              \
     {                                                                                               \
-        bf16_t* dst_ = smem + (((tt_) & 1) * 4 + 2 + (h_)) * V2_HALF_ELEMS;                         \
-        glds16((Wp_) + srcB[(h_)][0] + (k0_), dst_ + ldsoff[0]);                                    \
-        glds16((Wp_) + srcB[(h_)][1] + (k0_), dst_ + ldsoff[1]);                                    \
+        bf16_t* dst_ = smem + ((2 + (h_)) * 2 + (par_)) * V2_HALF_ELEMS;                            \
+        const char* src_ = reinterpret_cast<const char*>(Wp_);                                      \
+        const uint32_t kb_ = (uint32_t)(k0_) * 2u;                                                  \
+        glds16(reinterpret_cast<const bf16_t*>(src_ + (srcB[(h_)][0] + kb_)), dst_ + ldsoff[0]);    \
+        glds16(reinterpret_cast<const bf16_t*>(src_ + (srcB[(h_)][1] + kb_)), dst_ + ldsoff[1]);    \
     }
     // (segment, K offset) of K-tile tt: segment 0 = A.hi W.hi, 1 = A.lo W.hi, 2 = A.hi W.lo
 #define V2_SEGK(tt_, seg_, k0_)              \
@@ -647,10 +671,10 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         V2_SEGK(t0, s0_, k00_);
         const bf16_t* Ap0 = s0_ == 1 ? p.A[1] : p.A[0];
         const bf16_t* Wp0 = s0_ == 2 ? p.W[1] : p.W[0];
-        V2_ISSUE_A(t0, 0, Ap0, k00_);
-        V2_ISSUE_A(t0, 1, Ap0, k00_);
-        V2_ISSUE_B(t0, 0, Wp0, k00_);
-        V2_ISSUE_B(t0, 1, Wp0, k00_);
+        V2_ISSUE_A(0, 0, Ap0, k00_);
+        V2_ISSUE_A(0, 1, Ap0, k00_);
+        V2_ISSUE_B(0, 0, Wp0, k00_);
+        V2_ISSUE_B(0, 1, Wp0, k00_);
         a_seg = s0_;
         a_k0 = k00_ + BK;
         if (a_k0 == p.K) {
@@ -662,8 +686,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     }
     if (t0 + 1 < t1) {
         const bf16_t* Wp1 = b_seg == 2 ? p.W[1] : p.W[0];
-        V2_ISSUE_B(t0 + 1, 0, Wp1, b_k0);
-        V2_ISSUE_B(t0 + 1, 1, Wp1, b_k0);
+        V2_ISSUE_B(1, 0, Wp1, b_k0);
+        V2_ISSUE_B(1, 1, Wp1, b_k0);
         b_k0 += BK;
         if (b_k0 == p.K) {
             b_k0 = 0;
@@ -675,87 +699,68 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     }
     V2_BARRIER();
 
-    // fragment read offsets inside a half tile (elements): row r, chunk c -> r*64 + ((c ^ ((r>>1)&7))<<3)
-    for (int tt = t0; tt < t1; ++tt) {
-        const bf16_t* base = smem + (tt & 1) * 4 * V2_HALF_ELEMS;
-        const bf16_t* sA = base + wm * V2_HALF_ELEMS;                  // this wave's A half (128 rows)
-        const bf16_t* sB = base + (2 + (wn >> 1)) * V2_HALF_ELEMS;     // this wave's B half
-        const int brow0 = (wn & 1) * 64;
-        bf16x8 af[2][4], bfr[2][4];
-
-        // ---- phase 1: A(mq=0), B(nq=0); quadrant (0,0); issue A0(t+1)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(mb * 32 + frow, ks * 2 + fk)]);
-            bfr[0][ks] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(brow0 + frow, ks * 2 + fk)]);
-        }
-        const bf16_t* Apn = a_seg == 1 ? p.A[1] : p.A[0];
-        const bf16_t* Wpn = b_seg == 2 ? p.W[1] : p.W[0];
-        if (tt + 1 < t1) V2_ISSUE_A(tt + 1, 0, Apn, a_k0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-                acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[0][ks], acc[mb][0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-
-        // ---- phase 2: B(nq=1); quadrant (0,1); issue A1(t+1)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) bfr[1][ks] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(brow0 + 32 + frow, ks * 2 + fk)]);
-        if (tt + 1 < t1) V2_ISSUE_A(tt + 1, 1, Apn, a_k0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-                acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[1][ks], acc[mb][1], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        V2_BARRIER();   // every wave has finished reading the B halves of this tile
-
-        // ---- phase 3: A(mq=1); quadrant (1,1); issue B0(t+2)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) af[mb][ks] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(64 + mb * 32 + frow, ks * 2 + fk)]);
-        if (tt + 2 < t1) V2_ISSUE_B(tt + 2, 0, Wpn, b_k0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-                acc[2 + mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[1][ks], acc[2 + mb][1], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        V2_BARRIER();   // every wave has finished reading the A halves of this tile
-
-        // ---- phase 4: quadrant (1,0) from registers; issue B1(t+2)
-        if (tt + 2 < t1) V2_ISSUE_B(tt + 2, 1, Wpn, b_k0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-                acc[2 + mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[0][ks], acc[2 + mb][0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        // next tile's operands: everything but the two B halves just issued for tile t+2 must have landed
-        if (tt + 2 < t1) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        V2_BARRIER();
-        a_k0 += BK;
-        if (a_k0 == p.K) {
-            a_k0 = 0;
-            ++a_seg;
-        }
-        b_k0 += BK;
-        if (b_k0 == p.K) {
-            b_k0 = 0;
-            ++b_seg;
-        }
+    // one K tile out of ring buffer PAR (compile-time): 4 phases of 8 MFMAs, each issuing one half tile of a later K tile
+    bf16x8 af[2][4], bfr[2][4];
+#define V2_FRAG_A(PAR, ks, rowoff) (*reinterpret_cast<const bf16x8*>(pa[ks] + (PAR) * V2_HALF_ELEMS + (rowoff) * BK))
+#define V2_FRAG_B(PAR, ks, rowoff) (*reinterpret_cast<const bf16x8*>(pb[ks] + (PAR) * V2_HALF_ELEMS + (rowoff) * BK))
+#define V2_KSTEP(PAR, tt)                                                                                               \
+    {                                                                                                                   \
+        /* phase 1: A(mq=0), B(nq=0); quadrant (0,0); issue A0(t+1) */                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
+            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) af[mb][ks] = V2_FRAG_A(PAR, ks, mb * 32);                  \
+            bfr[0][ks] = V2_FRAG_B(PAR, ks, 0);                                                                         \
+        }                                                                                                               \
+        const bf16_t* Apn = a_seg == 1 ? p.A[1] : p.A[0];                                                               \
+        const bf16_t* Wpn = b_seg == 2 ? p.W[1] : p.W[0];                                                               \
+        if ((tt) + 1 < t1) V2_ISSUE_A(1 - PAR, 0, Apn, a_k0);                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
+            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
+                acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[0][ks], acc[mb][0], 0, 0, 0);      \
+        /* phase 2: B(nq=1); quadrant (0,1); issue A1(t+1) */                                                           \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) bfr[1][ks] = V2_FRAG_B(PAR, ks, 32);                           \
+        if ((tt) + 1 < t1) V2_ISSUE_A(1 - PAR, 1, Apn, a_k0);                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
+            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
+                acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[1][ks], acc[mb][1], 0, 0, 0);      \
+        V2_BARRIER(); /* every wave has finished reading the B halves of this tile */                                   \
+        /* phase 3: A(mq=1); quadrant (1,1); issue B0(t+2) */                                                           \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
+            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) af[mb][ks] = V2_FRAG_A(PAR, ks, 64 + mb * 32);             \
+        if ((tt) + 2 < t1) V2_ISSUE_B(PAR, 0, Wpn, b_k0);                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
+            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
+                acc[2 + mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[1][ks], acc[2 + mb][1], 0, 0, 0); \
+        V2_BARRIER(); /* every wave has finished reading the A halves of this tile */                                   \
+        /* phase 4: quadrant (1,0) from registers; issue B1(t+2) */                                                     \
+        if ((tt) + 2 < t1) V2_ISSUE_B(PAR, 1, Wpn, b_k0);                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
+            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
+                acc[2 + mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[0][ks], acc[2 + mb][0], 0, 0, 0); \
+        /* next tile's operands: everything but the two B halves just issued for tile t+2 must have landed */           \
+        if ((tt) + 2 < t1) {                                                                             \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                            \
+        } else {                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+        }                                                                                                               \
+        V2_BARRIER();                                                                                                   \
+        a_k0 += BK;                                                                                                     \
+        if (a_k0 == p.K) {                                                                                              \
+            a_k0 = 0;                                                                                                   \
+            ++a_seg;                                                                                                    \
+        }                                                                                                               \
+        b_k0 += BK;                                                                                                     \
+        if (b_k0 == p.K) {                                                                                              \
+            b_k0 = 0;                                                                                                   \
+            ++b_seg;                                                                                                    \
+        }                                                                                                               \
     }
+    for (int tt = t0; tt < t1; tt += 2) {
+        V2_KSTEP(0, tt);
+        if (tt + 1 < t1) V2_KSTEP(1, tt + 1);
+    }
+#undef V2_KSTEP
+#undef V2_FRAG_A
+#undef V2_FRAG_B
 
     // Partial tiles cross XCDs, whose L2s are not coherent.  No agent-scope fences here: a release fence writes back and an
     // acquire fence invalidates the WHOLE L2 of the XCD (measured: the operand panels of all 32 CUs get refetched and the
@@ -850,6 +855,8 @@ int f5_gemm_streamk_error() {      // 1 if a consumer ever timed out waiting for
 }
 template <int EPI>
 static int launch_v2(const F5GemmArgs& a, hipStream_t stream) {
+    F5_REQUIRE((size_t)(a.a_row_mod > 0 ? a.a_row_mod : a.M) * a.lda < (1ull << 31) && (size_t)(a.N + 256) * a.ldw < (1ull << 31),
+               "gemm: operands of the 256x256 kernel must stay below 4 GiB (32-bit byte offsets)");
     const int tiles_m = f5_cdiv(a.M, 256), tiles_n = a.N / 256;
     const int ntiles = tiles_m * tiles_n;
     if (f5_gemm_streamk && g_sk_part && ntiles >= g_sk_P) {
@@ -1357,13 +1364,13 @@ __global__ __launch_bounds__(512) void f5_gemm256f8_kernel(F5GemmArgs p, int til
 
 #define F8_ISSUE_A(tt_, h_)                                                                         \
     {                                                                                               \
-        uint8_t* dst_ = smem + (((tt_) & 1) * 4 + (h_)) * HALF;                                     \
+        uint8_t* dst_ = smem + ((h_) * 2 + ((tt_) & 1)) * HALF;                                     \
         glds16b(p.A8 + (srcA[(h_)][0] + (uint32_t)(tt_) * 128u), dst_ + ldsoff[0]);                 \
         glds16b(p.A8 + (srcA[(h_)][1] + (uint32_t)(tt_) * 128u), dst_ + ldsoff[1]);                 \
     }
 #define F8_ISSUE_B(tt_, h_)                                                                         \
     {                                                                                               \
-        uint8_t* dst_ = smem + (((tt_) & 1) * 4 + 2 + (h_)) * HALF;                                 \
+        uint8_t* dst_ = smem + ((2 + (h_)) * 2 + ((tt_) & 1)) * HALF;                               \
         glds16b(p.W8 + (srcB[(h_)][0] + (uint32_t)(tt_) * 128u), dst_ + ldsoff[0]);                 \
         glds16b(p.W8 + (srcB[(h_)][1] + (uint32_t)(tt_) * 128u), dst_ + ldsoff[1]);                 \
     }
@@ -1400,90 +1407,78 @@ __global__ __launch_bounds__(512) void f5_gemm256f8_kernel(F5GemmArgs p, int til
 
     const int frow = lane & 31;
     const int fk = lane >> 5;
-    for (int tt = 0; tt < T; ++tt) {
-        const uint8_t* base = smem + (tt & 1) * 4 * HALF;
-        const uint8_t* sA = base + wm * HALF;                      // this wave's A half (128 rows)
-        const uint8_t* sB = base + (2 + (wn >> 1)) * HALF;         // this wave's B half
-        const uint32_t* scA = reinterpret_cast<const uint32_t*>(sscale + (tt & 1) * 2048) + wm * 128;
-        const uint32_t* scB = reinterpret_cast<const uint32_t*>(sscale + (tt & 1) * 2048) + 256 + (wn >> 1) * 128;
-        const int brow0 = (wn & 1) * 64;
-        i32x8 af[2][2], bfr[2][2];
-        int sa[2], sb[2];       // scale dword of the row, shifted so that byte 0 / byte 2 = this lane's K block of sub-tile 0 / 1
-
-        // ---- phase 1: A(mq=0), B(nq=0); quadrant (0,0); issue A0(t+1) + scales(t+1)
+    // fragment / scale read pointers per (ring buffer, K sub-tile, chunk): row-block and quadrant offsets are immediates, so the
+    // loop issues no VALU instruction for LDS addressing (nothing co-issues with an MFMA on this chip: tools/probes/coissue.hip)
+    const int brow0 = (wn & 1) * 64;
+    // LDS layout [A0,A1,B0,B1][ring buffer][128 x 128 B]: the ring-buffer offset (16 KB) also fits the ds_read offset field
+    const uint8_t* qa[2][2];
+    const uint8_t* qb[2][2];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            sa[mb] = (int)(scA[mb * 32 + frow] >> (8 * fk));
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[mb][ks] = f8_frag(sA, mb * 32 + frow, ks, fk);
+        for (int w2 = 0; w2 < 2; ++w2) {
+            qa[ks][w2] = smem + (wm * 2) * HALF + f8_off(frow, 4 * ks + 2 * w2 + fk);
+            qb[ks][w2] = smem + ((2 + (wn >> 1)) * 2) * HALF + f8_off(brow0 + frow, 4 * ks + 2 * w2 + fk);
         }
-        {
-            sb[0] = (int)(scB[brow0 + frow] >> (8 * fk));
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bfr[0][ks] = f8_frag(sB, brow0 + frow, ks, fk);
-        }
-        if (tt + 1 < T) {
-            F8_ISSUE_A(tt + 1, 0);
-            F8_ISSUE_S(tt + 1);                          // slot of tile t-1: last read before the previous end-of-tile barrier
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                acc[mb][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[mb][0], bfr[0][0], acc[mb][0], 0, 0, 0, sa[mb], 0, sb[0]);
-                acc[mb][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[mb][1], bfr[0][1], acc[mb][0], 0, 0, 2, sa[mb], 2, sb[0]);
-            }
-        __builtin_amdgcn_s_setprio(0);
-
-        // ---- phase 2: B(nq=1); quadrant (0,1); issue A1(t+1)
-        {
-            sb[1] = (int)(scB[brow0 + 32 + frow] >> (8 * fk));
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bfr[1][ks] = f8_frag(sB, brow0 + 32 + frow, ks, fk);
-        }
-        if (tt + 1 < T) F8_ISSUE_A(tt + 1, 1);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                acc[mb][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[mb][0], bfr[1][0], acc[mb][1], 0, 0, 0, sa[mb], 0, sb[1]);
-                acc[mb][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[mb][1], bfr[1][1], acc[mb][1], 0, 0, 2, sa[mb], 2, sb[1]);
-            }
-        __builtin_amdgcn_s_setprio(0);
-        F8_BARRIER();   // every wave has finished reading the B halves of this tile
-
-        // ---- phase 3: A(mq=1); quadrant (1,1); issue B0(t+2)
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            sa[mb] = (int)(scA[64 + mb * 32 + frow] >> (8 * fk));
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) af[mb][ks] = f8_frag(sA, 64 + mb * 32 + frow, ks, fk);
-        }
-        if (tt + 2 < T) F8_ISSUE_B(tt + 2, 0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                acc[2 + mb][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[mb][0], bfr[1][0], acc[2 + mb][1], 0, 0, 0, sa[mb], 0, sb[1]);
-                acc[2 + mb][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[mb][1], bfr[1][1], acc[2 + mb][1], 0, 0, 2, sa[mb], 2, sb[1]);
-            }
-        __builtin_amdgcn_s_setprio(0);
-        F8_BARRIER();   // every wave has finished reading the A halves (and the scales) of this tile
-
-        // ---- phase 4: quadrant (1,0) from registers; issue B1(t+2)
-        if (tt + 2 < T) F8_ISSUE_B(tt + 2, 1);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                acc[2 + mb][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[mb][0], bfr[0][0], acc[2 + mb][0], 0, 0, 0, sa[mb], 0, sb[0]);
-                acc[2 + mb][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[mb][1], bfr[0][1], acc[2 + mb][0], 0, 0, 2, sa[mb], 2, sb[0]);
-            }
-        __builtin_amdgcn_s_setprio(0);
-        // next tile's operands and scales: everything but the two B halves issued for tile t+2 must have landed
-        if (tt + 2 < T) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        F8_BARRIER();
+    const uint32_t* sca = reinterpret_cast<const uint32_t*>(sscale) + wm * 128 + frow;
+    const uint32_t* scb = reinterpret_cast<const uint32_t*>(sscale) + 256 + (wn >> 1) * 128 + brow0 + frow;
+    i32x8 af[2][2], bfr[2][2];
+    int sa[2], sb[2];       // scale dword of the row, shifted so that byte 0 / byte 2 = this lane's K block of sub-tile 0 / 1
+#define F8_FRAG(Q, PAR, ks, rowoff)                                                                            \
+    ([&]() {                                                                                                   \
+        const u32x4 lo_ = *reinterpret_cast<const u32x4*>(Q[ks][0] + (PAR) * HALF + (rowoff) * 128);            \
+        const u32x4 hi_ = *reinterpret_cast<const u32x4*>(Q[ks][1] + (PAR) * HALF + (rowoff) * 128);            \
+        return i32x8{(int)lo_[0], (int)lo_[1], (int)lo_[2], (int)lo_[3], (int)hi_[0], (int)hi_[1], (int)hi_[2], (int)hi_[3]}; \
+    }())
+#define F8_MFMA2(ACC, AF, BF, SA, SB)                                                                          \
+    ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(AF[0], BF[0], ACC, 0, 0, 0, SA, 0, SB);              \
+    ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(AF[1], BF[1], ACC, 0, 0, 2, SA, 2, SB);
+#define F8_KSTEP(PAR, tt)                                                                                      \
+    {                                                                                                          \
+        /* phase 1: A(mq=0), B(nq=0); quadrant (0,0); issue A0(t+1) + scales(t+1) */                           \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) {                                                     \
+            sa[mb] = (int)(sca[(PAR) * 512 + mb * 32] >> (8 * fk));                                                     \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) af[mb][ks] = F8_FRAG(qa, PAR, ks, mb * 32);       \
+        }                                                                                                      \
+        sb[0] = (int)(scb[(PAR) * 512] >> (8 * fk));                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) bfr[0][ks] = F8_FRAG(qb, PAR, ks, 0);                 \
+        if ((tt) + 1 < T) {                                                                                    \
+            F8_ISSUE_A((tt) + 1, 0);                                                                           \
+            F8_ISSUE_S((tt) + 1);                                                                              \
+        }                                                                                                      \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) { F8_MFMA2(acc[mb][0], af[mb], bfr[0], sa[mb], sb[0]) } \
+        /* phase 2: B(nq=1); quadrant (0,1); issue A1(t+1) */                                                  \
+        sb[1] = (int)(scb[(PAR) * 512 + 32] >> (8 * fk));                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) bfr[1][ks] = F8_FRAG(qb, PAR, ks, 32);                \
+        if ((tt) + 1 < T) F8_ISSUE_A((tt) + 1, 1);                                                             \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) { F8_MFMA2(acc[mb][1], af[mb], bfr[1], sa[mb], sb[1]) } \
+        F8_BARRIER(); /* every wave has finished reading the B halves of this tile */                          \
+        /* phase 3: A(mq=1); quadrant (1,1); issue B0(t+2) */                                                  \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) {                                                     \
+            sa[mb] = (int)(sca[(PAR) * 512 + 64 + mb * 32] >> (8 * fk));                                                \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) af[mb][ks] = F8_FRAG(qa, PAR, ks, 64 + mb * 32);  \
+        }                                                                                                      \
+        if ((tt) + 2 < T) F8_ISSUE_B((tt) + 2, 0);                                                             \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) { F8_MFMA2(acc[2 + mb][1], af[mb], bfr[1], sa[mb], sb[1]) } \
+        F8_BARRIER(); /* every wave has finished reading the A halves (and the scales) of this tile */         \
+        /* phase 4: quadrant (1,0) from registers; issue B1(t+2) */                                            \
+        if ((tt) + 2 < T) F8_ISSUE_B((tt) + 2, 1);                                                             \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) { F8_MFMA2(acc[2 + mb][0], af[mb], bfr[0], sa[mb], sb[0]) } \
+        /* next tile's operands and scales: everything but the two B halves issued for tile t+2 must have landed */ \
+        if ((tt) + 2 < T) {                                                                                    \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                   \
+        } else {                                                                                               \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        }                                                                                                      \
+        F8_BARRIER();                                                                                          \
     }
+    for (int tt = 0; tt < T; tt += 2) {
+        F8_KSTEP(0, tt);
+        if (tt + 1 < T) F8_KSTEP(1, tt + 1);
+    }
+#undef F8_KSTEP
+#undef F8_MFMA2
+#undef F8_FRAG
 #undef F8_ISSUE_A
 #undef F8_ISSUE_B
 #undef F8_ISSUE_S

@@ -15,6 +15,8 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int iters, float seed, i
     for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(seed + e); b[e] = (__bf16)(seed * e); }
     float v[8];
     for (int e = 0; e < 8; ++e) v[e] = seed + e + threadIdx.x;
+    __shared__ unsigned int lds[16384];
+    for (int i = threadIdx.x; i < 16384; i += 512) lds[i] = i * 2654435761u;
     __syncthreads();
     const uint64_t c0 = clock64();
     if (mode == 1) {
@@ -33,6 +35,18 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int iters, float seed, i
 #pragma unroll
             for (int i = 0; i < 8; ++i) c4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c4[i], 0, 0, 0);
         for (int i = 0; i < 8; ++i) v[i] += c4[i][0];
+    } else if (mode == 6) {          // ds_read_b128 stream (conflict-free, 16 B per lane), results folded into v[]
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* src = reinterpret_cast<const u32x4*>(lds) + (threadIdx.x & 63);
+        unsigned int fold = 0;
+        for (int it = 0; it < iters * 2; ++it) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const u32x4 t = src[e * 64 + (it & 1) * 512];
+                fold ^= t[0] ^ t[3];
+            }
+        }
+        v[0] += (float)fold;
     } else if (mode == 2) {
         for (int it = 0; it < iters * 6; ++it)
 #pragma unroll
@@ -70,6 +84,8 @@ int main() {
     run("MFMA(AGPR acc) + v_exp on the same SIMDs", 4, 3);
     run("MFMA 16x16x32 alone (2x count)", 5, 0);
     run("MFMA 16x16x32 + v_fma", 5, 2);
+    run("ds_read_b128 alone (on waves 4-7)", 0, 6);
+    run("MFMA + ds_read_b128 on the same SIMDs", 1, 6);
     run("MFMA + MFMA", 1, 1);
     run("v_fma + v_fma", 2, 2);
     return 0;
