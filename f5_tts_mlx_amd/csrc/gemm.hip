@@ -710,8 +710,6 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) af[mb][ks] = V2_FRAG_A(PAR, ks, mb * 32);                  \
             bfr[0][ks] = V2_FRAG_B(PAR, ks, 0);                                                                         \
         }                                                                                                               \
-        const bf16_t* Apn = a_seg == 1 ? p.A[1] : p.A[0];                                                               \
-        const bf16_t* Wpn = b_seg == 2 ? p.W[1] : p.W[0];                                                               \
         if ((tt) + 1 < t1) V2_ISSUE_A(1 - PAR, 0, Apn, a_k0);                                            \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
@@ -747,13 +745,17 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         if (a_k0 == p.K) {                                                                                              \
             a_k0 = 0;                                                                                                   \
             ++a_seg;                                                                                                    \
+            Apn = a_seg == 1 ? p.A[1] : p.A[0];                                                                         \
         }                                                                                                               \
         b_k0 += BK;                                                                                                     \
         if (b_k0 == p.K) {                                                                                              \
             b_k0 = 0;                                                                                                   \
             ++b_seg;                                                                                                    \
+            Wpn = b_seg == 2 ? p.W[1] : p.W[0];                                                                         \
         }                                                                                                               \
     }
+    const bf16_t* Apn = a_seg == 1 ? p.A[1] : p.A[0];   // operand (bf16x3 segment) pointers of the tiles being staged
+    const bf16_t* Wpn = b_seg == 2 ? p.W[1] : p.W[0];
     for (int tt = t0; tt < t1; tt += 2) {
         V2_KSTEP(0, tt);
         if (tt + 1 < t1) V2_KSTEP(1, tt + 1);

@@ -35,6 +35,13 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int iters, float seed, i
 #pragma unroll
             for (int i = 0; i < 8; ++i) c4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c4[i], 0, 0, 0);
         for (int i = 0; i < 8; ++i) v[i] += c4[i][0];
+    } else if (mode == 7) {          // scalar ALU stream
+        int sacc = __builtin_amdgcn_readfirstlane(iters + 3);
+        for (int it = 0; it < iters * 4; ++it) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("s_mul_i32 %0, %0, 1664525\n\ts_add_i32 %0, %0, 1013904223" : "+s"(sacc));
+        }
+        if (sacc == 12345) v[0] += 1.0f;
     } else if (mode == 6) {          // ds_read_b128 stream (conflict-free, 16 B per lane), results folded into v[]
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const u32x4* src = reinterpret_cast<const u32x4*>(lds) + (threadIdx.x & 63);
@@ -84,6 +91,8 @@ int main() {
     run("MFMA(AGPR acc) + v_exp on the same SIMDs", 4, 3);
     run("MFMA 16x16x32 alone (2x count)", 5, 0);
     run("MFMA 16x16x32 + v_fma", 5, 2);
+    run("SALU alone (on waves 4-7)", 0, 7);
+    run("MFMA + SALU on the same SIMDs", 1, 7);
     run("ds_read_b128 alone (on waves 4-7)", 0, 6);
     run("MFMA + ds_read_b128 on the same SIMDs", 1, 6);
     run("MFMA + MFMA", 1, 1);
