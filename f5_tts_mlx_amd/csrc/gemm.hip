@@ -924,7 +924,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     const int wm = wave / WN, wn = wave % WN;
     bf16_t* smem = smem_all + grp * RING;
 
-    size_t a_src[NA], w_src[NW];
+    // staging: 32-bit BYTE offsets added to a uniform operand pointer (SGPR base + VGPR offset form of global_load_lds)
+    uint32_t a_src[NA], w_src[NW];
     int a_dst[NA], w_dst[NW];                           // wave-uniform LDS element offsets inside a stage
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -933,31 +934,41 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
         int gr = m0 + row;
         if (gr > p.M - 1) gr = p.M - 1;
         if (p.a_row_mod > 0) gr = gr % p.a_row_mod;
-        a_src[i] = (size_t)gr * p.lda + chunk * 8;
+        a_src[i] = ((uint32_t)gr * (uint32_t)p.lda + chunk * 8) * 2u;
         a_dst[i] = (i * NTG + wave * 64) * 8;
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int q_ = i * NTG + tg;
         const int row = q_ >> 3, chunk = (q_ & 7) ^ ((row >> 1) & 7);
-        w_src[i] = (size_t)(n0 + row) * p.ldw + chunk * 8;
+        w_src[i] = ((uint32_t)(n0 + row) * (uint32_t)p.ldw + chunk * 8) * 2u;
         w_dst[i] = BMt * BK + (i * NTG + wave * 64) * 8;
     }
     const int kt = p.K / BK;
     const int T = kt * p.nseg;
     const int Tg = T > grp ? (T - grp + KS - 1) / KS : 0;    // K tiles of this group
     const int nit = (T + KS - 1) / KS;                       // iterations (= tiles of group 0)
-    // jj_ = group-local tile number; the global K tile is jj_*KS + grp
-#define RING_ISSUE(jj_)                                                                                      \
+    // the group's K tiles are staged in order: running (segment, K offset) of the next tile to issue (global tile jj*KS + grp)
+    int is_seg = 0, is_k0 = grp * BK;
+    while (is_k0 >= p.K) {
+        is_k0 -= p.K;
+        ++is_seg;
+    }
+#define RING_ISSUE(ST_)                                                                                      \
     {                                                                                                        \
-        const int tt_ = (jj_) * KS + grp;                                                                    \
-        const int seg_ = tt_ / kt;                                                                           \
-        const int k0_ = (tt_ - seg_ * kt) * BK;                                                              \
-        bf16_t* st_ = smem + ((jj_) % NST) * STAGE;                                                          \
-        const bf16_t* Ap_ = (seg_ == 1) ? p.A[1] : p.A[0];                                                   \
-        const bf16_t* Wp_ = (seg_ == 2) ? p.W[1] : p.W[0];                                                   \
-        _Pragma("unroll") for (int i = 0; i < NA; ++i) glds16(Ap_ + a_src[i] + k0_, st_ + a_dst[i]);         \
-        _Pragma("unroll") for (int i = 0; i < NW; ++i) glds16(Wp_ + w_src[i] + k0_, st_ + w_dst[i]);         \
+        bf16_t* st_ = smem + (ST_) * STAGE;                                                                  \
+        const char* Ap_ = reinterpret_cast<const char*>((is_seg == 1) ? p.A[1] : p.A[0]);                    \
+        const char* Wp_ = reinterpret_cast<const char*>((is_seg == 2) ? p.W[1] : p.W[0]);                    \
+        const uint32_t kb_ = (uint32_t)is_k0 * 2u;                                                           \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                       \
+            glds16(reinterpret_cast<const bf16_t*>(Ap_ + (a_src[i] + kb_)), st_ + a_dst[i]);                 \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                       \
+            glds16(reinterpret_cast<const bf16_t*>(Wp_ + (w_src[i] + kb_)), st_ + w_dst[i]);                 \
+        is_k0 += KS * BK;                                                                                    \
+        while (is_k0 >= p.K) {                   /* at most once unless K < KS * 64 */                       \
+            is_k0 -= p.K;                                                                                    \
+            ++is_seg;                                                                                        \
+        }                                                                                                    \
     }
 
     f32x16 acc[MB][NB];
@@ -974,39 +985,56 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
 
     const int frow = lane & 31;
     const int fk = lane >> 5;
-    for (int jj = 0; jj < nit; ++jj) {
-        // tile jj must have landed; up to NST-2 younger tiles may stay in flight (conservative vmcnt(0) at the tail)
-        if (jj + NST - 2 < Tg) {
-            if (NST == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-            else if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (jj + NST - 1 < Tg) RING_ISSUE(jj + NST - 1);   // refills the slot consumed in iteration jj-1
-        if (KS > 1 && jj >= Tg) continue;                  // wave-uniform: no tile left for this group (barrier still met)
-
-        const bf16_t* sA = smem + (jj % NST) * STAGE;
-        const bf16_t* sB = sA + BMt * BK;
+    // fragment read pointers per K sub-step (and per 64 KB window of the ring): stage, row block and A / W part are ds_read
+    // immediates, the K loop is unrolled NST times so the stage is a constant (every non-MFMA instruction of the loop is paid
+    // in full on this chip: tools/probes/coissue.hip)
+    constexpr int SPS = 65536 / (STAGE * 2) < NST ? 65536 / (STAGE * 2) : NST;   // stages per 64 KB window (16-bit ds_read offsets)
+    static_assert(SPS >= 1, "a stage must fit the ds_read offset field");
+    constexpr int NSET = (NST + SPS - 1) / SPS;                      // windows = pointer sets
+    const bf16_t* pa[NSET][4];
+    const bf16_t* pb[NSET][4];
+#pragma unroll
+    for (int w2 = 0; w2 < NSET; ++w2)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[MB], bfr[NB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-                af[mb] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(wm * (32 * MB) + mb * 32 + frow, ks * 2 + fk)]);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                bfr[nb] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(wn * (32 * NB) + nb * 32 + frow, ks * 2 + fk)]);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+            pa[w2][ks] = smem + w2 * SPS * STAGE + swz_off(wm * (32 * MB) + frow, ks * 2 + fk);
+            pb[w2][ks] = smem + w2 * SPS * STAGE + BMt * BK + swz_off(wn * (32 * NB) + frow, ks * 2 + fk);
         }
+#define RING_STEP(ST_, jj_)                                                                                         \
+    {                                                                                                               \
+        /* tile jj must have landed; up to NST-2 younger tiles may stay in flight (conservative vmcnt(0) at the tail) */ \
+        if ((jj_) + NST - 2 < Tg) {                                                                                 \
+            if (NST == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");                              \
+            else if (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");                             \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        } else {                                                                                                    \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+        }                                                                                                           \
+        asm volatile("" ::: "memory");                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        asm volatile("" ::: "memory");                                                                              \
+        if ((jj_) + NST - 1 < Tg) RING_ISSUE(((ST_) + NST - 1) % NST); /* refills the slot consumed one iteration ago */ \
+        if (!(KS > 1 && (jj_) >= Tg)) {              /* wave-uniform: a group without a tile left still meets the barrier */ \
+            constexpr int W2 = (ST_) / SPS, SL = (ST_) % SPS;                                                        \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                      \
+                bf16x8 af[MB], bfr[NB];                                                                             \
+                _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                   \
+                    af[mb] = *reinterpret_cast<const bf16x8*>(pa[W2][ks] + SL * STAGE + mb * 32 * BK);              \
+                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                   \
+                    bfr[nb] = *reinterpret_cast<const bf16x8*>(pb[W2][ks] + SL * STAGE + nb * 32 * BK);             \
+                _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                   \
+                    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                               \
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0); \
+            }                                                                                                       \
+        }                                                                                                           \
     }
+    for (int jj = 0; jj < nit; jj += NST) {
+        RING_STEP(0, jj);
+        if (NST > 1 && jj + 1 < nit) RING_STEP(1 % NST, jj + 1);
+        if (NST > 2 && jj + 2 < nit) RING_STEP(2 % NST, jj + 2);
+        if (NST > 3 && jj + 3 < nit) RING_STEP(3 % NST, jj + 3);
+    }
+#undef RING_STEP
 #undef RING_ISSUE
     constexpr int STG = small_tile_staged<EPI, NB>() ? WM * WN * small_tile_stage_elems<NB>() : 0;   // staging area (bf16 elements)
     if (KS > 1) {
@@ -1612,6 +1640,8 @@ int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
     F5_REQUIRE(a.A[0] && a.W[0], "gemm: null operand");
     F5_REQUIRE(a.nseg == 1 || (a.A[1] && a.W[1]), "gemm: bf16x3 needs lo operands");
     F5_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: leading dims must be multiples of 8");
+    F5_REQUIRE((size_t)(a.a_row_mod > 0 ? a.a_row_mod : a.M) * a.lda < (1ull << 31) && (size_t)(a.N + 256) * a.ldw < (1ull << 31),
+               "gemm: operands must stay below 4 GiB (the kernels use 32-bit byte offsets)");
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(a, stream);
         case EPI_BF16: return launch_epi<EPI_BF16>(a, stream);
