@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    size_t a_off[NA], w_off[NW];
+    // 32-bit BYTE offsets added to a uniform operand pointer (SGPR base + VGPR offset loads)
+    uint32_t a_off[NA], w_off[NW];
     int sa_off[NA], sw_off[NW];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -203,29 +204,34 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
         int gr = m0 + srow;
         if (gr > p.M - 1) gr = p.M - 1;
         if (p.a_row_mod > 0) gr = gr % p.a_row_mod;
-        a_off[i] = (size_t)gr * p.lda + schunk * 8;
+        a_off[i] = ((uint32_t)gr * (uint32_t)p.lda + schunk * 8) * 2u;
         sa_off[i] = swz_off(srow, schunk);
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int qd = tid + 256 * i;
         const int srow = qd >> 3, schunk = qd & 7;
-        w_off[i] = (size_t)(n0 + srow) * p.ldw + schunk * 8;
+        w_off[i] = ((uint32_t)(n0 + srow) * (uint32_t)p.ldw + schunk * 8) * 2u;
         sw_off[i] = BMt * BK + swz_off(srow, schunk);
     }
 
-    const int kt = p.K / BK;
-    const int T = kt * p.nseg;
+    const int T = (p.K / BK) * p.nseg;
 
+    // tiles are loaded in order: running (segment, K offset) of the next tile to load
+    int ld_seg = 0, ld_k0 = 0;
     u32x4 ra[NA], rb[NW];
-#define LOAD_TILE(tt_)                                                                                        \
+#define LOAD_TILE()                                                                                           \
     {                                                                                                         \
-        const int seg_ = (tt_) / kt;                                                                          \
-        const int k0_ = ((tt_) - seg_ * kt) * BK;                                                             \
-        const bf16_t* Ap_ = (seg_ == 1) ? p.A[1] : p.A[0];                                                    \
-        const bf16_t* Wp_ = (seg_ == 2) ? p.W[1] : p.W[0];                                                    \
-        _Pragma("unroll") for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(Ap_ + a_off[i] + k0_); \
-        _Pragma("unroll") for (int i = 0; i < NW; ++i) rb[i] = *reinterpret_cast<const u32x4*>(Wp_ + w_off[i] + k0_); \
+        const char* Ap_ = reinterpret_cast<const char*>((ld_seg == 1) ? p.A[1] : p.A[0]);                     \
+        const char* Wp_ = reinterpret_cast<const char*>((ld_seg == 2) ? p.W[1] : p.W[0]);                     \
+        const uint32_t kb_ = (uint32_t)ld_k0 * 2u;                                                            \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(Ap_ + (a_off[i] + kb_)); \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i) rb[i] = *reinterpret_cast<const u32x4*>(Wp_ + (w_off[i] + kb_)); \
+        ld_k0 += BK;                                                                                          \
+        if (ld_k0 == p.K) {                                                                                   \
+            ld_k0 = 0;                                                                                        \
+            ++ld_seg;                                                                                         \
+        }                                                                                                     \
     }
 #define STORE_TILE(buf_)                                                                                      \
     {                                                                                                         \
@@ -241,35 +247,44 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    LOAD_TILE(0);
+    LOAD_TILE();
     STORE_TILE(0);
     __syncthreads();
 
     const int frow = lane & 31;
     const int fk = lane >> 5;
-    for (int tt = 0; tt < T; ++tt) {
-        const int cur = tt & 1;
-        if (tt + 1 < T) LOAD_TILE(tt + 1);
-        const bf16_t* sA = smem[cur];
-        const bf16_t* sB = smem[cur] + BMt * BK;
+    // fragment read pointers per K sub-step; buffer, row block and A / W part are ds_read immediates (K loop unrolled 2x)
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[MB], bfr[NB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-                af[mb] = *reinterpret_cast<const bf16x8*>(&sA[swz_off(wm * (32 * MB) + mb * 32 + frow, ks * 2 + fk)]);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                bfr[nb] = *reinterpret_cast<const bf16x8*>(&sB[swz_off(wn * (32 * NB) + nb * 32 + frow, ks * 2 + fk)]);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
-        }
-        if (tt + 1 < T) STORE_TILE(cur ^ 1);
-        __syncthreads();
+    for (int ks = 0; ks < 4; ++ks) {
+        pa[ks] = &smem[0][0] + swz_off(wm * (32 * MB) + frow, ks * 2 + fk);
+        pb[ks] = &smem[0][0] + BMt * BK + swz_off(wn * (32 * NB) + frow, ks * 2 + fk);
     }
+    static_assert(2 * (BMt + BNt) * BK * 2 <= 65536, "both buffers must be addressable by ds_read immediates");
+#define REG_STEP(CUR, tt_)                                                                                    \
+    {                                                                                                         \
+        if ((tt_) + 1 < T) LOAD_TILE();                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
+            bf16x8 af[MB], bfr[NB];                                                                           \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                 \
+                af[mb] = *reinterpret_cast<const bf16x8*>(pa[ks] + (CUR) * (BMt + BNt) * BK + mb * 32 * BK);  \
+            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                 \
+                bfr[nb] = *reinterpret_cast<const bf16x8*>(pb[ks] + (CUR) * (BMt + BNt) * BK + nb * 32 * BK); \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                 \
+                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                             \
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0); \
+        }                                                                                                     \
+        if ((tt_) + 1 < T) STORE_TILE(1 - (CUR));                                                             \
+        __syncthreads();                                                                                      \
+    }
+    for (int tt = 0; tt < T; tt += 2) {
+        REG_STEP(0, tt);
+        if (tt + 1 < T) REG_STEP(1, tt + 1);
+    }
+#undef REG_STEP
+#undef LOAD_TILE
+#undef STORE_TILE
 
     if (small_tile_staged<EPI, NB>() && n0 + BNt <= p.N && (p.debug_flags & 2) == 0) {
         static_assert(!small_tile_staged<EPI, NB>() || 4 * small_tile_stage_elems<NB>() <= 2 * (BMt + BNt) * BK, "staging fits");
