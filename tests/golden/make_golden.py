@@ -31,7 +31,28 @@ def main():
     audio = (a.astype(np.float64) / 32768.0).astype(np.float32)
     mel = O.log_mel_spectrogram(audio, dtype=np.float64)[0].astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "fixture_mel.npz"), mel=mel)
-    print("wrote golden fixtures", out.shape, mel.shape)
+    # flow-matching loss forward (cfm.py:169-251) with every random draw recorded
+    g = torch.Generator().manual_seed(77)
+    B, N = 2, 64
+    mel_in = torch.randn((B, N, cfg.mel_dim), generator=g)
+    rand = dict(x0=torch.randn((B, N, cfg.mel_dim), generator=g), time=torch.tensor([0.21, 0.83]),
+                frac_lengths=torch.tensor([0.75, 0.9]), span_rand=torch.tensor([0.35, 0.6]))
+    ltext = torch.randint(0, cfg.text_num_embeds, (B, 16), generator=g, dtype=torch.int32)
+    lens = torch.tensor([64, 51], dtype=torch.int32)
+    losses = {}
+    for name, (ra, rc) in dict(keep=(0.9, 0.9), drop_audio=(0.1, 0.9), drop_both=(0.9, 0.1)).items():
+        losses[name] = float(O.cfm_loss(O.DiTOracle(cfg, w, dtype=torch.float64), mel_in, ltext, lens=lens, rand_audio_drop=ra,
+                                        rand_cond_drop=rc, **rand))
+    np.savez_compressed(os.path.join(HERE, "tiny_cfm_loss.npz"), weights_seed=42, mel=mel_in.numpy(), text=ltext.numpy(), lens=lens.numpy(),
+                        x0=rand["x0"].numpy(), time=rand["time"].numpy(), frac_lengths=rand["frac_lengths"].numpy(),
+                        span_rand=rand["span_rand"].numpy(), loss_keep=losses["keep"], loss_drop_audio=losses["drop_audio"],
+                        loss_drop_both=losses["drop_both"])
+    # MX-fp8 quantisation (oracle/mx_oracle.py): bytes and scales of a fixed tensor
+    from oracle import mx_oracle as MX
+    xq = (torch.randn((8, 128), generator=g) * torch.logspace(-3, 2, 8)[:, None]).float()
+    q, e8 = MX.mx_quantize(xq)
+    np.savez_compressed(os.path.join(HERE, "mx_quantize.npz"), x=xq.numpy(), q=q.numpy(), e8=e8.numpy())
+    print("wrote golden fixtures", out.shape, mel.shape, losses)
 
 
 if __name__ == "__main__":

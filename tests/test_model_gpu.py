@@ -450,3 +450,18 @@ def test_from_pretrained_local_checkpoints(tmp_path):
     fm = F5TTS.from_pretrained(str(mdir), convert_weights=False, vocoder_name_or_path=None, device=str(DEV))
     mel, _ = fm.sample(wave, text=text, duration=150, steps=2, method="euler", seed=1)
     assert tuple(mel.shape) == (1, 150, 100)
+
+
+def test_golden_cfm_loss_on_the_engine(tiny_weights, tiny_x3):
+    """the committed golden loss values (tests/golden/tiny_cfm_loss.npz, fp64 oracle) reproduced by F5TTS.__call__ on the GPU"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_cfm_loss.npz"))
+    assert int(g["weights_seed"]) == 42
+    tts = F5TTS(tiny_x3)
+    for name, (ra, rc) in dict(keep=(0.9, 0.9), drop_audio=(0.1, 0.9), drop_both=(0.9, 0.1)).items():
+        rand = dict(x0=torch.from_numpy(g["x0"]), time=torch.from_numpy(g["time"]), frac_lengths=torch.from_numpy(g["frac_lengths"]),
+                    span_rand=torch.from_numpy(g["span_rand"]), rand_audio_drop=ra, rand_cond_drop=rc)
+        got = float(tts(torch.from_numpy(g["mel"]), torch.from_numpy(g["text"]), lens=torch.from_numpy(g["lens"]), rand=rand))
+        want = float(g["loss_" + name])
+        print(f"golden cfm loss [{name}]: engine {got:.6f} golden {want:.6f}")
+        assert abs(got - want) <= 2e-4 * want

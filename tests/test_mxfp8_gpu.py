@@ -47,6 +47,14 @@ def test_quantize_mx_bit_exact(lib):
     assert torch.all(err <= blk.abs().amax(-1) * 2.0 ** -3 + 1e-30)      # half a step at the top binade of (224, 448]
 
 
+def test_quantize_mx_golden(lib):
+    """the device quantiser against the committed golden bytes / scales (tests/golden/mx_quantize.npz)"""
+    import os
+    m = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mx_quantize.npz"))
+    q, sc = _dev_quantize(lib, torch.from_numpy(m["x"]))
+    assert np.array_equal(q.cpu().numpy(), m["q"]) and np.array_equal(sc.cpu().numpy(), m["e8"])
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 256), (1874, 1024, 1024), (700, 768, 2048)])
 def test_gemm_f8_matches_dequantised_operands(lib, M, N, K):
     """exact e4m3 x e4m3 products, fp32 accumulation: against fp64 on the DEQUANTISED operands only summation order differs"""
