@@ -1,5 +1,6 @@
 """CPU ORACLE for the duration predictor (reference: f5_tts_mlx/duration.py:44-260).  TEST INFRASTRUCTURE ONLY.
-Parity unpinned (see oracle/f5_oracle.py).  Reuses the DiT oracle's primitives for TextEmbedding / ConvNeXt / attention."""
+Pinned against the reference's duration.py executed over oracle/mlx_shim.py (tests/golden/ref_duration.npz); MLX's own
+arithmetic stays unpinned (see oracle/f5_oracle.py).  Reuses the DiT oracle's primitives for TextEmbedding / ConvNeXt / attention."""
 from __future__ import annotations
 
 from types import SimpleNamespace

@@ -5,11 +5,17 @@ This file restates, on torch-CPU / numpy, the algorithm of the reference
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the
 product path (f5_tts_mlx_amd/) never does.
 
-PARITY UNPINNED: the reference ships no tests / golden vectors and its arithmetic lives in MLX
-(`mlx>=0.18.1`, unpinned, pyproject.toml:35), which is not installable here.  This restatement
-follows the reference source line by line (citations below) and is cross-checked against
-independent implementations (scipy STFT, torch.nn.functional) in tests/test_oracle.py, but it has
-never been compared with outputs of the reference itself.
+PINNING STATUS: the reference ships no tests / golden vectors and its arithmetic lives in MLX
+(`mlx>=0.18.1`, unpinned, pyproject.toml:35), which is not installable here.  What IS pinned: the
+reference's own Python modules (dit, cfm, rope, convnext_v2, audio, utils, duration), imported
+unmodified from /root/reference and executed over `oracle/mlx_shim.py` (a numpy emulation of the
+mlx primitives they call), produce the committed vectors `tests/golden/ref_*.npz`
+(`tests/golden/make_reference_golden.py`); this restatement reproduces them to fp32 rounding
+(tests/test_reference_golden.py: forward 6e-6 max, trajectories < 1e-4 max, masks / tokens
+bit-exact).  What is NOT pinned: MLX's own kernels — the meaning of each mlx primitive is the
+shim's reading of the MLX documentation, never compared with MLX running ("parity unpinned" in
+that sense).  Independent cross-checks (scipy STFT, torch.nn.functional) are in
+tests/test_oracle.py.
 
 Precision switches
   dtype            torch.float32 (reference arithmetic) or torch.float64 (ground truth)

@@ -1,0 +1,135 @@
+"""The HIP engine against golden vectors produced by the REFERENCE's own Python source (tests/golden/ref_*.npz, made by
+tests/golden/make_reference_golden.py over oracle/mlx_shim.py — see that script's header for what the vectors do and do not pin).
+
+Gate (BASELINE.json north_star): mean |mel_engine - mel_reference| <= 1e-3, in the bf16x3 precision mode; plain bf16 drift is
+reported and loosely bounded.  Nothing here reads /root/reference: only the committed vectors travel to the GPU box.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from f5test import DEV, DiTConfig, report, synthetic_weights
+from f5_tts_mlx_amd.cfm import F5TTS
+from f5_tts_mlx_amd.dit import DiT
+from f5_tts_mlx_amd.utils import lens_to_mask, list_str_to_idx, list_str_to_tensor, mask_from_frac_lengths
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MEL_L1_TOL = 1e-3
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope="module")
+def models():
+    g = load("ref_dit_forward.npz")
+    cfg = DiTConfig(**json.loads(str(g["cfg"])))
+    w = synthetic_weights(cfg, seed=int(g["weights_seed"]))
+    out = {}
+    for prec in ("bf16x3", "bf16"):
+        m = DiT.from_config(cfg, precision=prec, device=DEV)
+        m.load_weights(w)
+        out[prec] = m
+    return cfg, out
+
+
+def test_dit_forward_vs_reference_code(models):
+    cfg, ms = models
+    g = load("ref_dit_forward.npz")
+    x, cond, text, time, mask = (torch.from_numpy(g[k]) for k in ("x", "cond", "text", "time", "mask"))
+    for prec, tol in (("bf16x3", 2e-4), ("bf16", 3e-2)):
+        for tag, (drop, m) in dict(cond=(False, None), null=(True, None), cond_masked=(False, mask), null_masked=(True, mask)).items():
+            got = ms[prec](x=x, cond=cond, text=text, time=time, drop_audio_cond=drop, drop_text=drop, mask=m)
+            _, mean, refm = report(f"dit[{prec}] {tag} vs reference code", got.cpu(), torch.from_numpy(g["out_" + tag]))
+            assert mean <= tol * max(1.0, refm), (prec, tag)
+    got = ms["bf16x3"](x=x[:1], cond=cond[:1], text=text[:1], time=torch.tensor(0.7), drop_audio_cond=False, drop_text=False)
+    _, mean, _ = report("dit[bf16x3] scalar time vs reference code", got.cpu(), torch.from_numpy(g["out_scalar_time"]))
+    assert mean <= 2e-4
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_sample_vs_reference_code(models, method):
+    cfg, ms = models
+    g = load("ref_sample.npz")
+    durations = torch.from_numpy(g["durations"])
+    y0 = torch.zeros((2, int(durations.max()), cfg.mel_dim))
+    for i, z in enumerate((g["z0"], g["z1"])):
+        y0[i, :z.shape[1]] = torch.from_numpy(z.T)
+    kw = dict(duration=durations, lens=torch.from_numpy(g["lens"]), steps=int(g[f"steps_{method}"]), method=method, cfg_strength=2.0,
+              sway_sampling_coef=-1.0, y0=y0)
+    want_out, want_traj = torch.from_numpy(g[f"out_{method}"]), torch.from_numpy(g[f"traj_{method}"])
+    out, traj = F5TTS(transformer=ms["bf16x3"]).sample(torch.from_numpy(g["cond"]), torch.from_numpy(g["text"]), **kw)
+    assert traj.shape == want_traj.shape and torch.equal(traj[0].cpu(), want_traj[0])
+    _, l1, _ = report(f"sample[bf16x3] {method} final mel vs reference code", out.cpu(), want_out)
+    _, l1t, _ = report(f"sample[bf16x3] {method} trajectory vs reference code", traj.cpu(), want_traj)
+    assert l1 <= MEL_L1_TOL and l1t <= MEL_L1_TOL
+    # conditioning frames are spliced back bit-exactly (cfm.py:395-397)
+    cm = lens_to_mask(torch.maximum((torch.from_numpy(g["text"]) != -1).sum(-1), torch.from_numpy(g["lens"])), out.shape[1])
+    assert torch.equal(out.cpu()[cm], want_out[cm])
+    outb, _ = F5TTS(transformer=ms["bf16"]).sample(torch.from_numpy(g["cond"]), torch.from_numpy(g["text"]), **kw)
+    _, l1b, _ = report(f"sample[bf16] {method} drift vs reference code", outb.cpu(), want_out)
+    assert l1b <= 5e-2
+
+
+def test_sample_batch1_no_cfg_vs_reference_code(models):
+    cfg, ms = models
+    g = load("ref_sample.npz")
+    y0 = torch.from_numpy(g["z0"].T.copy())[None]
+    out, traj = F5TTS(transformer=ms["bf16x3"]).sample(torch.from_numpy(g["cond"][:1]), torch.from_numpy(g["text"][:1]),
+                                                       duration=int(g["durations"][0]), steps=4, method="euler", cfg_strength=0.0,
+                                                       sway_sampling_coef=None, y0=y0)
+    _, l1, _ = report("sample[bf16x3] B1 no-cfg vs reference code", out.cpu(), torch.from_numpy(g["out_b1_nocfg"]))
+    _, l1t, _ = report("sample[bf16x3] B1 no-cfg trajectory vs reference code", traj.cpu(), torch.from_numpy(g["traj_b1_nocfg"]))
+    assert l1 <= MEL_L1_TOL and l1t <= MEL_L1_TOL
+
+
+def test_cfm_loss_vs_reference_code(models):
+    cfg, ms = models
+    g = load("ref_cfm_loss.npz")
+    tts = F5TTS(ms["bf16x3"])
+    for name, (ra, rc) in dict(keep=(0.9, 0.9), drop_audio=(0.1, 0.9), drop_both=(0.9, 0.1)).items():
+        rand = dict(x0=torch.from_numpy(g["x0"]), time=torch.from_numpy(g["time"]), frac_lengths=torch.from_numpy(g["frac_lengths"]),
+                    span_rand=torch.from_numpy(g["span_rand"]), rand_audio_drop=ra, rand_cond_drop=rc)
+        got = float(tts(torch.from_numpy(g["mel"]), torch.from_numpy(g["text"]), lens=torch.from_numpy(g["lens"]), rand=rand))
+        want = float(g["loss_" + name])
+        print(f"cfm loss [{name}]: engine {got:.6f} reference code {want:.6f}")
+        assert abs(got - want) <= 2e-4 * want
+
+
+def test_host_side_and_mel_front_end_vs_reference_code():
+    """index paths bit-exact; the HIP mel front-end within the mel-L1 gate of audio.py's output"""
+    from f5_tts_mlx_amd.audio import MelSpec
+    g = load("ref_host.npz")
+    lens = torch.from_numpy(g["lens"])
+    assert np.array_equal(lens_to_mask(lens).numpy(), g["lens_mask"])
+    assert np.array_equal(lens_to_mask(lens, 12).numpy(), g["lens_mask_len12"])
+    fm = mask_from_frac_lengths(torch.tensor([20, 31, 8], dtype=torch.int32), torch.tensor([0.7, 0.85, 1.0]), max_length=32,
+                                rand=torch.tensor([0.5, 0.1, 0.99]))
+    assert np.array_equal(fm.numpy(), g["frac_mask"])
+    assert np.array_equal(list_str_to_tensor(["hello", "héllo wörld", ""]).numpy(), g["utf8"])
+    assert np.array_equal(list_str_to_idx(json.loads(str(g["tok_in"])), json.loads(str(g["vocab"]))).numpy(), g["tok_idx"])
+    mel = MelSpec()(torch.from_numpy(g["audio"]).to(DEV)).cpu()
+    ref = torch.from_numpy(g["mel"])
+    _, l1, _ = report("mel front-end vs reference code", mel, ref)
+    assert mel.shape == ref.shape and l1 <= 1e-4
+
+
+def test_duration_predictor_vs_reference_code():
+    """DurationPredictor on the HIP ops vs duration.py's own output (tests/golden/ref_duration.npz)"""
+    from f5_tts_mlx_amd.duration import DurationPredictor, DurationTransformer, synthetic_duration_weights
+    g = load("ref_duration.npz")
+    kw = json.loads(str(g["cfg"]))
+    w = synthetic_duration_weights(seed=int(g["weights_seed"]), **kw)
+    for prec, tol in (("bf16x3", 2e-4), ("bf16", 2e-2)):
+        dp = DurationPredictor(DurationTransformer(heads=8, precision=prec, device=DEV, **kw))
+        dp.load_weights(w)
+        for tag in ("b1", "b2_long_text"):
+            got = dp(torch.from_numpy(g[f"{tag}_mel"]), torch.from_numpy(g[f"{tag}_text"]), lens=torch.from_numpy(g[f"{tag}_lens"]))
+            mx, _, refm = report(f"duration predictor [{prec}] {tag} vs reference code", got.cpu(), torch.from_numpy(g[f"{tag}_seconds"]))
+            assert mx <= tol * max(1.0, refm), (prec, tag)
