@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY.  Purpose: MLX cannot be installed in the build container, so the reference's own Python source
 cannot run as is.  With this shim registered under the module names `mlx`, `mlx.core`, `mlx.nn`, `einx` (plus empty stand-ins
-for `vocos_mlx`, `jieba`, `pypinyin`), the reference's *code* — DiT, CFM sampler, solvers, RoPE, ConvNeXt, mel front-end, masks,
+for `vocos_mlx`, `jieba`, `pypinyin`, `soundfile`, `sounddevice`), the reference's *code* — DiT, CFM sampler, solvers, RoPE, ConvNeXt, mel front-end, masks,
 tokenisers — executes unmodified on numpy arrays, and `tests/golden/make_reference_golden.py` records its outputs as golden
 vectors that pin `oracle/f5_oracle.py` (and, through the GPU tests, the engine).
 
@@ -114,6 +114,8 @@ def _build_core() -> types.ModuleType:
     mx.sin = lambda a: _wrap(np.sin(_raw(a)))
     mx.sqrt = lambda a: _wrap(np.sqrt(np.asarray(a, dtype=np.float32)))
     mx.sum = lambda a, axis=None, keepdims=False: _wrap(np.sum(_raw(a), axis=axis, keepdims=keepdims))
+    mx.mean = lambda a, axis=None, keepdims=False: _wrap(np.mean(_raw(a), axis=axis, keepdims=keepdims))
+    mx.square = lambda a: _wrap(np.square(_raw(a)))
     mx.outer = lambda a, b: _wrap(np.outer(_raw(a), _raw(b)))
     mx.matmul = lambda a, b: _wrap(np.matmul(_raw(a), _raw(b)))
     mx.einsum = lambda spec, *ops: _wrap(np.einsum(spec, *[_raw(o) for o in ops]))
@@ -384,7 +386,8 @@ def install():
     mlx.core, mlx.nn = mx, nn
     sys.modules.update({"mlx": mlx, "mlx.core": mx, "mlx.nn": nn, "mlx.nn.losses": nn.losses, "einx": _build_einx()})
     for name, attrs in (("vocos_mlx", {"Vocos": type("Vocos", (), {})}), ("jieba", {"setLogLevel": lambda *_a: None}),
-                        ("pypinyin", {"lazy_pinyin": None, "Style": type("Style", (), {"TONE3": 0})})):
+                        ("pypinyin", {"lazy_pinyin": None, "Style": type("Style", (), {"TONE3": 0})}),
+                        ("soundfile", {}), ("sounddevice", {})):
         if name not in sys.modules:
             m = types.ModuleType(name)
             for k, v in attrs.items():

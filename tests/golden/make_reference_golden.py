@@ -43,6 +43,12 @@ REF_CFG = dict(dim=1024, depth=2, heads=16, dim_head=64, ff_mult=2, mel_dim=100,
 WEIGHTS_SEED = 7
 DUR_CFG = dict(dim=512, depth=3, text_num_embeds=70, text_dim=512, conv_layers=2, ff_mult=2)     # from_pretrained's, 3 of 8 blocks
 DUR_SEED = 5
+GEN_VOCAB = " abcdefghijklmnopqrstuvwxyz,.!?'-ABCDEFGHIJKLMNOPQRSTUVWXYZ0123"        # 64 symbols; anything else -> 0 (utils.py:129)
+GEN_CASES = dict(
+    single_duration=dict(generation_text="The quick brown fox.", duration=6.4, steps=3, method="euler", seed=3),
+    single_estimated=dict(generation_text="Hello there; general Kenobi", estimate_duration=True, steps=2, method="rk4", seed=11, speed=1.3),
+    sentences_predicted=dict(generation_text="One fish. Two fish! Red fish", steps=2, method="midpoint", seed=5, speed=0.1, cfg_strength=1.5),
+)
 
 
 class injected_random:
@@ -189,6 +195,50 @@ def main():
         dur.update({f"{tag}_mel": dmel, f"{tag}_text": dtext, f"{tag}_lens": dlens,
                     f"{tag}_seconds": f32(dp(mx.array(dmel), mx.array(dtext), lens=mx.array(dlens)))})
     np.savez_compressed(os.path.join(HERE, "ref_duration.npz"), cfg=json.dumps(DUR_CFG), weights_seed=DUR_SEED, **dur)
+
+    # ---- 6. generate() (generate.py:113-245): the API wrapper around sample --------------------------------------
+    # Stand-ins (test infrastructure, identical on the engine side of the comparison): `soundfile` -> scipy WAV reader
+    # / capture of the written array; `sounddevice` unused (output_path given); `jieba.cut` -> the package's emulation
+    # of jieba's segmentation of single-byte text; `F5TTS.from_pretrained` -> the synthetic-weight model above plus a
+    # character vocabulary, the duration predictor of section 5 and a FAKE vocoder (frame n -> 256 samples
+    # mel[n, j % 100]); `mx.random.seed/normal` -> the package's threefry emulation of MLX's generator (rng.py).
+    import scipy.io.wavfile as wavfile
+    from f5_tts_mlx_amd.rng import mlx_like_normal
+    from f5_tts_mlx_amd.utils import _ascii_segments
+    written = {}
+
+    def sf_read(path):
+        sr, a = wavfile.read(path)
+        return a.astype(np.float64) / 32768.0, sr
+
+    sys.modules["soundfile"].read = sf_read
+    sys.modules["soundfile"].write = lambda path, data, sr: written.__setitem__(path, (np.asarray(data, dtype=np.float32), sr))
+    sys.modules["jieba"].cut = _ascii_segments
+    import f5_tts_mlx.generate as ref_generate  # noqa: E402
+    ref_utils.jieba.cut = _ascii_segments
+
+    gen_model = build_reference_model(cfg, weights)
+    gen_model._vocab_char_map = {c: i for i, c in enumerate(GEN_VOCAB)}
+    gen_model._vocoder = lambda mel: mx.array(np.asarray(mel)[0][:, np.arange(256) % 100].reshape(-1))
+    gen_model._duration_predictor = dp
+    dp._vocab_char_map = gen_model._vocab_char_map
+    ref_generate.F5TTS.from_pretrained = classmethod(lambda cls, name, quantization_bits=None: gen_model)
+    seed_state = {}
+    saved = (mx.random.seed, mx.random.normal)
+    mx.random.seed = lambda s: seed_state.__setitem__("seed", int(s))
+    mx.random.normal = lambda shape=(), dtype=np.float32: mx.array(mlx_like_normal(seed_state["seed"], tuple(int(v) for v in shape)))
+    wav = os.path.join(ROOT, "f5_tts_mlx_amd", "assets", "test_en_1_ref_short.wav")
+    caption = "Some call me nature, others call me mother nature."
+    gen = {}
+    for tag, kw in GEN_CASES.items():
+        ref_generate.generate(ref_audio_path=wav, ref_audio_text=caption, output_path=tag, **kw)
+        wave, sr = written[tag]
+        assert sr == 24000 and wave.ndim == 1 and wave.shape[0] > 0
+        gen["wave_" + tag] = wave
+    mx.random.seed, mx.random.normal = saved
+    np.savez_compressed(os.path.join(HERE, "ref_generate.npz"), cases=json.dumps(GEN_CASES), vocab=GEN_VOCAB, caption=caption,
+                        dur_cfg=json.dumps(DUR_CFG), dur_seed=DUR_SEED, **gen, **meta)
+    print("generate():", {k: v.shape for k, v in gen.items()})
 
     print("reference goldens written:", {k: v.shape for k, v in fwd.items()}, {k: float(v) for k, v in losses.items()})
 

@@ -133,3 +133,30 @@ def test_duration_predictor_vs_reference_code():
             got = dp(torch.from_numpy(g[f"{tag}_mel"]), torch.from_numpy(g[f"{tag}_text"]), lens=torch.from_numpy(g[f"{tag}_lens"]))
             mx, _, refm = report(f"duration predictor [{prec}] {tag} vs reference code", got.cpu(), torch.from_numpy(g[f"{tag}_seconds"]))
             assert mx <= tol * max(1.0, refm), (prec, tag)
+
+
+def test_generate_vs_reference_code(models, tmp_path):
+    """generate() (generate.py:113-245) end to end vs the reference's own function run over the shim: RMS rule, seconds -> frames,
+    estimated / predicted durations, sentence loop, text conversion, reference trim by samples, WAV output.  Stand-ins shared by
+    both sides (see make_reference_golden.py §6): fake vocoder, character vocabulary, rng.py noise for `seed`."""
+    import os as _os
+    from f5_tts_mlx_amd import generate as G
+    from f5_tts_mlx_amd.duration import DurationPredictor, DurationTransformer, synthetic_duration_weights
+    cfg, ms = models
+    g = load("ref_generate.npz")
+    vocab = {c: i for i, c in enumerate(str(g["vocab"]))}
+    dkw = json.loads(str(g["dur_cfg"]))
+    dp = DurationPredictor(DurationTransformer(heads=8, precision="bf16x3", device=DEV, **dkw))
+    dp.load_weights(synthetic_duration_weights(seed=int(g["dur_seed"]), **dkw))
+    idx = torch.arange(256, device=DEV) % 100
+    f5 = F5TTS(transformer=ms["bf16x3"], vocab_char_map=vocab, vocoder=lambda mel: mel[0][:, idx].reshape(-1), duration_predictor=dp)
+    wav = _os.path.join(_os.path.dirname(G.__file__), "assets", "test_en_1_ref_short.wav")
+    for tag, kw in json.loads(str(g["cases"])).items():
+        out = str(tmp_path / f"{tag}.wav")
+        wave = G.generate(ref_audio_path=wav, ref_audio_text=str(g["caption"]), output_path=out, f5tts=f5, **kw)
+        want = torch.from_numpy(g["wave_" + tag])
+        assert wave.shape == want.shape, (tag, wave.shape, want.shape)          # identical frame counts on every sentence
+        _, l1, _ = report(f"generate[{tag}] wave (fake vocoder = mel samples) vs reference code", wave.cpu(), want)
+        assert l1 <= MEL_L1_TOL, tag
+        sr, written = __import__("scipy.io.wavfile", fromlist=["read"]).read(out)
+        assert sr == 24000 and np.array_equal(written, wave.cpu().numpy())
