@@ -139,6 +139,23 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_sample.npz"), cond=cond_mel, lens=ref_lens, text=stext, durations=durations,
                         z0=z[0], z1=z[1], out_b1_nocfg=f32(out1), traj_b1_nocfg=f32(traj1), **samples, **meta)
 
+    # ---- 2b. duration / lens clamps (cfm.py:301-303,317-319): more text tokens than reference frames
+    # (conditioning region extended over zero padding), duration below lens+1 raised, duration above max_duration clipped
+    r2 = np.random.default_rng(77)
+    c_cond = f32(r2.standard_normal((2, 8, cfg.mel_dim)))
+    c_lens = np.array([8, 6], np.int32)
+    c_text = r2.integers(0, cfg.text_num_embeds, (2, 14)).astype(np.int32)
+    c_text[1, 11:] = -1
+    c_req = np.array([10, 50], np.int32)
+    c_final = [15, 45]                                   # max(max(#tokens, lens) + 1, requested) clipped to max_duration = 45
+    cz = [f32(r2.standard_normal((cfg.mel_dim, d))) for d in c_final]
+    with injected_random(normal=cz):
+        c_out, c_traj = model.sample(mx.array(c_cond), mx.array(c_text), mx.array(c_req), lens=mx.array(c_lens), steps=3, method="euler",
+                                     cfg_strength=2.0, sway_sampling_coef=-1.0, seed=1, max_duration=45)
+    assert c_out.shape == (2, 45, cfg.mel_dim)
+    np.savez_compressed(os.path.join(HERE, "ref_sample_clamps.npz"), cond=c_cond, lens=c_lens, text=c_text, durations=c_req,
+                        final_durations=np.array(c_final, np.int32), max_duration=45, z0=cz[0], z1=cz[1], out=f32(c_out), traj=f32(c_traj), **meta)
+
     # ---- 3. F5TTS.__call__ loss forward (cfm.py:169-251), every draw recorded in reference order --------------
     Bl, Nl = 2, 48
     mel_in = f32(r.standard_normal((Bl, Nl, cfg.mel_dim)))

@@ -180,3 +180,19 @@ def test_duration_predictor_matches_reference_code():
                          depth=kw["depth"], dtype=torch.float32)
         want = torch.from_numpy(g[f"{tag}_seconds"])
         assert got.shape == want.shape and float((got - want).abs().max()) < 2e-5 * float(want.abs().max()), tag
+
+
+def test_sample_duration_clamps_match_reference_code(ref_model):
+    """cfm.py:301-303,317-319: lens = max(#text tokens, lens) (more tokens than reference frames: the conditioning region runs over
+    zero padding), duration raised to lens + 1, clipped to max_duration"""
+    cfg, dit = ref_model
+    g, _ = load("ref_sample_clamps.npz")
+    nmax = int(g["max_duration"])
+    y0 = torch.zeros((2, nmax, cfg.mel_dim))
+    for i, z in enumerate((g["z0"], g["z1"])):
+        y0[i, :z.shape[1]] = torch.from_numpy(z.T)
+    out, traj, aux = O.sample(dit, torch.from_numpy(g["cond"]), torch.from_numpy(g["text"]), torch.from_numpy(g["durations"]),
+                              lens=torch.from_numpy(g["lens"]), steps=3, method="euler", y0=y0, max_duration=nmax, return_aux=True)
+    assert aux["duration"].tolist() == g["final_durations"].tolist() and aux["lens"].tolist() == [14, 11]
+    assert float((traj - torch.from_numpy(g["traj"])).abs().max()) < TRAJ_TOL
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) < TRAJ_TOL

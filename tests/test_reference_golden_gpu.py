@@ -160,3 +160,20 @@ def test_generate_vs_reference_code(models, tmp_path):
         assert l1 <= MEL_L1_TOL, tag
         sr, written = __import__("scipy.io.wavfile", fromlist=["read"]).read(out)
         assert sr == 24000 and np.array_equal(written, wave.cpu().numpy())
+
+
+def test_sample_duration_clamps_vs_reference_code(models):
+    """more text tokens than reference frames, duration raised to lens + 1 and clipped to max_duration (cfm.py:301-303,317-319)"""
+    cfg, ms = models
+    g = load("ref_sample_clamps.npz")
+    nmax = int(g["max_duration"])
+    y0 = torch.zeros((2, nmax, cfg.mel_dim))
+    for i, z in enumerate((g["z0"], g["z1"])):
+        y0[i, :z.shape[1]] = torch.from_numpy(z.T)
+    out, traj = F5TTS(transformer=ms["bf16x3"]).sample(torch.from_numpy(g["cond"]), torch.from_numpy(g["text"]),
+                                                       duration=torch.from_numpy(g["durations"]), lens=torch.from_numpy(g["lens"]),
+                                                       steps=3, method="euler", y0=y0, max_duration=nmax)
+    assert tuple(out.shape) == g["out"].shape
+    _, l1, _ = report("sample[bf16x3] clamps final mel vs reference code", out.cpu(), torch.from_numpy(g["out"]))
+    _, l1t, _ = report("sample[bf16x3] clamps trajectory vs reference code", traj.cpu(), torch.from_numpy(g["traj"]))
+    assert l1 <= MEL_L1_TOL and l1t <= MEL_L1_TOL
