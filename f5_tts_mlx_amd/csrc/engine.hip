@@ -1021,7 +1021,7 @@ extern "C" int f5_debug_set_gemm_flags(int v) {
 }
 extern int f5_gemm_tile_override;
 extern "C" int f5_debug_set_gemm_tile(int sel) {
-    F5_REQUIRE(sel >= 0 && sel <= 11, "gemm tile override must be 0 (auto) .. 11");
+    F5_REQUIRE(sel >= 0 && sel <= 13, "gemm tile override must be 0 (auto) .. 13");
     f5_gemm_tile_override = sel;
     return 0;
 }

@@ -1132,6 +1132,24 @@ static int launch_ring8(const F5GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// 128x256 ring tiles for ONE round on the QKV projection at batch 1 (M = 1874, N = 3072: 15 x 12 = 180 workgroups), two
+// wave layouts (tile overrides 12 / 13): 8 waves of 64x64 and 8 waves of 32x128, i.e. 1.0 / 1.25 KB of LDS fragment reads
+// per MFMA against 1.5 for the 64x128 tile of 4 waves of 32x64, and half the L2->LDS bytes per flop.  Measured in-graph
+// (tools/qkv_tiles_bench.py): 27.0-28.1 / 24.7-24.8 us against 25.5-27.2 us for the register-staged 64x128 default, and
+// 22.3-23.1 us at M = 937 where only 96 workgroups exist: a lone workgroup takes ~1.4 us per K tile whatever the fill, three
+// times its MFMA time -- neither L2 bytes nor occupancy is what bounds this shape.  Kept as overrides, not selected.
+template <int EPI, int MB, int NB, int WM, int WN>
+static int launch_ring_wide(const F5GemmArgs& a, hipStream_t stream) {
+    constexpr int BMt = 32 * MB * WM, BNt = 32 * NB * WN;
+    F5_REQUIRE(a.N % BNt == 0, "gemm: this tile needs N %% %d == 0", BNt);
+    const int tiles_m = f5_cdiv(a.M, BMt), tiles_n = a.N / BNt;
+    const int ntiles = tiles_m * tiles_n;
+    const int order = gemm_mfast(a) ? -tiles_m : tiles_n;
+    hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, NB, 3, WM, WN>), dim3(ntiles), dim3(64 * WM * WN), 0, stream, a, order, ntiles);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 // =================================================================================================
 // v3: 128x256x32 block tile, 256 threads = 4 waves (2 x 2), wave tile 64x128 (2x4 accumulators), global_load_lds
 // ring of 3 K-tiles of 24 KB => 72 KB of LDS and <= 256 registers, i.e. TWO workgroups per CU.  Rationale (measured
@@ -1615,6 +1633,13 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     if (sel == 4 || (sel == 0 && v2ok && t256 >= 512)) {
         F5_REQUIRE(v2ok, "gemm: the 256x256 kernel needs N %% 256 == 0 and M >= 256");
         return launch_v2<EPI>(a, stream);
+    }
+    if (sel == 12 || sel == 13) {
+        if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_BF16 || EPI == EPI_GELU_TANH) {
+            if (a.N % 256 == 0)
+                return sel == 12 ? launch_ring_wide<EPI, 2, 2, 2, 4>(a, stream) : launch_ring_wide<EPI, 1, 4, 4, 2>(a, stream);
+        }
+        sel = 0;
     }
     if (sel == 10) return launch_ring_ks2<EPI, 1>(a, stream);
     if (sel == 11) return launch_ring_ks2<EPI, 2>(a, stream);

@@ -164,7 +164,9 @@ int f5_op_im2col7(const float* x, void* out_hi, void* out_lo, int nbatch, int se
 int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scratch, float* wave, int nframes, int n_fft,
                 int hop, void* stream);
 
-/* debug / benchmarking hook: force the GEMM block tile (0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 global_load_lds kernel) */
+/* debug / benchmarking hook: force the GEMM block tile (0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 global_load_lds kernel,
+ * 5 / 6 = ring 64x128 / 64x64, 7 = 128x256 two-per-CU, 8 / 9 = 8-wave ring 128x192 / 128x128, 10 / 11 = in-workgroup split-K
+ * 64x128 / 128x128, 12 / 13 = 8-wave ring 128x256 with 64x64 / 32x128 wave tiles) */
 int f5_debug_set_gemm_tile(int sel);
 /* bit 0: skip GEMM epilogues of the 256x256 / 128x256 kernels (timing experiments only; results are garbage);
  * bit 1: small-tile kernels use the direct (2-byte store) epilogue instead of the LDS-staged one */

@@ -540,6 +540,32 @@ def test_gemm_ring8_kernels(lib, tile):
         E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+@pytest.mark.parametrize("tile", [12, 13])
+def test_gemm_wide_ring_kernels(lib, tile):
+    """128x256 ring tiles (8 waves of 64x64, 8 waves of 32x128): plain, bf16x3, GELU epilogue and the
+    QKV + RoPE + head-split epilogue (staged, one or two heads per wave tile)"""
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        for (M, N, K) in ((1, 256, 64), (333, 512, 192), (1874, 768, 1024), (130, 1280, 2048)):
+            r = rng(M + N + K + tile)
+            a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+            refbf = (bf16r(a).double() @ bf16r(w).double().T) + bias.double()
+            out, hi1, _ = _gemm(lib, a, w, bias, 1, 1)
+            mx, _, _ = report(f"gemm tile={tile} {M}x{N}x{K}", hi1.float(), refbf)
+            assert mx <= 1e-2 * max(1.0, float(refbf.abs().max()))
+            _, hi, lo = _gemm(lib, a, w, bias, 1, 3)
+            ref32 = a.double() @ w.double().T + bias.double()
+            assert float((join(hi, lo).double() - ref32).abs().max()) <= 5e-5 * max(1.0, float(ref32.abs().max()))
+            _, hi, lo = _gemm(lib, a, w, bias, 2, 3)
+            refg = F.gelu(ref32, approximate="tanh")
+            assert float((join(hi, lo).double() - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))
+        _attention_case(lib, 2, 4, 300, [300, 211], 1, seed=21)     # D = 256, N = 768 = 3 x 256
+        _attention_case(lib, 1, 8, 130, None, 3, seed=22)           # D = 512, N = 1536
+        _attention_case(lib, 2, 16, 937, None, 1, seed=23)          # the batch-1 shape: M = 1874, N = 3072
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))
+
+
 def test_gemm_streamk_schedule(lib):
     """256x256 kernel under the stream-K schedule (>= one tile per CU): split tiles are handed over through the partial-tile
     scratch; every epilogue; bitwise run-to-run determinism; agreement with the one-tile-per-workgroup schedule."""
