@@ -229,3 +229,19 @@ def test_mlx_affine_quantisation_roundtrip():
     assert set(out) == {"a.weight", "a.bias", "n.weight"} and out["a.weight"].shape == (24, 192)
     with pytest.raises(ValueError):
         dequantize_mlx_affine(pk, sc[:, :2], bi[:, :2], 8)
+
+
+def test_bench_flop_model_matches_survey():
+    """bench.py's algorithmic flop count per utterance-forward is SURVEY.md §8(d)'s F(937) = 442 304 409 600; the hoisted
+    (executed) figure drops the per-sample work and counts the x-part of the input projection at its padded K = 128"""
+    import importlib
+    import sys
+    from f5test import ROOT
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    assert bench.flops_forward(937, hoisted=False) == 442_304_409_600
+    executed = bench.flops_forward(937, hoisted=True)
+    assert executed == 432_959_365_120 + 937 * 2 * (128 - 100) * 1024      # SURVEY's F_h + the K padding 100 -> 128
+    assert executed < bench.flops_forward(937, hoisted=False)
+    assert abs(62 * 442_304_409_600 / 1e12 - 27.423) < 1e-3                # reference-equivalent TFLOP per 32-point Euler utterance
