@@ -344,25 +344,30 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) {
             const int rowblk = row0 + mb * 32;
+            // RoPE factors of the whole 32-row block, issued as ONE batch of loads (in a one-round launch the epilogue is a
+            // latency chain: four dependent batches cost four round trips).  The table index depends on the column only through
+            // its position inside the head, i.e. on the parity of nb; rows >= M read a valid entry and are never stored.
+            constexpr int PAR = NBW >= 2 ? 2 : 1;
+            float rc[4][4][PAR], rs[4][4][PAR];
+            if (EPI == EPI_QKV_ROPE) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                float rc[4][NBW], rs[4][NBW];
-                if (EPI == EPI_QKV_ROPE) {
-                    const int rowbase = rowblk + rg * 8 + hi * 4;
-                    const int nbase = rowbase % p.seq_len;
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int nbase = (rowblk + rg * 8 + hi * 4) % p.seq_len;
 #pragma unroll
                     for (int ri = 0; ri < 4; ++ri) {
                         int n = nbase + ri;
                         if (n >= p.seq_len) n -= p.seq_len;
-                        const bool ok = rowbase + ri < p.M;
 #pragma unroll
-                        for (int nb = 0; nb < NBW; ++nb) {
-                            const int j = ((nb * 32 + lcol) & 63) >> 1;
-                            rc[ri][nb] = ok ? p.rope_cos[n * 32 + j] : 1.0f;
-                            rs[ri][nb] = ok ? p.rope_sin[n * 32 + j] : 0.0f;
+                        for (int q = 0; q < PAR; ++q) {
+                            const int j = ((q * 32 + lcol) & 63) >> 1;
+                            rc[rg][ri][q] = p.rope_cos[n * 32 + j];
+                            rs[rg][ri][q] = p.rope_sin[n * 32 + j];
                         }
                     }
                 }
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
 #pragma unroll
                 for (int ri = 0; ri < 4; ++ri) {
                     const int r = rg * 4 + ri;
@@ -374,7 +379,8 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
                         if (EPI == EPI_GELU_ERF_BF16) v = f5_gelu_erf(v);
                         if (EPI == EPI_QKV_ROPE) {
                             const float partner = __shfl_xor(v, 1, 64);
-                            v = (lcol & 1) ? (v * rc[ri][nb] + partner * rs[ri][nb]) : (v * rc[ri][nb] - partner * rs[ri][nb]);
+                            const float c = rc[rg][ri][nb & (PAR - 1)], sn = rs[rg][ri][nb & (PAR - 1)];
+                            v = (lcol & 1) ? (v * c + partner * sn) : (v * c - partner * sn);
                         }
                         bf16_t h, l;
                         f5_split(v, h, l);
@@ -900,7 +906,9 @@ static bool gemm_mfast(const F5GemmArgs& a) {
     return a_bytes <= (size_t)4 << 20;     // whole A operand fits in one XCD's 4 MB L2
 }
 
-template <int EPI, int MB, int NB, int NST, int WM = 2, int WN = 2, int KS = 1>
+// ABL (timing experiments only, results are garbage; tools/ring_ablate.py): 1 = no operand loads after the prologue, 2 = no MFMAs,
+// 4 = no LDS fragment reads, 8 = no workgroup barrier -- what a K step of a lone workgroup is made of
+template <int EPI, int MB, int NB, int NST, int WM = 2, int WN = 2, int KS = 1, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
     // WM x WN waves per K group, wave tile 32*MB x 32*NB; KS groups split the K tiles round-robin (group g owns tiles
     // g, g+KS, ...; its own ring) and are summed in group order through LDS at the end: small-M problems are one round
@@ -1015,6 +1023,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
             pa[w2][ks] = smem + w2 * SPS * STAGE + swz_off(wm * (32 * MB) + frow, ks * 2 + fk);
             pb[w2][ks] = smem + w2 * SPS * STAGE + BMt * BK + swz_off(wn * (32 * NB) + frow, ks * 2 + fk);
         }
+    bf16x8 abl_frag;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) abl_frag[e] = (bf16_t)0;
+    if (ABL & 4) asm volatile("" : "+v"(abl_frag));
 #define RING_STEP(ST_, jj_)                                                                                         \
     {                                                                                                               \
         /* tile jj must have landed; up to NST-2 younger tiles may stay in flight (conservative vmcnt(0) at the tail) */ \
@@ -1026,20 +1038,22 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
         }                                                                                                           \
         asm volatile("" ::: "memory");                                                                              \
-        __builtin_amdgcn_s_barrier();                                                                               \
+        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();                                                               \
         asm volatile("" ::: "memory");                                                                              \
-        if ((jj_) + NST - 1 < Tg) RING_ISSUE(((ST_) + NST - 1) % NST); /* refills the slot consumed one iteration ago */ \
+        if (!(ABL & 1) && (jj_) + NST - 1 < Tg) RING_ISSUE(((ST_) + NST - 1) % NST); /* refills the slot consumed one iteration ago */ \
         if (!(KS > 1 && (jj_) >= Tg)) {              /* wave-uniform: a group without a tile left still meets the barrier */ \
             constexpr int W2 = (ST_) / SPS, SL = (ST_) % SPS;                                                        \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                      \
                 bf16x8 af[MB], bfr[NB];                                                                             \
                 _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                   \
-                    af[mb] = *reinterpret_cast<const bf16x8*>(pa[W2][ks] + SL * STAGE + mb * 32 * BK);              \
+                    af[mb] = (ABL & 4) ? abl_frag : *reinterpret_cast<const bf16x8*>(pa[W2][ks] + SL * STAGE + mb * 32 * BK); \
                 _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                   \
-                    bfr[nb] = *reinterpret_cast<const bf16x8*>(pb[W2][ks] + SL * STAGE + nb * 32 * BK);             \
+                    bfr[nb] = (ABL & 4) ? abl_frag : *reinterpret_cast<const bf16x8*>(pb[W2][ks] + SL * STAGE + nb * 32 * BK); \
                 _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                   \
-                    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                               \
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0); \
+                    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                             \
+                        if (ABL & 2) asm volatile("" ::"v"(af[mb]), "v"(bfr[nb]));                                  \
+                        else acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0); \
+                    }                                                                                               \
             }                                                                                                       \
         }                                                                                                           \
     }
@@ -1138,16 +1152,36 @@ static int launch_ring8(const F5GemmArgs& a, hipStream_t stream) {
 // (tools/qkv_tiles_bench.py): 27.0-28.1 / 24.7-24.8 us against 25.5-27.2 us for the register-staged 64x128 default, and
 // 22.3-23.1 us at M = 937 where only 96 workgroups exist: a lone workgroup takes ~1.4 us per K tile whatever the fill, three
 // times its MFMA time -- neither L2 bytes nor occupancy is what bounds this shape.  Kept as overrides, not selected.
-template <int EPI, int MB, int NB, int WM, int WN>
+template <int EPI, int MB, int NB, int WM, int WN, int KS = 1, int ABL = 0>
 static int launch_ring_wide(const F5GemmArgs& a, hipStream_t stream) {
     constexpr int BMt = 32 * MB * WM, BNt = 32 * NB * WN;
     F5_REQUIRE(a.N % BNt == 0, "gemm: this tile needs N %% %d == 0", BNt);
     const int tiles_m = f5_cdiv(a.M, BMt), tiles_n = a.N / BNt;
     const int ntiles = tiles_m * tiles_n;
     const int order = gemm_mfast(a) ? -tiles_m : tiles_n;
-    hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, NB, 3, WM, WN>), dim3(ntiles), dim3(64 * WM * WN), 0, stream, a, order, ntiles);
+    hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, NB, 3, WM, WN, KS, ABL>), dim3(ntiles), dim3(64 * WM * WN * KS), 0, stream, a, order,
+                       ntiles);
     F5_LAUNCH_CHECK();
     return 0;
+}
+// timing-only ablations of the ring main loop (debug flags bits 4-7), bf16 epilogue, tile 13 (128x256, 8 waves) and tile 10
+// (64x128, two K groups of 4 waves)
+template <int ABL>
+static int launch_ring_ablate(const F5GemmArgs& a, int sel, hipStream_t stream) {
+    return sel == 13 ? launch_ring_wide<EPI_BF16, 1, 4, 4, 2, 1, ABL>(a, stream) : launch_ring_wide<EPI_BF16, 1, 2, 2, 2, 2, ABL>(a, stream);
+}
+static int launch_ring_ablate(const F5GemmArgs& a, int sel, int abl, hipStream_t stream) {
+    switch (abl) {
+        case 1: return launch_ring_ablate<1>(a, sel, stream);
+        case 2: return launch_ring_ablate<2>(a, sel, stream);
+        case 4: return launch_ring_ablate<4>(a, sel, stream);
+        case 8: return launch_ring_ablate<8>(a, sel, stream);
+        case 6: return launch_ring_ablate<6>(a, sel, stream);     // loads + barrier only
+        case 7: return launch_ring_ablate<7>(a, sel, stream);     // barrier + loop skeleton
+        case 9: return launch_ring_ablate<9>(a, sel, stream);     // LDS reads + MFMAs, no loads, no barrier
+        case 15: return launch_ring_ablate<15>(a, sel, stream);   // loop skeleton
+        default: f5_set_error("gemm: ablation %d is not instantiated", abl); return 2;
+    }
 }
 
 // =================================================================================================
@@ -1633,6 +1667,10 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     if (sel == 4 || (sel == 0 && v2ok && t256 >= 512)) {
         F5_REQUIRE(v2ok, "gemm: the 256x256 kernel needs N %% 256 == 0 and M >= 256");
         return launch_v2<EPI>(a, stream);
+    }
+    if constexpr (EPI == EPI_BF16) {
+        const int abl = (a.debug_flags >> 4) & 15;
+        if (abl && (sel == 13 || sel == 10) && a.N % 256 == 0) return launch_ring_ablate(a, sel, abl, stream);
     }
     if (sel == 12 || sel == 13) {
         if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_BF16 || EPI == EPI_GELU_TANH) {

@@ -169,7 +169,9 @@ int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scra
  * 64x128 / 128x128, 12 / 13 = 8-wave ring 128x256 with 64x64 / 32x128 wave tiles) */
 int f5_debug_set_gemm_tile(int sel);
 /* bit 0: skip GEMM epilogues of the 256x256 / 128x256 kernels (timing experiments only; results are garbage);
- * bit 1: small-tile kernels use the direct (2-byte store) epilogue instead of the LDS-staged one */
+ * bit 1: small-tile kernels use the direct (2-byte store) epilogue instead of the LDS-staged one;
+ * bits 4-7 (timing only, garbage results; tile overrides 10 / 13 with the bf16 epilogue): 16 = no operand loads after the prologue,
+ * 32 = no MFMAs, 64 = no LDS fragment reads, 128 = no workgroup barrier (combinations 96, 112, 144, 240 are instantiated) */
 int f5_debug_set_gemm_flags(int v);
 /* small-tile GEMM tile numbering: 0 auto, 1 n fastest, 2 m fastest */
 int f5_debug_set_gemm_order(int v);
