@@ -153,6 +153,17 @@ def gemm_roofline_f8(lib, E, dev, M, D, g, iters):
                 traffic=None, traffic_unit="bytes/launch", algorithmic_bytes=M * D + 3 * D * D + (M + 3 * D) * D // 32 + 2 * M * 3 * D)
 
 
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(weights, budget_s: float = 25.0):
     """The oracle (CPU restatement of the reference, kind="port") timed on the host cores on a bounded sample: full-size
     fp32 DiT forwards at N=937 (B=1), first a short sweep over thread counts (one forward each), then the best setting is
@@ -189,7 +200,7 @@ def cpu_baseline(weights, budget_s: float = 25.0):
                 sample=f"{n_rep} full-size fp32 DiT forwards (B=1, N={N_FRAMES}) of the oracle on torch-CPU with {best} threads "
                        f"(sweep s/forward: {dict((k, round(v, 2)) for k, v in sweep.items())}), {dt:.2f} s each, "
                        f"extrapolated x{n_fwd} forwards per utterance",
-                rtf=10.0 / (n_fwd * dt), host_cpus=ncpu)
+                rtf=10.0 / (n_fwd * dt), host_cpus=ncpu, cpu_model=_cpu_model())
 
 
 def main():
