@@ -830,6 +830,8 @@ static int check_args(const f5_engine* e, const f5_sample_args* a) {
     F5_REQUIRE(e->finalized, "weights are not finalized");
     F5_REQUIRE(a->B >= 1 && a->N >= 1 && a->nt >= 1 && a->steps >= 1, "bad sizes B=%d N=%d nt=%d steps=%d", a->B, a->N, a->nt,
                a->steps);
+    // the RoPE / head-split epilogues step through a 4-row group with a single wrap at the sequence boundary
+    F5_REQUIRE(a->N >= 4, "sequences shorter than 4 mel frames are not supported (N=%d)", a->N);
     F5_REQUIRE(a->method >= F5_EULER && a->method <= F5_RK4, "Unknown method: %d", a->method);
     F5_REQUIRE(a->text && a->cond && a->lens && a->durations && a->workspace, "null pointer in f5_sample_args");
     F5_REQUIRE(((uintptr_t)a->workspace & 255) == 0, "workspace must be 256-byte aligned");

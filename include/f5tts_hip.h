@@ -70,7 +70,7 @@ int f5_mark_weights_loaded(f5_engine* e);
  * grid); the engine runs everything from the masks to the final splice on the GPU.             */
 typedef struct f5_sample_args {
     int32_t B;                 /* utterances                                                     */
-    int32_t N;                 /* max_duration in frames (cfm.py:319)                            */
+    int32_t N;                 /* max_duration in frames (cfm.py:319); the engine needs N >= 4   */
     int32_t nt;                /* text columns                                                   */
     const int32_t* text;       /* dev  [B][nt] token ids, -1 padded (utils.py:124-133)           */
     const float* cond;         /* dev  [B][N][mel] reference mel, zero padded to N (cfm.py:321)  */
@@ -106,7 +106,7 @@ int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, const void*
 /* dit.py:136-166: qk [B*n][2*dmodel] (RoPE'd q | k), vt [B*H][64][npad] -> out [B*n][dmodel] */
 int f5_op_attention(const void* qk_hi, const void* qk_lo, const void* vt_hi, const void* vt_lo, void* out_hi, void* out_lo,
                     const int32_t* kv_len, int B, int H, int seq_len, int npad, int dmodel, float scale, int hp, void* stream);
-/* QKV projection + bias + RoPE + head split (dit.py:136-158) */
+/* QKV projection + bias + RoPE + head split (dit.py:136-158); B > 1 needs seq_len >= 4 */
 int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                    const float* rope_cos, const float* rope_sin, void* qk_hi, void* qk_lo, void* vt_hi, void* vt_lo, int B,
                    int seq_len, int npad, int heads, int dmodel, int nseg, void* stream);
