@@ -88,7 +88,6 @@ def _time_launches(run, dev, iters: int) -> float:
 def gemm_roofline(model: DiT, B: int, iters: int = 20):
     """Live HIP-event timing of the dominant kernel (QKV projection GEMM, f5_gemm_kernel<EPI_QKV_ROPE>) at the
     bench shape: M = 2*B*N rows (cond + null), K = 1024, N = 3072."""
-    import ctypes as C
     from f5_tts_mlx_amd import engine as E
     lib, dev = E.load_library(), model.device
     M, D, H = 2 * B * N_FRAMES, 1024, 16

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import math
 from pathlib import Path
-from typing import Callable, Dict, List, Literal, Optional, Union
+from typing import Callable, List, Literal, Optional, Union
 
 import numpy as np
 import torch
@@ -22,7 +22,7 @@ from .dit import DiT
 from .rng import mlx_like_normal
 from .utils import (default, exists, fetch_from_hub, lens_to_mask, list_str_to_idx, list_str_to_tensor,
                     mask_from_frac_lengths)
-from .weights import F5TTS_335M, convert_upstream_weights, dequantize_mlx_checkpoint
+from .weights import convert_upstream_weights, dequantize_mlx_checkpoint
 
 # ode solvers -- generic host versions with the reference's semantics (cfm.py:38-122); the engine has
 # the same three schemes fused with the CFG combine (csrc/rowops.hip: ode_stage_kernel)

@@ -9,7 +9,7 @@ Every layer is one HIP kernel launch through the C ABI (`f5_op_*`); Python only 
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -7,7 +7,6 @@ is missing or a call fails, this module raises.
 from __future__ import annotations
 
 import ctypes as C
-import os
 from pathlib import Path
 from typing import Dict, Optional, Sequence
 

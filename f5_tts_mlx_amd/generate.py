@@ -12,7 +12,6 @@ import datetime
 import pkgutil
 import re
 import sys
-from pathlib import Path
 from typing import Literal, Optional
 
 import numpy as np

@@ -12,8 +12,7 @@ Python-level module tree.
 """
 from __future__ import annotations
 
-import ctypes as C
-from typing import Dict, Optional
+from typing import Dict
 
 import numpy as np
 import torch

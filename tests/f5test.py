@@ -1,7 +1,6 @@
 """Shared helpers for the parity tests (the oracle is imported here and ONLY under tests/)."""
 from __future__ import annotations
 
-import ctypes as C
 import os
 import sys
 

@@ -1,7 +1,6 @@
 """Multi-GPU path on CPU: shard arithmetic + the weight-broadcast / output-gather protocol under gloo (world_size 2)."""
 import os
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

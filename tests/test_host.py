@@ -12,7 +12,7 @@ import torch
 from f5test import O, ROOT, TINY, F5TTS_335M, synthetic_weights
 from f5_tts_mlx_amd import engine as E
 from f5_tts_mlx_amd import utils as U
-from f5_tts_mlx_amd.cfm import (F5TTS, odeint_euler, odeint_midpoint, odeint_rk4, prepare_lengths, time_grid)
+from f5_tts_mlx_amd.cfm import (odeint_euler, odeint_midpoint, odeint_rk4, prepare_lengths, time_grid)
 from f5_tts_mlx_amd.rng import mlx_like_normal, threefry2x32
 from f5_tts_mlx_amd.weights import check_weights, convert_upstream_weights, num_params, param_specs
 

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from f5test import DEV, E, O, TINY, F5TTS_335M, report, synth_inputs, synthetic_weights
-from f5_tts_mlx_amd.cfm import F5TTS, time_grid
+from f5_tts_mlx_amd.cfm import F5TTS
 from f5_tts_mlx_amd.dit import DiT
 
 pytestmark = pytest.mark.gpu
@@ -184,7 +184,6 @@ def test_full_size_forward_parity():
 # vocoder + full wave path
 # ------------------------------------------------------------------------------------------------
 def test_istft_op_matches_torch_istft():
-    import ctypes as C
     lib = E.load_library()
     r = np.random.default_rng(2)
     N = 37

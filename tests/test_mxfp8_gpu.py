@@ -1,6 +1,4 @@
 """MX-fp8 path (BASELINE configs[4]): quantiser, 256x256x128 MX GEMM and its epilogues against the MX oracle."""
-import ctypes as C
-
 import numpy as np
 import pytest
 import torch
