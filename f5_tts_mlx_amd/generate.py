@@ -145,35 +145,42 @@ def generate(
     return wave
 
 
+# command line: the reference's flags and defaults (generate.py:248-362), table driven
+_CLI = (
+    ("--model", str, "lucasnewman/f5-tts-mlx", "checkpoint: hub name or local directory"),
+    ("--text", str, None, "what to say; read from stdin when omitted"),
+    ("--duration", float, None, "total length (reference + generated) in seconds"),
+    ("--estimate-duration", bool, False, "derive the length from the reference audio and the text sizes"),
+    ("--ref-audio", str, None, "24 kHz mono WAV to clone (default: the bundled sample)"),
+    ("--ref-text", str, None, "transcript of --ref-audio"),
+    ("--output", str, None, "WAV file to write"),
+    ("--steps", int, 8, "ODE grid points (steps - 1 solver updates)"),
+    ("--cfg", float, 2.0, "classifier-free guidance strength"),
+    ("--sway-coef", float, -1.0, "sway-sampling coefficient of the time grid"),
+    ("--speed", float, 1.0, "speaking-rate factor used by the duration heuristics"),
+    ("--seed", int, None, "noise seed"),
+)
+
+
 def main(argv=None):
-    parser = argparse.ArgumentParser(description="Generate audio from text using f5-tts on MI355X")
-    parser.add_argument("--model", type=str, default="lucasnewman/f5-tts-mlx", help="Name or local path of the model to use")
-    parser.add_argument("--text", type=str, default=None, help="Text to generate speech from (leave blank to input via stdin)")
-    parser.add_argument("--duration", type=float, default=None, help="Duration of the generated audio in seconds")
-    parser.add_argument("--estimate-duration", type=bool, default=False, help="Estimate duration from the reference audio")
-    parser.add_argument("--ref-audio", type=str, default=None, help="Path to the reference audio file")
-    parser.add_argument("--ref-text", type=str, default=None, help="Text spoken in the reference audio")
-    parser.add_argument("--output", type=str, default=None, help="Path to save the generated audio output")
-    parser.add_argument("--steps", type=int, default=8, help="Number of steps to take when sampling the neural ODE")
-    parser.add_argument("--method", type=str, default="rk4", choices=["euler", "midpoint", "rk4"], help="ODE method")
-    parser.add_argument("--cfg", type=float, default=2.0, help="Strength of classifer free guidance")
-    parser.add_argument("--sway-coef", type=float, default=-1.0, help="Coefficient for sway sampling")
-    parser.add_argument("--speed", type=float, default=1.0, help="Speed factor for the duration heuristic")
-    parser.add_argument("--seed", type=int, default=None, help="Seed for noise generation")
-    parser.add_argument("--q", type=int, default=None, choices=[4, 8], help="(MLX-only) quantized checkpoints")
-    args = parser.parse_args(argv)
+    ap = argparse.ArgumentParser(description="F5-TTS text to speech on MI355X (same flags as f5_tts_mlx.generate)")
+    for flag, kind, dflt, doc in _CLI:
+        ap.add_argument(flag, type=kind, default=dflt, help=doc)
+    ap.add_argument("--method", default="rk4", choices=("euler", "midpoint", "rk4"), help="ODE solver")
+    ap.add_argument("--q", type=int, default=None, choices=(4, 8), help="load the MLX 4/8-bit checkpoint (expanded to fp32 on load)")
+    ns = ap.parse_args(argv)
 
-    if args.text is None:
-        if not sys.stdin.isatty():
-            args.text = sys.stdin.read()
-        else:
+    text = ns.text
+    if text is None:
+        if sys.stdin.isatty():
             print("Please enter the text to generate:")
-            args.text = input("> ")
+            text = input("> ")
+        else:
+            text = sys.stdin.read()
 
-    generate(generation_text=args.text, duration=args.duration, estimate_duration=args.estimate_duration, model_name=args.model,
-             ref_audio_path=args.ref_audio, ref_audio_text=args.ref_text, steps=args.steps, method=args.method,
-             cfg_strength=args.cfg, sway_sampling_coef=args.sway_coef, speed=args.speed, seed=args.seed,
-             quantization_bits=args.q, output_path=args.output)
+    generate(text, duration=ns.duration, estimate_duration=ns.estimate_duration, model_name=ns.model, ref_audio_path=ns.ref_audio,
+             ref_audio_text=ns.ref_text, steps=ns.steps, method=ns.method, cfg_strength=ns.cfg, sway_sampling_coef=ns.sway_coef,
+             speed=ns.speed, seed=ns.seed, quantization_bits=ns.q, output_path=ns.output)
 
 
 if __name__ == "__main__":

@@ -91,53 +91,58 @@ def list_str_to_idx(text: List[Union[str, List[str]]], vocab_char_map: Dict[str,
 
 # convert char to pinyin
 
-def convert_char_to_pinyin(text_list: List[str], polyphone: bool = True) -> List[List[str]]:
-    """utils.py:139-173.  The reference segments with jieba and romanises Chinese with pypinyin; neither
-    is installable here, so pure single-byte text takes the reference's own ASCII branch (segmentation
-    does not change the output for such text apart from the word-boundary space rule, reproduced below)
-    and text with multi-byte characters needs the optional dependencies."""
-    final_text_list = []
-    zh_quote_trans = str.maketrans({"“": '"', "”": '"', "‘": "'", "’": "'"})
-    custom_trans = str.maketrans({";": ","})
-    try:  # optional, identical to the reference when available
+_ZH_PUNCT = "。，、；：？！《》【】—…"
+_QUOTES = str.maketrans({"“": '"', "”": '"', "‘": "'", "’": "'"})     # librispeech test-clean carries zh quotes
+_OOV = str.maketrans({";": ","})
+
+
+def _text_backends():
+    """(segmenter, romaniser): jieba + pypinyin when importable (what the reference uses), else the single-byte emulation."""
+    try:
         import jieba  # type: ignore
         from pypinyin import Style, lazy_pinyin  # type: ignore
         jieba.setLogLevel(20)
+        return (lambda t: list(jieba.cut(t))), (lambda t: lazy_pinyin(t, style=Style.TONE3, tone_sandhi=True))
     except Exception:  # pragma: no cover - environment dependent
-        jieba = None
+        return None, None
+
+
+def convert_char_to_pinyin(text_list: List[str], polyphone: bool = True) -> List[List[str]]:
+    """utils.py:139-173: token list per text — single-byte runs character by character (a space is inserted before a
+    multi-character run unless the previous token is one of ` :'"`), pure-CJK runs as tone-numbered pinyin syllables each preceded
+    by a space, mixed runs character by character.  jieba / pypinyin are not installable here: without them single-byte text
+    goes through `_ascii_segments` (jieba's behaviour on such text) and anything else raises."""
+    segment, romanise = _text_backends()
+    result = []
     for text in text_list:
-        char_list: List[str] = []
-        text = text.translate(zh_quote_trans).translate(custom_trans)
-        if jieba is None:
-            if len(bytes(text, "UTF-8")) != len(text):
+        text = text.translate(_QUOTES).translate(_OOV)
+        if segment is None:
+            if len(text.encode("utf-8")) != len(text):
                 raise RuntimeError("convert_char_to_pinyin: non single-byte text needs jieba + pypinyin (not installed)")
-            segs = _ascii_segments(text)
+            pieces = _ascii_segments(text)
         else:
-            segs = list(jieba.cut(text))
-        for seg in segs:
-            seg_byte_len = len(bytes(seg, "UTF-8"))
-            if seg_byte_len == len(seg):  # pure alphabets and symbols
-                if char_list and seg_byte_len > 1 and char_list[-1] not in " :'\"":
-                    char_list.append(" ")
-                char_list.extend(seg)
-            elif polyphone and seg_byte_len == 3 * len(seg):  # pure chinese characters
-                seg = lazy_pinyin(seg, style=Style.TONE3, tone_sandhi=True)
-                for c in seg:
-                    if c not in "。，、；：？！《》【】—…":
-                        char_list.append(" ")
-                    char_list.append(c)
-            else:  # mixed
-                for c in seg:
-                    if ord(c) < 256:
-                        char_list.extend(c)
+            pieces = segment(text)
+        toks: List[str] = []
+        for piece in pieces:
+            width = len(piece.encode("utf-8"))
+            if width == len(piece):                                   # letters, digits, ascii symbols
+                if toks and width > 1 and toks[-1] not in " :'\"":
+                    toks.append(" ")
+                toks += list(piece)
+            elif polyphone and width == 3 * len(piece):               # CJK only
+                for syllable in romanise(piece):
+                    if syllable not in _ZH_PUNCT:
+                        toks.append(" ")
+                    toks.append(syllable)
+            else:                                                     # mixed
+                for ch in piece:
+                    if ord(ch) < 256 or ch in _ZH_PUNCT:
+                        toks.append(ch)
                     else:
-                        if c not in "。，、；：？！《》【】—…":
-                            char_list.append(" ")
-                            char_list.extend(lazy_pinyin(c, style=Style.TONE3, tone_sandhi=True))
-                        else:
-                            char_list.append(c)
-        final_text_list.append(char_list)
-    return final_text_list
+                        toks.append(" ")
+                        toks += romanise(ch)
+        result.append(toks)
+    return result
 
 
 def _ascii_segments(text: str) -> List[str]:

@@ -196,3 +196,30 @@ def test_sample_duration_clamps_match_reference_code(ref_model):
     assert aux["duration"].tolist() == g["final_durations"].tolist() and aux["lens"].tolist() == [14, 11]
     assert float((traj - torch.from_numpy(g["traj"])).abs().max()) < TRAJ_TOL
     assert float((out - torch.from_numpy(g["out"])).abs().max()) < TRAJ_TOL
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/f5_tts_mlx"), reason="reference checkout not present (GPU box)")
+def test_text_front_end_matches_reference_code_live():
+    """convert_char_to_pinyin / split_sentences / estimated_duration of the package vs the reference's own functions (live, over
+    the shim; jieba's segmentation of single-byte text is the package's emulation on both sides)"""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')
+from oracle import mlx_shim; mx, nn = mlx_shim.install()
+from f5_tts_mlx_amd import utils as U, generate as G
+sys.modules['jieba'].cut = U._ascii_segments
+import f5_tts_mlx.utils as RU, f5_tts_mlx.generate as RG
+texts = ["Some call me nature, others call me mother nature. Hello;world", "“q” ‘x’", "x,yz a:b 'cd' \"ef\" 3.5%% done; ok",
+         "", "a", " ab  cd ", "it's 12:30pm - really?!", "One fish. Two fish! Red fish", "no terminator"]
+for t in texts:
+    assert RU.convert_char_to_pinyin([t]) == U.convert_char_to_pinyin([t]), t
+    assert RG.split_sentences(t) == G.split_sentences(t), t
+audio = np.zeros(127987, np.float32)
+for ref_text, gen_text, speed in (("Some call me nature.", "Hello there; general Kenobi", 1.3), ("abc", "。，、；：？！ x", 1.0)):
+    assert RG.estimated_duration(mx.array(audio), ref_text, gen_text, speed) == G.estimated_duration(audio, ref_text, gen_text, speed)
+print('LIVE-OK')
+""" % (ROOT,)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "LIVE-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
