@@ -192,7 +192,10 @@ def _build_nn(mx) -> types.ModuleType:
                 leaf = parts[-1]
                 if strict and not hasattr(obj, leaf):
                     raise ValueError(f"load_weights: no parameter {name}")
-                setattr(obj, leaf, _wrap(np.asarray(value)))
+                new = _wrap(np.asarray(value))
+                if strict and hasattr(obj, leaf) and tuple(np.shape(getattr(obj, leaf))) != tuple(new.shape):
+                    raise ValueError(f"load_weights: {name} has shape {tuple(new.shape)}, the module expects {tuple(np.shape(getattr(obj, leaf)))}")
+                setattr(obj, leaf, new)
             return self
 
     class Linear(Module):

@@ -223,3 +223,61 @@ print('LIVE-OK')
 """ % (ROOT,)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "LIVE-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/f5_tts_mlx"), reason="reference checkout not present (GPU box)")
+def test_oracle_vs_reference_code_live_fuzz():
+    """Live, build container only: the reference's DiT / sample run over the shim on several random small configurations (widths,
+    depths, heads, text-conv depth incl. 0, batch, lengths, ragged masks, solvers, CFG on/off) against the oracle on the same
+    weights and inputs.  Complements the committed vectors, which are one configuration."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, '/root/reference'); sys.path.insert(0, %r)
+import make_reference_golden as M
+from oracle import f5_oracle as O
+mx = M.mx
+worst = 0.0
+for case in range(6):
+    r = np.random.default_rng(100 + case)
+    heads = int(r.choice([2, 4, 8]))
+    cfg = M.DiTConfig(dim=64 * heads, depth=int(r.integers(1, 4)), heads=heads, dim_head=64, ff_mult=int(r.choice([2, 4])),
+                      mel_dim=100, text_num_embeds=int(r.integers(20, 90)), text_dim=int(r.choice([64, 128])),
+                      conv_layers=int(r.choice([0, 1, 3])), conv_pos_groups=16)
+    w = M.synthetic_weights(cfg, seed=200 + case)
+    model = M.build_reference_model(cfg, w)
+    orc = O.DiTOracle(cfg, w, dtype=torch.float32)
+    B, n_ref = int(r.integers(1, 4)), int(r.integers(5, 20))
+    durs = np.sort(r.integers(n_ref + 6, n_ref + 40, B))[::-1].astype(np.int32).copy()
+    nt = int(r.integers(3, n_ref + 10))
+    cond = r.standard_normal((B, n_ref, 100)).astype(np.float32)
+    text = r.integers(0, cfg.text_num_embeds, (B, nt)).astype(np.int32)
+    if B > 1:
+        text[-1, max(1, nt - 3):] = -1
+    lens = r.integers(max(1, n_ref - 4), n_ref + 1, B).astype(np.int32)
+    method = ["euler", "midpoint", "rk4"][case %% 3]
+    cfg_strength = 0.0 if case == 4 else 2.0
+    sway = None if case == 5 else -1.0
+    # final durations follow cfm.py:301-303,317-319; the noise is drawn per element with those widths
+    text_lens = (text != -1).sum(-1)
+    final = np.maximum(np.maximum(text_lens, lens) + 1, durs)
+    z = [r.standard_normal((100, int(d))).astype(np.float32) for d in final]
+    with M.injected_random(normal=z):
+        out, traj = model.sample(mx.array(cond), mx.array(text), mx.array(durs), lens=mx.array(lens), steps=3, method=method,
+                                 cfg_strength=cfg_strength, sway_sampling_coef=sway, seed=1)
+    y0 = torch.zeros((B, int(final.max()), 100))
+    for i, zi in enumerate(z):
+        y0[i, :zi.shape[1]] = torch.from_numpy(zi.T)
+    o_out, o_traj = O.sample(orc, torch.from_numpy(cond), torch.from_numpy(text), torch.from_numpy(durs), lens=torch.from_numpy(lens),
+                             steps=3, method=method, cfg_strength=cfg_strength, sway_sampling_coef=sway, y0=y0)
+    ref = torch.from_numpy(np.asarray(traj, dtype=np.float32))
+    assert ref.shape == o_traj.shape, (case, ref.shape, o_traj.shape)
+    err = float((o_traj - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    worst = max(worst, err)
+    assert err < 2e-4, (case, err, cfg)
+print('LIVE-OK worst', worst)
+""" % (ROOT, os.path.join(ROOT, "tests"), GOLDEN)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert "LIVE-OK" in r.stdout, (r.stdout[-800:], r.stderr[-3000:])
+    print(r.stdout.strip().splitlines()[-1])
