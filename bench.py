@@ -5,17 +5,25 @@ A "step" = one `F5TTS.sample()` call (32-point Euler = 31 updates = 62 DiT forwa
 batch of synthetic 10 s utterances (N = 937 mel frames, SURVEY.md §8(d) inputs), inputs resident in
 HBM, output = final mel on device.  value = mel frames produced per second, whole job.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|bf16x3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision f16|bf16|bf16x3|mxfp8]
 
-Multi-GPU (utterances are independent): one process per GPU under torch.distributed.run,
-weights generated on rank 0 and replicated with ONE RCCL broadcast of the weights arena, every rank
-samples its own B utterances, no data-path collective ("scaling": "weak").
+Precision: the headline mode is "f16" (IEEE-half MFMA operands, fp32 everywhere else), the one-pass mode that meets the
+1e-3 mel-L1 parity gate; the line carries `parity_l1`, the measured distance of the TIMED configuration's output from the fp32
+oracle's committed answer for this very workload (tests/golden/full_b1_euler32.npz).  "bf16" (BASELINE's label) is reported
+as a sub-record together with its parity figure, which is outside the gate.
+
+Multi-GPU (utterances are independent): `--gpus N` with no launcher environment re-executes itself under
+`torch.distributed.run --nproc-per-node N` (rendezvous on 127.0.0.1); under a launcher (WORLD_SIZE set) it is one rank.  One
+process per GPU, weights generated on rank 0 and replicated with ONE RCCL broadcast of the weights arena, every rank samples
+its own B utterances, no data-path collective ("scaling": "weak").  `--dry-run` runs the same launch / barrier / reduce /
+report skeleton on CPU over gloo without touching the engine (what the CPU test suite exercises).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -26,16 +34,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from f5_tts_mlx_amd.audio import log_mel_spectrogram  # noqa: E402
-from f5_tts_mlx_amd.cfm import F5TTS, time_grid  # noqa: E402
-from f5_tts_mlx_amd.dit import DiT  # noqa: E402
-from f5_tts_mlx_amd.weights import F5TTS_335M, synthetic_weights  # noqa: E402
-
 N_FRAMES = 937            # int(10.0 * 93.75), generate.py:23,163
 REF_SAMPLES = 72_000      # 3.0 s reference audio -> 281 mel frames
 NT = 160
 ODE_POINTS = 32
-BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak, MI355X_MICROARCH.md
+FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (MX) MFMA peak, MI355X_MICROARCH.md
+PARITY_TOL = 1e-3
+GOLDEN = os.path.join(ROOT, "tests", "golden", "full_b1_euler32.npz")
+DTYPE_TEXT = {
+    "f16": "f16 (IEEE-half MFMA operands, fp32 accumulate / residual stream / LayerNorm / softmax state; meets the 1e-3 gate)",
+    "bf16": "bf16 (bfloat16 MFMA operands; outside the 1e-3 parity gate, see parity_l1)",
+    "bf16x3": "bf16x3 (split-bf16 operands, 3 MFMA passes, fp32-class)",
+    "mxfp8": "mxfp8 (OCP e4m3 + E8M0 block scales for the four per-block GEMMs; attention and the rest bf16)",
+}
 
 
 def flops_forward(N: int, hoisted: bool) -> float:
@@ -51,19 +63,27 @@ def flops_forward(N: int, hoisted: bool) -> float:
     return blocks + conv + out + N * 2 * 712 * 1024 + ada + text
 
 
+def synth_waves(B: int, first: int) -> np.ndarray:
+    return np.stack([np.random.default_rng(1234 + i).standard_normal(REF_SAMPLES).astype(np.float32) * np.float32(0.1)
+                     for i in range(first, first + B)])
+
+
 def synth_batch(B: int, first: int, device):
-    conds, texts, y0s = [], [], []
-    for i in range(first, first + B):
-        wave = (np.random.default_rng(1234 + i).standard_normal(REF_SAMPLES).astype(np.float32) * np.float32(0.1))
-        conds.append(log_mel_spectrogram(torch.from_numpy(wave).to(device))[0])
-        texts.append(np.random.default_rng(2345 + i).integers(0, 2545, NT).astype(np.int32))
-        y0s.append(np.random.default_rng(3456 + i).standard_normal((100, N_FRAMES)).astype(np.float32).T)
-    cond = torch.stack(conds)                                            # (B, 281, 100) on device
-    text = torch.from_numpy(np.stack(texts)).to(device)
-    y0 = torch.from_numpy(np.ascontiguousarray(np.stack(y0s))).to(device)
-    return cond, text, y0
+    """SURVEY §8(d) inputs for utterances [first, first + B): reference mel (through the HIP mel front-end, one launch for the
+    batch), text ids, injected noise; also returns the raw reference waves (device) for the wave -> wave timing."""
+    from f5_tts_mlx_amd.audio import log_mel_spectrogram
+    waves = torch.from_numpy(synth_waves(B, first)).to(device)
+    cond = log_mel_spectrogram(waves)                                    # (B, 281, 100) on device
+    text = torch.from_numpy(np.stack([np.random.default_rng(2345 + i).integers(0, 2545, NT).astype(np.int32)
+                                      for i in range(first, first + B)])).to(device)
+    y0 = torch.from_numpy(np.ascontiguousarray(np.stack(
+        [np.random.default_rng(3456 + i).standard_normal((100, N_FRAMES)).astype(np.float32).T for i in range(first, first + B)]))).to(device)
+    return cond, text, y0, waves
 
 
+# ------------------------------------------------------------------------------------------------
+# roofline: live HIP-event timing of the dominant kernels at the bench shape
+# ------------------------------------------------------------------------------------------------
 def _time_launches(run, dev, iters: int) -> float:
     """Average duration (ms) of `iters` back-to-back launches of `run`, replayed from a hipGraph (as the kernel runs inside
     sample(): no host launch gaps), timed with HIP events on the stream the graph is launched on."""
@@ -85,54 +105,106 @@ def _time_launches(run, dev, iters: int) -> float:
     return e0.elapsed_time(e1) / iters
 
 
-def gemm_roofline(model: DiT, B: int, iters: int = 20):
-    """Live HIP-event timing of the dominant kernel (QKV projection GEMM, f5_gemm_kernel<EPI_QKV_ROPE>) at the
-    bench shape: M = 2*B*N rows (cond + null), K = 1024, N = 3072."""
-    from f5_tts_mlx_amd import engine as E
-    lib, dev = E.load_library(), model.device
-    M, D, H = 2 * B * N_FRAMES, 1024, 16
-    npad = (N_FRAMES + 63) // 64 * 64
-    nseg = 3 if model.precision == "bf16x3" else 1
-    g = torch.Generator(device="cpu").manual_seed(0)
-    if model.precision == "mxfp8":
-        return gemm_roofline_f8(lib, E, dev, M, D, g, iters)
-    # operand statistics of the real workload (activations ~N(0,1), weights ~N(0,1/fan_in)): data toggling sets the
-    # DVFS clock, so a microbenchmark on hotter random data would not agree with the in-graph rocprof average
-    mk = lambda std, *s: (torch.randn(*s, generator=g) * std).to(dev).to(torch.bfloat16)
-    a_hi, a_lo, w_hi, w_lo = mk(1.0, M, D), mk(0.004, M, D), mk(D ** -0.5, 3 * D, D), mk(1e-4, 3 * D, D)
-    bias = torch.zeros(3 * D, device=dev)
-    cos_t, sin_t = torch.ones(N_FRAMES, 32, device=dev), torch.zeros(N_FRAMES, 32, device=dev)
-    qk = [torch.empty(M, 2 * D, dtype=torch.bfloat16, device=dev) for _ in range(2)]
-    vt = [torch.zeros(2 * B * H, 64, npad, dtype=torch.bfloat16, device=dev) for _ in range(2)]
-    lo = (lambda t: t) if nseg == 3 else (lambda t: None)      # plain bf16 mode has no "lo" operands / outputs
-    def run():
-        E.check(lib.f5_op_qkv_rope(E.ptr(a_hi), E.ptr(lo(a_lo)), E.ptr(w_hi), E.ptr(lo(w_lo)), E.ptr(bias), E.ptr(cos_t),
-                                   E.ptr(sin_t), E.ptr(qk[0]), E.ptr(lo(qk[1])), E.ptr(vt[0]), E.ptr(lo(vt[1])), 2 * B, N_FRAMES,
-                                   npad, H, D, nseg, E.stream_ptr(dev)))
-    ms = _time_launches(run, dev, iters)
-    flops = 2.0 * M * D * 3 * D                      # algorithmic: one (hi*hi) pass, whatever the precision mode
-    achieved = flops / (ms * 1e-3) / 1e12
-    shape = f"M={M} N={3 * D} K={D}"
-    traffic = None
-    try:   # HBM/fabric bytes per launch from the last committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), if it is this shape
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["qkv_gemm"]
-        if pm.get("shape") == shape and pm.get("precision") == model.precision:
-            traffic = pm["fetch_bytes_corrected_x2"] + pm["write_bytes"]
+def _pmc_traffic(key: str, shape: str, precision: str):
+    """HBM/fabric bytes per launch from the last committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), if it is this shape."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key]
+        if pm.get("shape") == shape and pm.get("precision") == precision:
+            return pm["fetch_bytes_corrected_x2"] + pm["write_bytes"]
     except Exception:
         pass
-    return dict(bound="mfma", kernel="QKV projection GEMM + bias + RoPE + head split (f5_gemm*_kernel<EPI_QKV_ROPE>)", shape=shape,
-                avg_launch_ms=ms, achieved=achieved, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / BF16_PEAK_TFLOPS,
-                traffic=traffic, traffic_unit="bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
-                algorithmic_bytes=2 * M * D + 2 * 3 * D * D + 2 * M * 3 * D)
+    return None
 
 
-FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (MX) MFMA peak, MI355X_MICROARCH.md
+def kernel_rooflines(precision: str, dev, B: int, iters: int = 20):
+    """Live timing of the five kernels that make up a DiT block (>= 95 % of sample() time), each launched through its C-ABI op entry
+    point at the bench shape M = 2*B*N rows (cond + null branch), from a hipGraph, HIP events around `iters` launches.
+    `share` = launches per block x average time / block total; the entry with the largest share is the dominant kernel."""
+    from f5_tts_mlx_amd import engine as E
+    lib = E.load_library()
+    M, D, FF, H = 2 * B * N_FRAMES, 1024, 2048, 16
+    npad = (N_FRAMES + 63) // 64 * 64
+    nseg = 3 if precision == "bf16x3" else 1
+    opd = E.operand_dtype(precision)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    # operand statistics of the real workload (activations ~N(0,1), weights ~N(0,1/fan_in)): data toggling sets the
+    # DVFS clock, so a microbenchmark on hotter random data would not agree with the in-graph rocprof average
+    mk = lambda std, *s: (torch.randn(*s, generator=g) * std).to(dev).to(opd)
+    lo = (lambda t: t) if nseg == 3 else (lambda t: None)      # one-pass modes have no "lo" operands / outputs
+    P, st = E.ptr, (lambda: E.stream_ptr(dev))
+    x1, x1l, x2, x2l = mk(1.0, M, D), mk(0.004, M, D), mk(1.0, M, FF), mk(0.004, M, FF)
+    wq, wql = mk(D ** -0.5, 3 * D, D), mk(1e-4, 3 * D, D)
+    wo, wol = mk(D ** -0.5, D, D), mk(1e-4, D, D)
+    w1, w1l = mk(D ** -0.5, FF, D), mk(1e-4, FF, D)
+    w2, w2l = mk(FF ** -0.5, D, FF), mk(1e-4, D, FF)
+    bq, b1, bd, gate = torch.zeros(3 * D, device=dev), torch.zeros(FF, device=dev), torch.zeros(D, device=dev), torch.full((D,), 0.5, device=dev)
+    cos_t, sin_t = torch.ones(N_FRAMES, 32, device=dev), torch.zeros(N_FRAMES, 32, device=dev)
+    qk = [torch.empty(M, 2 * D, dtype=opd, device=dev) for _ in range(2)]
+    vt = [torch.zeros(2 * B * H, 64, npad, dtype=opd, device=dev) for _ in range(2)]
+    ao = [torch.empty(M, D, dtype=opd, device=dev) for _ in range(2)]
+    ffh = [torch.empty(M, FF, dtype=opd, device=dev) for _ in range(2)]
+    xres = torch.zeros(M, D, device=dev)
+
+    def k_qkv():
+        E.check(lib.f5_op_qkv_rope(P(x1), P(lo(x1l)), P(wq), P(lo(wql)), P(bq), P(cos_t), P(sin_t), P(qk[0]), P(lo(qk[1])), P(vt[0]),
+                                   P(lo(vt[1])), 2 * B, N_FRAMES, npad, H, D, nseg, st()))
+
+    def k_attn():
+        import ctypes as C
+        E.check(lib.f5_op_attention(P(qk[0]), P(lo(qk[1])), P(vt[0]), P(lo(vt[1])), P(ao[0]), P(lo(ao[1])), P(None), 2 * B, H, N_FRAMES,
+                                    npad, D, C.c_float(0.125), int(nseg == 3), st()))
+
+    def k_out():
+        E.check(lib.f5_op_gemm_resid_gate(P(x1), P(lo(x1l)), P(wo), P(lo(wol)), P(bd), P(gate), P(None), P(xres), M, D, D, D, D, D, nseg, st()))
+
+    def k_ff1():
+        E.check(lib.f5_op_gemm(P(x1), P(lo(x1l)), P(w1), P(lo(w1l)), P(b1), P(None), P(ffh[0]), P(lo(ffh[1])), M, FF, D, D, D, FF, nseg, 2, st()))
+
+    def k_ff2():
+        E.check(lib.f5_op_gemm_resid_gate(P(x2), P(lo(x2l)), P(w2), P(lo(w2l)), P(bd), P(gate), P(None), P(xres), M, D, FF, FF, FF, D, nseg, st()))
+
+    specs = [
+        ("qkv_gemm", "QKV projection GEMM + bias + RoPE + head split (f5_gemm*_kernel<EPI_QKV_ROPE>)", k_qkv, 2.0 * M * D * 3 * D,
+         f"M={M} N={3 * D} K={D}", 2 * M * D + 2 * 3 * D * D + 2 * M * 3 * D),
+        ("attention", "flash attention, 16 heads x 64 (f5_attn*_kernel)", k_attn, 4.0 * 2 * B * H * N_FRAMES * N_FRAMES * 64,
+         f"B={2 * B} H={H} N={N_FRAMES} d=64", 2 * 3 * M * D + 2 * M * D),
+        ("out_proj_gemm", "attention out-projection GEMM + gated fp32 residual update (f5_gemm*_kernel<EPI_RESID_GATE>, K=1024)", k_out,
+         2.0 * M * D * D, f"M={M} N={D} K={D}", 2 * M * D + 2 * D * D + 8 * M * D),
+        ("ff1_gemm", "FF1 GEMM + bias + GELU-tanh (f5_gemm*_kernel<EPI_GELU_TANH>)", k_ff1, 2.0 * M * D * FF, f"M={M} N={FF} K={D}",
+         2 * M * D + 2 * D * FF + 2 * M * FF),
+        ("ff2_gemm", "FF2 GEMM + gated fp32 residual update (f5_gemm*_kernel<EPI_RESID_GATE>, K=2048)", k_ff2, 2.0 * M * FF * D,
+         f"M={M} N={D} K={FF}", 2 * M * FF + 2 * D * FF + 8 * M * D),
+    ]
+    out = []
+    with E.operand_type(precision):
+        k_qkv()                                        # q / k / V^T hold real values before attention is timed
+        for key, name, fn, flops, shape, alg_bytes in specs:
+            ms = _time_launches(fn, dev, iters)
+            ach = flops / (ms * 1e-3) / 1e12
+            out.append(dict(key=key, bound="mfma", kernel=name, shape=shape, avg_launch_ms=ms, achieved=ach, peak=BF16_PEAK_TFLOPS,
+                            unit="TFLOP/s", frac=ach / BF16_PEAK_TFLOPS, traffic=_pmc_traffic(key, shape, precision),
+                            traffic_unit="bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", algorithmic_bytes=alg_bytes,
+                            algorithmic_flops=flops))
+    total = sum(k["avg_launch_ms"] for k in out)
+    for k in out:
+        k["share_of_block"] = k["avg_launch_ms"] / total
+    # the residual-update GEMM template runs twice per block (out-proj + FF2): as ONE kernel symbol it is the dominant entry of the
+    # rocprofv3 --stats CSV at batch 1; report the symbol-level share too
+    sym = {"f5_gemm*_kernel<EPI_RESID_GATE>": sum(k["avg_launch_ms"] for k in out if k["key"] in ("out_proj_gemm", "ff2_gemm")) / total}
+    for k in out:
+        if k["key"] not in ("out_proj_gemm", "ff2_gemm"):
+            sym[k["key"]] = k["share_of_block"]
+    return out, sym
 
 
-def gemm_roofline_f8(lib, E, dev, M, D, g, iters):
+def gemm_roofline_f8(dev, B: int, iters: int = 20):
     """mxfp8 mode: the QKV projection runs on f5_gemm256f8_kernel (MX-fp8 operands, v_mfma_scale_f32_32x32x64_f8f6f4).  Timed
     here through f5_op_gemm_f8 with the plain bf16-output epilogue (same main loop and output bytes; the RoPE / head-split
     epilogue of the in-engine launch is not exported as an op), operands quantised from workload-like data."""
+    from f5_tts_mlx_amd import engine as E
+    lib = E.load_library()
+    M, D = 2 * B * N_FRAMES, 1024
+    g = torch.Generator(device="cpu").manual_seed(0)
     a = (torch.randn(M, D, generator=g)).to(dev)
     w = (torch.randn(3 * D, D, generator=g) * D ** -0.5).to(dev)
     a8, asc = torch.empty(M, D, dtype=torch.uint8, device=dev), torch.empty(M, D // 32, dtype=torch.uint8, device=dev)
@@ -142,16 +214,21 @@ def gemm_roofline_f8(lib, E, dev, M, D, g, iters):
     E.check(lib.f5_op_quantize_mx(E.ptr(w), D, E.ptr(w8), D, E.ptr(wsc), 3 * D, D, st))
     bias = torch.zeros(3 * D, device=dev)
     out = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev)
+
     def run():
         E.check(lib.f5_op_gemm_f8(E.ptr(a8), E.ptr(asc), E.ptr(w8), E.ptr(wsc), E.ptr(bias), E.ptr(None), E.ptr(None), E.ptr(None),
                                   E.ptr(out), E.ptr(None), E.ptr(None), M, 3 * D, D, D, D, 3 * D, 1, E.stream_ptr(dev)))
     ms = _time_launches(run, dev, iters)
     achieved = 2.0 * M * D * 3 * D / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="QKV-shaped MX-fp8 GEMM + bias, bf16 out (f5_gemm256f8_kernel<EPI_BF16>)", shape=f"M={M} N={3 * D} K={D}",
-                avg_launch_ms=ms, achieved=achieved, peak=FP8_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / FP8_PEAK_TFLOPS,
-                traffic=None, traffic_unit="bytes/launch", algorithmic_bytes=M * D + 3 * D * D + (M + 3 * D) * D // 32 + 2 * M * 3 * D)
+    return dict(key="qkv_gemm_f8", bound="mfma", kernel="QKV-shaped MX-fp8 GEMM + bias, bf16 out (f5_gemm256f8_kernel<EPI_BF16>)",
+                shape=f"M={M} N={3 * D} K={D}", avg_launch_ms=ms, achieved=achieved, peak=FP8_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=achieved / FP8_PEAK_TFLOPS, traffic=None, traffic_unit="bytes/launch",
+                algorithmic_bytes=M * D + 3 * D * D + (M + 3 * D) * D // 32 + 2 * M * 3 * D)
 
 
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle; checker / baseline leg only)
+# ------------------------------------------------------------------------------------------------
 def _cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -168,6 +245,7 @@ def cpu_baseline(weights, budget_s: float = 25.0):
     fp32 DiT forwards at N=937 (B=1), first a short sweep over thread counts (one forward each), then the best setting is
     timed again; extrapolated to the 62 forwards of a 32-point Euler solve.  ~10-30 s of CPU work in total."""
     from oracle import f5_oracle as O   # checker / baseline leg only
+    from f5_tts_mlx_amd.weights import F5TTS_335M
     orc = O.DiTOracle(F5TTS_335M, weights)
     r = np.random.default_rng(0)
     x = torch.from_numpy(r.standard_normal((1, N_FRAMES, 100)).astype(np.float32))
@@ -202,114 +280,251 @@ def cpu_baseline(weights, budget_s: float = 25.0):
                 rtf=10.0 / (n_fwd * dt), host_cpus=ncpu, cpu_model=_cpu_model())
 
 
+# ------------------------------------------------------------------------------------------------
+# launch helpers
+# ------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(ngpus: int) -> None:
+    """`python bench.py --gpus N` with no launcher environment: become N ranks on this node (one per GPU) under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execve(sys.executable, cmd, env)
+
+
+def parity_against_golden(out_utt0: torch.Tensor, args) -> dict | None:
+    """mel L1 of utterance 0 of the timed configuration vs the fp32 oracle's committed answer (only this exact workload has one)."""
+    if not (args.method == "euler" and args.ode_points == ODE_POINTS and os.path.exists(GOLDEN)):
+        return None
+    g = np.load(GOLDEN)
+    l1 = float(np.abs(out_utt0.detach().cpu().numpy().astype(np.float64) - g["out"].astype(np.float64)).mean())
+    return dict(parity_l1=l1, parity_gate=PARITY_TOL, parity_ok=bool(l1 <= PARITY_TOL),
+                parity_ref="fp32 CPU oracle, tests/golden/full_b1_euler32.npz (bench utterance 0, 62 forwards)")
+
+
+def timed_samples(f5, cond, text, kw, steps, warmup, barrier):
+    out = None
+    for _ in range(warmup):
+        out, _ = f5.sample(cond, text, **kw)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out, _ = f5.sample(cond, text, **kw)
+    barrier()
+    return time.perf_counter() - t0, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU (BASELINE configs[1] = 1, configs[2] = 32)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "mxfp8"])
-    ap.add_argument("--vocoder", action="store_true", help="include the Vocos vocoder (random-init) in the timed region: mel -> waveform")
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "bf16x3", "mxfp8"])
+    ap.add_argument("--vocoder", action="store_true", help="put the Vocos vocoder (random-init) into the HEADLINE timed region")
     ap.add_argument("--config", default=None, choices=["c5"],
                     help="c5 = BASELINE configs[4]: MX-fp8 block GEMMs + Vocos, 16-point midpoint, batch 32")
     ap.add_argument("--method", default="euler")
     ap.add_argument("--ode-points", type=int, default=ODE_POINTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (batch 32, bf16, wave-to-wave RTF)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launch, barrier, reduce and report only (no engine)")
     args = ap.parse_args()
     if args.config == "c5":
         args.precision, args.vocoder, args.method, args.ode_points = "mxfp8", True, "midpoint", 16
         if args.batch == 1:
             args.batch = 32
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)                 # does not return
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
+    dist = None
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    device = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(device)
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     B = args.batch
 
-    model = DiT.from_config(F5TTS_335M, precision=args.precision, device=device)
+    def barrier():
+        if not args.dry_run:
+            torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        if not args.dry_run:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(x: float) -> float:
+        if not dist_on:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cpu" if args.dry_run else f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    if args.dry_run:
+        # same skeleton, no GPU: a "step" is a small CPU matmul; proves the N-rank launch path and the report fields
+        a = torch.randn(256, 256)
+        for _ in range(args.warmup):
+            a = torch.tanh(a @ a.T / 256)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            a = torch.tanh(a @ a.T / 256)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            ms = elapsed / args.steps * 1e3
+            print(json.dumps({"metric": "mel_frames_per_sec", "value": world * B * N_FRAMES / (ms * 1e-3), "unit": "mel-frames/s",
+                              "n_gpus": world, "gpus_arg": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "dry-run (CPU, gloo)",
+                              "data": "dry run: no engine, no GPU", "config": {"workload": "dry-run launch skeleton", "global_batch": world * B,
+                                                                              "seq_len": N_FRAMES, "parallelism": f"dp{world} (utterance sharding)"}}))
+        if dist_on:
+            dist.destroy_process_group()
+        return
+
+    from f5_tts_mlx_amd.cfm import F5TTS
+    from f5_tts_mlx_amd.dit import DiT
+    from f5_tts_mlx_amd.weights import F5TTS_335M, synthetic_weights
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+
+    def make_model(precision):
+        m = DiT.from_config(F5TTS_335M, precision=precision, device=device)
+        return m
+
+    model = make_model(args.precision)
     weights = None
     t_w = time.perf_counter()
     if rank == 0:
         weights = synthetic_weights(F5TTS_335M, seed=42)
         model.load_weights(weights)
+    bcast_ms = None
     if dist_on:
         from f5_tts_mlx_amd.dist import broadcast_weights
         bcast_ms = broadcast_weights(model.engine, src=0)
-    else:
-        bcast_ms = None
     load_s = time.perf_counter() - t_w
 
     vocoder = None
-    if args.vocoder:
+    if args.vocoder or not args.no_sub:
         from f5_tts_mlx_amd.vocos import Vocos, synthetic_vocos_weights
-        vocoder = Vocos(synthetic_vocos_weights(seed=7), device=device).decode
-    f5 = F5TTS(transformer=model, vocoder=vocoder)
-    cond, text, y0 = synth_batch(B, first=rank * B, device=device)
+        vocoder = Vocos(synthetic_vocos_weights(seed=7), precision=args.precision if args.precision != "mxfp8" else "bf16", device=device)
+    f5 = F5TTS(transformer=model, vocoder=vocoder.decode if args.vocoder else None)
+    cond, text, y0, waves = synth_batch(B, first=rank * B, device=device)
     kw = dict(duration=N_FRAMES, steps=args.ode_points, method=args.method, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0,
               use_graph=not args.no_graph)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out, _ = f5.sample(cond, text, **kw)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, _ = f5.sample(cond, text, **kw)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, out = timed_samples(f5, cond, text, kw, args.steps, args.warmup, barrier)
+    elapsed = max_over_ranks(elapsed)
     assert torch.isfinite(out).all()
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        frames = world * B * N_FRAMES
-        value = frames / (ms_per_step * 1e-3)
         per = {"euler": 1, "midpoint": 2, "rk4": 4}[args.method]
         n_fwd = 2 * per * (args.ode_points - 1)
-        exec_tflop = world * B * n_fwd * flops_forward(N_FRAMES, hoisted=True) / 1e12
-        ref_tflop = world * B * n_fwd * flops_forward(N_FRAMES, hoisted=False) / 1e12
-        roof = gemm_roofline(model, B)
+        fwd_exec, fwd_ref = flops_forward(N_FRAMES, hoisted=True), flops_forward(N_FRAMES, hoisted=False)
+
+        def summarize(ms_per_step, nb, nworld=1):
+            tf = nworld * nb * n_fwd * fwd_exec / 1e12 / (ms_per_step * 1e-3)
+            return dict(ms_per_step=ms_per_step, value=nworld * nb * N_FRAMES / (ms_per_step * 1e-3), unit="mel-frames/s",
+                        rtf_mel_only=nworld * nb * 10.0 / (ms_per_step * 1e-3), whole_path_tflops=tf,
+                        whole_path_frac_of_bf16_peak=tf / (nworld * BF16_PEAK_TFLOPS))
+
+        ms_per_step = elapsed / args.steps * 1e3
+        head = summarize(ms_per_step, B, world)
+        if args.precision == "mxfp8":
+            kernels, sym = [gemm_roofline_f8(device, B)], {}
+        else:
+            kernels, sym = kernel_rooflines(args.precision, device, B)
+        dominant = max(kernels, key=lambda k: k.get("share_of_block", 1.0))
+        if sym.get("f5_gemm*_kernel<EPI_RESID_GATE>", 0.0) >= max(sym.values(), default=0.0):
+            # the residual-update GEMM symbol (out-proj + FF2 launches) leads the rocprof CSV: report its heavier instance
+            dominant = max((k for k in kernels if k["key"] in ("out_proj_gemm", "ff2_gemm")), key=lambda k: k["share_of_block"])
         rec = {
-            "metric": "mel_frames_per_sec", "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "bf16x3": "bf16x3 (split-bf16 operands, fp32-class)",
-                      "mxfp8": "mxfp8 (OCP e4m3 + E8M0 block scales for the four per-block GEMMs; attention and the rest bf16)"}[args.precision],
+            "metric": "mel_frames_per_sec", "value": head["value"], "unit": "mel-frames/s", "n_gpus": world, "gpus_arg": args.gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE_TEXT[args.precision],
             "data": "synthetic (seeded random-init 335M weights, white-noise reference audio, random token ids)",
             "config": {"workload": f"F5-TTS 335M, {args.ode_points}-point {args.method} (={n_fwd} DiT forwards, CFG), "
                                    f"batch {B}/GPU x 10 s (N=937) utterances, hipGraph={not args.no_graph}"
                                    + (", + Vocos vocoder (mel -> waveform) in the timed region" if args.vocoder else ""),
                        "global_batch": world * B, "seq_len": N_FRAMES, "parallelism": f"dp{world} (utterance sharding)"},
-            "rtf": world * B * 10.0 / (ms_per_step * 1e-3),
-            # the reference's own definition (generate.py:183-189): seconds of GENERATED audio (reference trimmed off) per second
-            "rtf_generated_only": world * B * (N_FRAMES - REF_SAMPLES // 256) * 256 / 24000.0 / (ms_per_step * 1e-3),
-            "per_gpu_value": value / world,
-            "executed_tflop_per_step": exec_tflop, "reference_tflop_per_step": ref_tflop,
-            "whole_path_tflops": exec_tflop / (ms_per_step * 1e-3),
-            "whole_path_frac_of_bf16_peak": exec_tflop / (ms_per_step * 1e-3) / (world * BF16_PEAK_TFLOPS),
-            "weights_load_s": load_s, "weights_broadcast_ms": bcast_ms,
-            "roofline": roof,
+            "per_gpu_value": head["value"] / world,
+            "executed_tflop_per_step": world * B * n_fwd * fwd_exec / 1e12, "reference_tflop_per_step": world * B * n_fwd * fwd_ref / 1e12,
+            "whole_path_tflops": head["whole_path_tflops"], "whole_path_frac_of_bf16_peak": head["whole_path_frac_of_bf16_peak"],
+            "rtf_mel_only": head["rtf_mel_only"],
+            "weights_load_s": load_s, "weights_broadcast_ms": bcast_ms, "ranks_seen_by_rccl": world if dist_on else 1,
+            "roofline": dominant, "roofline_kernels": kernels, "roofline_symbol_shares": sym,
         }
+        par = parity_against_golden(out[0], args) if not args.vocoder else None
+        if par:
+            rec.update(par)
+
+        if world == 1 and not args.no_sub:
+            sub = {}
+            # (1) RTF as SURVEY §8(d) defines it: reference WAVE in -> mel front-end -> sample -> Vocos -> WAVE out
+            f5w = F5TTS(transformer=model, vocoder=vocoder.decode)
+
+            def wave_step():
+                c = f5w._mel_spec(waves)                                   # HIP mel front-end, one launch for the batch
+                return f5w.sample(c, text, **kw)[0]
+            for _ in range(1):
+                w_out = wave_step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                w_out = wave_step()
+            barrier()
+            ms_w = (time.perf_counter() - t0) / args.steps * 1e3
+            assert torch.isfinite(w_out).all()
+            rec["rtf"] = B * 10.0 / (ms_w * 1e-3)
+            # the reference's own definition (generate.py:183-189): seconds of GENERATED audio (reference trimmed off) per second
+            rec["rtf_generated_only"] = B * (N_FRAMES - REF_SAMPLES // 256) * 256 / 24000.0 / (ms_w * 1e-3)
+            sub["wave_to_wave"] = dict(ms_per_step=ms_w, includes="mel front-end + sample + Vocos vocoder (random-init weights)",
+                                       samples_out=int(w_out.numel()))
+            # (2) BASELINE configs[2]: batch 32 in the same precision (the MFMA-roofline configuration)
+            if B != 32:
+                c32, t32, y32, _ = synth_batch(32, first=0, device=device)
+                kw32 = dict(kw, y0=y32)
+                el, o32 = timed_samples(f5, c32, t32, kw32, 2, 1, barrier)
+                s32 = summarize(el / 2 * 1e3, 32)
+                p32 = parity_against_golden(o32[0], args)
+                if p32:
+                    s32.update(p32)
+                sub[f"b32_{args.precision}"] = s32
+                del c32, t32, y32, o32
+            # (3) the north-star's nominal dtype next to the parity-valid one
+            if args.precision != "bf16" and B == 1:
+                mb = make_model("bf16")
+                mb.load_weights(weights)
+                el, ob = timed_samples(F5TTS(transformer=mb), cond, text, kw, 3, 1, barrier)
+                sb = summarize(el / 3 * 1e3, B)
+                pb = parity_against_golden(ob[0], args)
+                if pb:
+                    sb.update(pb)
+                sub["b1_bf16"] = sb
+                del mb
+            rec["sub"] = sub
+        else:
+            rec["rtf"] = None if not args.vocoder else head["rtf_mel_only"]
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(rec))
     if dist_on:
+        barrier()
         dist.destroy_process_group()
 
 

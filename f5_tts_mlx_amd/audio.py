@@ -61,13 +61,15 @@ def _tables(device: torch.device, sample_rate: int, n_fft: int, n_mels: int):
 
 
 def log_mel_spectrogram(audio: torch.Tensor, sample_rate: int = 24_000, n_mels: int = 100, n_fft: int = 1024,
-                        hop_length: int = 256, padding: int = 0) -> torch.Tensor:
+                        hop_length: int = 256, padding: int = 0, device=None) -> torch.Tensor:
     """audio.py:162-210.  audio: [t] or [b, t] (device tensor or anything torch.as_tensor accepts).
     Returns (b, frames, n_mels) float32 on the GPU — the layout the reference code produces."""
     lib = _eng.load_library()
     audio = torch.as_tensor(audio)
-    if not audio.is_cuda:
-        audio = audio.to("cuda")
+    if device is not None:
+        audio = audio.to(device)
+    elif not audio.is_cuda:
+        audio = audio.to("cuda")                                       # host input and no device given: current GPU
     audio = audio.to(torch.float32)
     if audio.ndim == 1:
         audio = audio[None]
@@ -88,7 +90,8 @@ def log_mel_spectrogram(audio: torch.Tensor, sample_rate: int = 24_000, n_mels: 
 class MelSpec:
     """audio.py:213-230."""
 
-    def __init__(self, sample_rate=24_000, n_fft=1024, hop_length=256, n_mels=100):
+    def __init__(self, sample_rate=24_000, n_fft=1024, hop_length=256, n_mels=100, device=None):
+        self.device = device                # where host audio is moved to (the owning model's device); None = current GPU
         self.sample_rate = sample_rate
         self.n_fft = n_fft
         self.hop_length = hop_length
@@ -96,4 +99,4 @@ class MelSpec:
 
     def __call__(self, audio, **kwargs) -> torch.Tensor:
         return log_mel_spectrogram(audio, sample_rate=self.sample_rate, n_mels=self.n_mels, n_fft=self.n_fft,
-                                   hop_length=self.hop_length)
+                                   hop_length=self.hop_length, device=self.device)

@@ -24,52 +24,8 @@ from .utils import (default, exists, fetch_from_hub, lens_to_mask, list_str_to_i
                     mask_from_frac_lengths)
 from .weights import convert_upstream_weights, dequantize_mlx_checkpoint
 
-# ode solvers -- generic host versions with the reference's semantics (cfm.py:38-122); the engine has
-# the same three schemes fused with the CFG combine (csrc/rowops.hip: ode_stage_kernel)
-
-
-def odeint_euler(func, y0, t):
-    ys = [y0]
-    y_current = y0
-    for i in range(len(t) - 1):
-        t_current = t[i]
-        dt = t[i + 1] - t_current
-        k = func(t_current, y_current)
-        y_next = y_current + dt * k
-        ys.append(y_next)
-        y_current = y_next
-    return torch.stack(ys)
-
-
-def odeint_midpoint(func, y0, t):
-    ys = [y0]
-    y_current = y0
-    for i in range(len(t) - 1):
-        t_current = t[i]
-        dt = t[i + 1] - t_current
-        k1 = func(t_current, y_current)
-        mid = y_current + 0.5 * dt * k1
-        k2 = func(t_current + 0.5 * dt, mid)
-        y_next = y_current + dt * k2
-        ys.append(y_next)
-        y_current = y_next
-    return torch.stack(ys)
-
-
-def odeint_rk4(func, y0, t):
-    ys = [y0]
-    y_current = y0
-    for i in range(len(t) - 1):
-        t_current = t[i]
-        dt = t[i + 1] - t_current
-        k1 = func(t_current, y_current)
-        k2 = func(t_current + 0.5 * dt, y_current + 0.5 * dt * k1)
-        k3 = func(t_current + 0.5 * dt, y_current + 0.5 * dt * k2)
-        k4 = func(t_current + dt, y_current + dt * k3)
-        y_next = y_current + (dt / 6) * (k1 + 2 * k2 + 2 * k3 + k4)
-        ys.append(y_next)
-        y_current = y_next
-    return torch.stack(ys)
+# The three fixed-grid solvers (cfm.py:38-122) live in the engine, fused with the CFG combine (csrc/rowops.hip: ode_stage_kernel,
+# sequenced by csrc/engine.hip: run_sample_body); there is no host-side ODE loop.
 
 
 def time_grid(steps: int, sway_sampling_coef: Optional[float]) -> np.ndarray:
@@ -209,7 +165,7 @@ class F5TTS:
         seed: Optional[int] = None,
         max_duration=4096,
         y0: Optional[torch.Tensor] = None,       # extension: inject the initial noise (b, n, d)
-        use_graph: bool = True,
+        use_graph="auto",                        # extension: True / False / "auto" (graph from the 2nd call of a shape on)
     ) -> tuple[torch.Tensor, torch.Tensor]:
         self.eval()
         device = self.transformer.device
@@ -268,14 +224,15 @@ class F5TTS:
 
     @classmethod
     def from_pretrained(cls, hf_model_name_or_path: str, convert_weights=None, quantization_bits: int | None = None,
-                        precision: str = "bf16", device: str = "cuda:0",
-                        vocoder_name_or_path: str | None = "lucasnewman/vocos-mel-24khz") -> "F5TTS":
+                        precision: str = "f16", device: str = "cuda:0",
+                        vocoder_name_or_path: str | None = "lucasnewman/vocos-mel-24khz",
+                        allow_missing_vocoder: bool = False) -> "F5TTS":
         """cfm.py:404-520.  Loads `model_v1.safetensors` (or `model_v1_{4,8}b.safetensors`) + `vocab.txt` (+ the duration
         predictor `duration_v2.safetensors` when present) from a local directory or the HF hub (network required), and the
         Vocos vocoder (cfm.py:446) from `vocoder_name_or_path`, `$F5_VOCOS_PATH`, or the hub.  MLX int4/int8 checkpoints are
-        expanded to fp32 on load (weights.dequantize_mlx_checkpoint) and run on the bf16 path.  If the vocoder cannot be
-        found the model is returned WITHOUT one (sample() then returns mel frames) and a warning is printed; the
-        reference would raise from `Vocos.from_pretrained`."""
+        expanded to fp32 on load (weights.dequantize_mlx_checkpoint) and run like a full-precision checkpoint.  If the vocoder
+        cannot be found this raises, like the reference's `Vocos.from_pretrained` (cfm.py:446); pass
+        `allow_missing_vocoder=True` (or `vocoder_name_or_path=None`) to get a model whose sample() returns mel frames."""
         path = fetch_from_hub(hf_model_name_or_path, quantization_bits=quantization_bits)
         if path is None:
             raise ValueError(f"Could not find model {hf_model_name_or_path}")
@@ -309,9 +266,14 @@ class F5TTS:
                 from huggingface_hub import snapshot_download
                 vdir = snapshot_download(repo_id=vocoder_name_or_path, allow_patterns=["*.safetensors", "*.yaml", "*.json"])
                 vocoder = Vocos.from_pretrained(vdir, precision=precision, device=device).decode
-            except Exception as exc:                                       # offline: keep going without a vocoder
+            except Exception as exc:
+                if not allow_missing_vocoder:
+                    raise RuntimeError(
+                        f"vocoder {vocoder_name_or_path!r} unavailable ({type(exc).__name__}: {exc}).  Point "
+                        "vocoder_name_or_path or $F5_VOCOS_PATH at a local vocos-mel-24khz directory, or pass "
+                        "allow_missing_vocoder=True to get mel frames out of sample().") from exc
                 print(f"[f5_tts_mlx_amd] vocoder {vocoder_name_or_path!r} unavailable ({type(exc).__name__}); "
-                      f"sample() will return mel frames.  Set F5_VOCOS_PATH to a local vocos-mel-24khz directory.")
+                      f"sample() will return mel frames.")
 
         model_filename = "model_v1.safetensors"                            # cfm.py:448-453
         if exists(quantization_bits):

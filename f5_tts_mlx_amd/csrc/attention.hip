@@ -17,14 +17,16 @@
 // for Q, K, V and splits P in registers: 3 MFMAs per product.
 #include "attention.hpp"
 
+namespace F5_NS {
+
 #define KLD 72   // K  tile row stride in elements (144 B)
 #define VLD 68   // V^T tile row stride in elements (136 B)
 
 template <bool HP>
 __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
     constexpr int NP = HP ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][NP][64 * KLD];
-    __shared__ __attribute__((aligned(16))) bf16_t sV[2][NP][64 * VLD];
+    __shared__ __attribute__((aligned(16))) op16_t sK[2][NP][64 * KLD];
+    __shared__ __attribute__((aligned(16))) op16_t sV[2][NP][64 * VLD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
     const size_t rowbase = (size_t)b * p.seq_len;
 
     // Q fragments (B operand): query row lq, dims ks*16 + hi*8 .. +8
-    bf16x8 qf[NP][4];
+    op16x8 qf[NP][4];
     {
         int qr = q0 + lq;
         if (qr > p.seq_len - 1) qr = p.seq_len - 1;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
         for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                qf[pp][ks] = *reinterpret_cast<const bf16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+                qf[pp][ks] = *reinterpret_cast<const op16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
     }
 
     // staging: 2 chunks of K and 2 chunks of V^T per thread (per precision part)
@@ -107,12 +109,12 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = (kb * 32 + lq) * KLD + ks * 16 + hi * 8;
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sK[cur][0][off]);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[kb], 0, 0, 0);
+                const op16x8 a = *reinterpret_cast<const op16x8*>(&sK[cur][0][off]);
+                s[kb] = F5_MFMA32(a, qf[0][ks], s[kb], 0, 0, 0);
                 if (HP) {
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sK[cur][NP - 1][off]);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[0][ks], s[kb], 0, 0, 0);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
+                    const op16x8 al = *reinterpret_cast<const op16x8*>(&sK[cur][NP - 1][off]);
+                    s[kb] = F5_MFMA32(al, qf[0][ks], s[kb], 0, 0, 0);
+                    s[kb] = F5_MFMA32(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
                 }
             }
         }
@@ -165,22 +167,22 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
                 pw[e] = f5_pack2(p0, p1);
                 if (HP) pwl[e] = f5_pack2_lo(p0, p1);
             }
-            const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
-            bf16x8 pbl = pb;
-            if (HP) pbl = __builtin_bit_cast(bf16x8, u32x4{pwl[0], pwl[1], pwl[2], pwl[3]});
+            const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+            op16x8 pbl = pb;
+            if (HP) pbl = __builtin_bit_cast(op16x8, u32x4{pwl[0], pwl[1], pwl[2], pwl[3]});
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const int off = (db * 32 + lq) * VLD + ks4 * 16 + 4 * hi;
-                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&sV[cur][0][off]);
-                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&sV[cur][0][off + 8]);
-                const bf16x8 a = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                const op16x4 v0 = *reinterpret_cast<const op16x4*>(&sV[cur][0][off]);
+                const op16x4 v1 = *reinterpret_cast<const op16x4*>(&sV[cur][0][off + 8]);
+                const op16x8 a = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = F5_MFMA32(a, pb, o[db], 0, 0, 0);
                 if (HP) {
-                    const bf16x4 w0 = *reinterpret_cast<const bf16x4*>(&sV[cur][NP - 1][off]);
-                    const bf16x4 w1 = *reinterpret_cast<const bf16x4*>(&sV[cur][NP - 1][off + 8]);
-                    const bf16x8 al = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pb, o[db], 0, 0, 0);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pbl, o[db], 0, 0, 0);
+                    const op16x4 w0 = *reinterpret_cast<const op16x4*>(&sV[cur][NP - 1][off]);
+                    const op16x4 w1 = *reinterpret_cast<const op16x4*>(&sV[cur][NP - 1][off + 8]);
+                    const op16x8 al = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[db] = F5_MFMA32(al, pb, o[db], 0, 0, 0);
+                    o[db] = F5_MFMA32(a, pbl, o[db], 0, 0, 0);
                 }
             }
         }
@@ -256,7 +258,7 @@ __device__ __forceinline__ attn_f32x2 attn_exp_block(f32x16& s, float c2, float 
     return sum2;
 }
 
-__device__ __forceinline__ void attn_glds16(const bf16_t* gptr, bf16_t* lds_wave_base) {
+__device__ __forceinline__ void attn_glds16(const op16_t* gptr, op16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
     constexpr int NP = HP ? 2 : 1;
     constexpr int NST = HP ? 2 : 3;
     constexpr int TILE = 64 * 64;                       // elements per K or V^T tile image
-    __shared__ __attribute__((aligned(16))) bf16_t smem[NST * NP * 2 * TILE];   // [stage][part][K | V^T][64*64]
+    __shared__ __attribute__((aligned(16))) op16_t smem[NST * NP * 2 * TILE];   // [stage][part][K | V^T][64*64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
     const int ntile = (kvlen + 63) >> 6;
     const size_t rowbase = (size_t)b * p.seq_len;
 
-    bf16x8 qf[NP][4];
+    op16x8 qf[NP][4];
     {
         int qr = q0 + lq;
         if (qr > p.seq_len - 1) qr = p.seq_len - 1;
@@ -294,12 +296,12 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
         for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                qf[pp][ks] = *reinterpret_cast<const bf16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+                qf[pp][ks] = *reinterpret_cast<const op16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
     }
 
     // staging pointers (advanced by one KV tile per issue: tiles are issued in increasing order) + wave-uniform LDS offsets
-    const bf16_t* kptr[NP][2];
-    const bf16_t* vptr[NP][2];
+    const op16_t* kptr[NP][2];
+    const op16_t* vptr[NP][2];
     int krow[2], kcol[2], ldsoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -318,11 +320,11 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
     const size_t kstep = (size_t)64 * p.ldqk;
 #define A2_ISSUE(j_)                                                                                         \
     {                                                                                                        \
-        bf16_t* st_ = smem + ((j_) % NST) * (NP * 2 * TILE);                                                 \
+        op16_t* st_ = smem + ((j_) % NST) * (NP * 2 * TILE);                                                 \
         const bool tail_ = ((j_) * 64 + 63) > p.seq_len - 1;                                                 \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
             _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                              \
-                const bf16_t* ks_ = kptr[pp][i];                                                             \
+                const op16_t* ks_ = kptr[pp][i];                                                             \
                 if (tail_) {                                                                                 \
                     int key_ = (j_) * 64 + krow[i];                                                          \
                     if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                          \
@@ -364,11 +366,11 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
         }
         if (ABL != 6 && j + NST - 1 < ntile) A2_ISSUE(j + NST - 1);   // slot consumed in iteration j-1: every wave is past it
 
-        const bf16_t* st = smem + (j % NST) * (NP * 2 * TILE);
-        const bf16_t* sK = st;
-        const bf16_t* sV = st + TILE;
-        const bf16_t* sKl = st + (NP - 1) * 2 * TILE;
-        const bf16_t* sVl = st + (NP - 1) * 2 * TILE + TILE;
+        const op16_t* st = smem + (j % NST) * (NP * 2 * TILE);
+        const op16_t* sK = st;
+        const op16_t* sV = st + TILE;
+        const op16_t* sKl = st + (NP - 1) * 2 * TILE;
+        const op16_t* sVl = st + (NP - 1) * 2 * TILE + TILE;
 
         f32x16 s[2];
         __builtin_amdgcn_s_setprio(1);
@@ -379,19 +381,19 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = attn_swz(kb * 32 + lq, ks * 2 + hi);
-                bf16x8 a;
+                op16x8 a;
                 if (ABL == 7) a = qf[0][ks ^ 1];
-                else a = *reinterpret_cast<const bf16x8*>(&sK[off]);
+                else a = *reinterpret_cast<const op16x8*>(&sK[off]);
                 if (ABL == 4) {
                     asm volatile("" ::"v"(a));
                     s[kb][ks] += (float)ks;
                 } else {
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[kb], 0, 0, 0);
+                    s[kb] = F5_MFMA32(a, qf[0][ks], s[kb], 0, 0, 0);
                 }
                 if (HP) {
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sKl[off]);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[0][ks], s[kb], 0, 0, 0);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
+                    const op16x8 al = *reinterpret_cast<const op16x8*>(&sKl[off]);
+                    s[kb] = F5_MFMA32(al, qf[0][ks], s[kb], 0, 0, 0);
+                    s[kb] = F5_MFMA32(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
                 }
             }
         }
@@ -457,26 +459,26 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
                 pw[e] = f5_pack2(p0, p1);
                 if (HP) pwl[e] = f5_pack2_lo(p0, p1);
             }
-            const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
-            bf16x8 pbl = pb;
-            if (HP) pbl = __builtin_bit_cast(bf16x8, u32x4{pwl[0], pwl[1], pwl[2], pwl[3]});
+            const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+            op16x8 pbl = pb;
+            if (HP) pbl = __builtin_bit_cast(op16x8, u32x4{pwl[0], pwl[1], pwl[2], pwl[3]});
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const int voff = attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp);
-                bf16x8 a;
+                op16x8 a;
                 if (ABL == 7) a = qf[0][(ks4 + db) & 3];
-                else a = *reinterpret_cast<const bf16x8*>(&sV[voff]);
+                else a = *reinterpret_cast<const op16x8*>(&sV[voff]);
                 if (ABL == 3) {
                     asm volatile("" ::"v"(a), "v"(pb));
                     o[db][ks4] += 1.0f;
                 } else {
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                    o[db] = F5_MFMA32(a, pb, o[db], 0, 0, 0);
                 }
                 if (HP) {
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sVl[voff]);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pb, o[db], 0, 0, 0);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pbl, o[db], 0, 0, 0);
+                    const op16x8 al = *reinterpret_cast<const op16x8*>(&sVl[voff]);
+                    o[db] = F5_MFMA32(al, pb, o[db], 0, 0, 0);
+                    o[db] = F5_MFMA32(a, pbl, o[db], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
     constexpr int NST = 3;
     constexpr int TILE = 64 * 64;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[NST * 2 * TILE];   // [stage][K | V^T][64*64]
+    __shared__ __attribute__((aligned(16))) op16_t smem[NST * 2 * TILE];   // [stage][K | V^T][64*64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -528,18 +530,18 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
     const int ntile = (kvlen + 63) >> 6;
     const size_t rowbase = (size_t)b * p.seq_len;
 
-    bf16x8 qf[2][4];
+    op16x8 qf[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         int qr = q0 + qb * 32 + lq;
         if (qr > p.seq_len - 1) qr = p.seq_len - 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            qf[qb][ks] = *reinterpret_cast<const bf16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+            qf[qb][ks] = *reinterpret_cast<const op16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
     }
 
-    const bf16_t* kptr[2];
-    const bf16_t* vptr[2];
+    const op16_t* kptr[2];
+    const op16_t* vptr[2];
     int krow[2], kcol[2], ldsoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -555,10 +557,10 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
     const size_t kstep = (size_t)64 * p.ldqk;
 #define A2W_ISSUE(j_)                                                                                        \
     {                                                                                                        \
-        bf16_t* st_ = smem + ((j_) % NST) * (2 * TILE);                                                      \
+        op16_t* st_ = smem + ((j_) % NST) * (2 * TILE);                                                      \
         const bool tail_ = ((j_) * 64 + 63) > p.seq_len - 1;                                                 \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-            const bf16_t* ks_ = kptr[i];                                                                     \
+            const op16_t* ks_ = kptr[i];                                                                     \
             if (tail_) {                                                                                     \
                 int key_ = (j_) * 64 + krow[i];                                                              \
                 if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                              \
@@ -596,8 +598,8 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
         asm volatile("" ::: "memory");
         if (j + NST - 1 < ntile) A2W_ISSUE(j + NST - 1);
 
-        const bf16_t* sK = smem + (j % NST) * (2 * TILE);
-        const bf16_t* sV = sK + TILE;
+        const op16_t* sK = smem + (j % NST) * (2 * TILE);
+        const op16_t* sV = sK + TILE;
 
         f32x16 s[2][2];                                   // [query block][key block]
         __builtin_amdgcn_s_setprio(1);
@@ -609,9 +611,9 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
                 for (int e = 0; e < 16; ++e) s[qb][kb][e] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sK[attn_swz(kb * 32 + lq, ks * 2 + hi)]);
-                s[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[0][kb], 0, 0, 0);
-                s[1][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[1][ks], s[1][kb], 0, 0, 0);
+                const op16x8 a = *reinterpret_cast<const op16x8*>(&sK[attn_swz(kb * 32 + lq, ks * 2 + hi)]);
+                s[0][kb] = F5_MFMA32(a, qf[0][ks], s[0][kb], 0, 0, 0);
+                s[1][kb] = F5_MFMA32(a, qf[1][ks], s[1][kb], 0, 0, 0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -657,20 +659,20 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
 #pragma unroll
         for (int ks4 = 0; ks4 < 4; ++ks4) {
             const int kb = ks4 >> 1, sp = ks4 & 1;
-            bf16x8 pb[2];
+            op16x8 pb[2];
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 uint32_t pw[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pw[e] = f5_pack2(s[qb][kb][8 * sp + 2 * e], s[qb][kb][8 * sp + 2 * e + 1]);
-                pb[qb] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+                pb[qb] = __builtin_bit_cast(op16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
             }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sV[attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp)]);
-                o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[0], o[0][db], 0, 0, 0);
-                o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[1], o[1][db], 0, 0, 0);
+                const op16x8 a = *reinterpret_cast<const op16x8*>(&sV[attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp)]);
+                o[0][db] = F5_MFMA32(a, pb[0], o[0][db], 0, 0, 0);
+                o[1][db] = F5_MFMA32(a, pb[1], o[1][db], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -714,13 +716,13 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
     constexpr int RING = NST * NP * 2 * TILE;           // elements per group ring
     static_assert(KS * RING * 2 <= 160 * 1024, "LDS budget");
     static_assert((KS - 1) * 4 * 34 * 64 * 4 <= KS * RING * 2, "merge area must fit in the rings");
-    __shared__ __attribute__((aligned(16))) bf16_t smem_all[KS * RING];
+    __shared__ __attribute__((aligned(16))) op16_t smem_all[KS * RING];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave_all >> 2, wave = wave_all & 3;
     const int tg = tid & 255;
-    bf16_t* smem = smem_all + grp * RING;
+    op16_t* smem = smem_all + grp * RING;
     const int hi = lane >> 5, lq = lane & 31;
     const int bh = blockIdx.y;
     const int b = bh / p.H, h = bh - b * p.H;
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
     const int ntg = ntile > grp ? (ntile - grp + KS - 1) / KS : 0;   // tiles of this group
     const size_t rowbase = (size_t)b * p.seq_len;
 
-    bf16x8 qf[NP][4];
+    op16x8 qf[NP][4];
     {
         int qr = q0 + lq;
         if (qr > p.seq_len - 1) qr = p.seq_len - 1;
@@ -739,11 +741,11 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
         for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                qf[pp][ks] = *reinterpret_cast<const bf16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+                qf[pp][ks] = *reinterpret_cast<const op16x8*>(p.qk[pp] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
     }
 
-    const bf16_t* kptr[NP][2];
-    const bf16_t* vptr[NP][2];
+    const op16_t* kptr[NP][2];
+    const op16_t* vptr[NP][2];
     int krow[2], kcol[2], ldsoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -763,12 +765,12 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
     // jj_ = group-local tile number; the global tile is jj_*KS + grp
 #define A2S_ISSUE(jj_)                                                                                       \
     {                                                                                                        \
-        bf16_t* st_ = smem + ((jj_) % NST) * (NP * 2 * TILE);                                                \
+        op16_t* st_ = smem + ((jj_) % NST) * (NP * 2 * TILE);                                                \
         const int gt_ = (jj_) * KS + grp;                                                                    \
         const bool tail_ = (gt_ * 64 + 63) > p.seq_len - 1;                                                  \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
             _Pragma("unroll") for (int pp = 0; pp < NP; ++pp) {                                              \
-                const bf16_t* ks_ = kptr[pp][i];                                                             \
+                const op16_t* ks_ = kptr[pp][i];                                                             \
                 if (tail_) {                                                                                 \
                     int key_ = gt_ * 64 + krow[i];                                                           \
                     if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                          \
@@ -806,11 +808,11 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
         if (jj + NST - 1 < ntg) A2S_ISSUE(jj + NST - 1);
         if (jj >= ntg) continue;                          // wave-uniform: this group has no tile left (still meets the barrier)
 
-        const bf16_t* st = smem + (jj % NST) * (NP * 2 * TILE);
-        const bf16_t* sK = st;
-        const bf16_t* sV = st + TILE;
-        const bf16_t* sKl = st + (NP - 1) * 2 * TILE;
-        const bf16_t* sVl = st + (NP - 1) * 2 * TILE + TILE;
+        const op16_t* st = smem + (jj % NST) * (NP * 2 * TILE);
+        const op16_t* sK = st;
+        const op16_t* sV = st + TILE;
+        const op16_t* sKl = st + (NP - 1) * 2 * TILE;
+        const op16_t* sVl = st + (NP - 1) * 2 * TILE + TILE;
 
         f32x16 s[2];
         __builtin_amdgcn_s_setprio(1);
@@ -821,12 +823,12 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = attn_swz(kb * 32 + lq, ks * 2 + hi);
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sK[off]);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[kb], 0, 0, 0);
+                const op16x8 a = *reinterpret_cast<const op16x8*>(&sK[off]);
+                s[kb] = F5_MFMA32(a, qf[0][ks], s[kb], 0, 0, 0);
                 if (HP) {
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sKl[off]);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qf[0][ks], s[kb], 0, 0, 0);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
+                    const op16x8 al = *reinterpret_cast<const op16x8*>(&sKl[off]);
+                    s[kb] = F5_MFMA32(al, qf[0][ks], s[kb], 0, 0, 0);
+                    s[kb] = F5_MFMA32(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
                 }
             }
         }
@@ -875,19 +877,19 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
                 pw[e] = f5_pack2(p0, p1);
                 if (HP) pwl[e] = f5_pack2_lo(p0, p1);
             }
-            const bf16x8 pb = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
-            bf16x8 pbl = pb;
-            if (HP) pbl = __builtin_bit_cast(bf16x8, u32x4{pwl[0], pwl[1], pwl[2], pwl[3]});
+            const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+            op16x8 pbl = pb;
+            if (HP) pbl = __builtin_bit_cast(op16x8, u32x4{pwl[0], pwl[1], pwl[2], pwl[3]});
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const int voff = attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp);
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sV[voff]);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                const op16x8 a = *reinterpret_cast<const op16x8*>(&sV[voff]);
+                o[db] = F5_MFMA32(a, pb, o[db], 0, 0, 0);
                 if (HP) {
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sVl[voff]);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, pb, o[db], 0, 0, 0);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pbl, o[db], 0, 0, 0);
+                    const op16x8 al = *reinterpret_cast<const op16x8*>(&sVl[voff]);
+                    o[db] = F5_MFMA32(al, pb, o[db], 0, 0, 0);
+                    o[db] = F5_MFMA32(a, pbl, o[db], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -963,7 +965,7 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
 template <int WPS>
 __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
     constexpr int TILE = 64 * 64;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[3 * 2 * TILE];   // [stage][K | V^T][64*64]
+    __shared__ __attribute__((aligned(16))) op16_t smem[3 * 2 * TILE];   // [stage][K | V^T][64*64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -975,17 +977,17 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
     const int ntile = (kvlen + 63) >> 6;
     const size_t rowbase = (size_t)b * p.seq_len;
 
-    bf16x8 qf[4];
+    op16x8 qf[4];
     {
         int qr = q0 + lq;
         if (qr > p.seq_len - 1) qr = p.seq_len - 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+            qf[ks] = *reinterpret_cast<const op16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
     }
     // staging pointers (advanced by one KV tile per issue) and wave-uniform LDS offsets
-    const bf16_t* kptr[2];
-    const bf16_t* vptr[2];
+    const op16_t* kptr[2];
+    const op16_t* vptr[2];
     int krow[2], kcol[2], ldsoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1002,10 +1004,10 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
     // issue KV tile j_ (tiles are issued in increasing order: pointers advance by one tile per issue)
 #define A3_ISSUE(j_)                                                                                         \
     {                                                                                                        \
-        bf16_t* st_ = smem + ((j_) % 3) * (2 * TILE);                                                        \
+        op16_t* st_ = smem + ((j_) % 3) * (2 * TILE);                                                        \
         const bool tail_ = ((j_) * 64 + 63) > p.seq_len - 1;                                                 \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
-            const bf16_t* ks_ = kptr[i];                                                                     \
+            const op16_t* ks_ = kptr[i];                                                                     \
             if (tail_) {                                                                                     \
                 int key_ = (j_) * 64 + krow[i];                                                              \
                 if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                              \
@@ -1019,12 +1021,12 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
     }
 #define A3_SCORES(dst_, slot_)                                                                               \
     {                                                                                                        \
-        const bf16_t* sK_ = smem + (slot_) * (2 * TILE);                                                     \
+        const op16_t* sK_ = smem + (slot_) * (2 * TILE);                                                     \
         _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                   \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) dst_[kb][e] = 0.0f;                               \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                               \
-                const bf16x8 a_ = *reinterpret_cast<const bf16x8*>(&sK_[koff[kb][ks]]);                      \
-                dst_[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, qf[ks], dst_[kb], 0, 0, 0);          \
+                const op16x8 a_ = *reinterpret_cast<const op16x8*>(&sK_[koff[kb][ks]]);                      \
+                dst_[kb] = F5_MFMA32(a_, qf[ks], dst_[kb], 0, 0, 0);          \
             }                                                                                                \
         }                                                                                                    \
     }
@@ -1108,14 +1110,14 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
             __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                              \
         }                                                                                                    \
-        const bf16_t* sV_ = smem + ((j_) % 3) * (2 * TILE) + TILE;                                           \
+        const op16_t* sV_ = smem + ((j_) % 3) * (2 * TILE) + TILE;                                           \
         _Pragma("unroll") for (int ks4 = 0; ks4 < 4; ++ks4) {                                                \
             const int kb = ks4 >> 1, sp = ks4 & 1;                                                           \
-            const bf16x8 pb_ = __builtin_bit_cast(                                                           \
-                bf16x8, u32x4{pw_[kb][4 * sp], pw_[kb][4 * sp + 1], pw_[kb][4 * sp + 2], pw_[kb][4 * sp + 3]}); \
+            const op16x8 pb_ = __builtin_bit_cast(                                                           \
+                op16x8, u32x4{pw_[kb][4 * sp], pw_[kb][4 * sp + 1], pw_[kb][4 * sp + 2], pw_[kb][4 * sp + 3]}); \
             _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                               \
-                const bf16x8 a_ = *reinterpret_cast<const bf16x8*>(&sV_[voff[db][ks4]]);                     \
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, pb_, o[db], 0, 0, 0);                    \
+                const op16x8 a_ = *reinterpret_cast<const op16x8*>(&sV_[voff[db][ks4]]);                     \
+                o[db] = F5_MFMA32(a_, pb_, o[db], 0, 0, 0);                    \
             }                                                                                                \
         }                                                                                                    \
     }
@@ -1210,3 +1212,4 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     F5_LAUNCH_CHECK();
     return 0;
 }
+}  // namespace F5_NS

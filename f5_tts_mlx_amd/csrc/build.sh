@@ -1,17 +1,28 @@
 #!/bin/bash
 # Build the C-ABI shared library for gfx950 (cross-compiles without a GPU).
+# The kernel sources are compiled twice: bf16 MFMA operands (namespace f5bf) and fp16 operands (-DF5_F16=1, namespace f5hf).
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in gemm attention convpos rowops audio engine; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer build/$f.o)" ] || [ ../../include/f5tts_hip.h -nt build/$f.o ]; then
-    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
-    pids+=($!)
-  fi
+stale() {  # $1 = source, $2 = object, $3 = 1 when the source includes the public C-ABI header
+  [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer "$2")" ] || { [ "$3" = 1 ] && [ ../../include/f5tts_hip.h -nt "$2" ]; }
+}
+objs=()
+for f in gemm attention convpos rowops; do
+  for v in 0 1; do
+    o=build/${f}_h$v.o
+    objs+=($o)
+    if stale $f.hip $o 0; then $HIPCC $FLAGS -DF5_F16=$v -c $f.hip -o $o & pids+=($!); fi
+  done
+done
+for f in audio engine; do
+  o=build/$f.o
+  objs+=($o)
+  if stale $f.hip $o 1; then $HIPCC $FLAGS -c $f.hip -o $o & pids+=($!); fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC build/gemm.o build/attention.o build/convpos.o build/rowops.o build/audio.o build/engine.o -o libf5tts_hip.so
+$HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o libf5tts_hip.so
 echo "built $(pwd)/libf5tts_hip.so"

@@ -5,9 +5,6 @@
 #include <stdio.h>
 #include <string.h>
 
-typedef __bf16 bf16_t;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
@@ -15,6 +12,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define F5_WAVE 64
+
+// GEMM epilogues (csrc/gemm.hip); "BF16" in a name means "the 16-bit operand type of the build" (bf16 or fp16, op16.hpp)
+enum F5Epi : int {
+    EPI_F32 = 0,         // out_f32 = acc + bias
+    EPI_BF16 = 1,        // out_bf  = bf16(acc + bias)
+    EPI_GELU_TANH = 2,   // out_bf  = bf16(gelu_tanh(acc + bias))                 (dit.py:94-99)
+    EPI_GELU_ERF = 3,    // out_f32 = gelu_erf(acc + bias)                        (convnext_v2.py:50-51)
+    EPI_RESID_GATE = 4,  // out_f32 += gate[col] * ((acc + bias) * keep[row])     (dit.py:172-173,319,323)
+    EPI_QKV_ROPE = 5,    // q,k: rope(acc + bias) -> qk[row][col]; v -> vt[b,h][d][n] (dit.py:136-158)
+    EPI_ADDROWS = 6,     // out_f32 = acc + addrows[row][col]; out_bf = bf16(same)  (dit.py:250 split GEMM)
+    EPI_RESID_KEEP = 7,  // out_f32 = (resid[row][col] + acc + bias) * keep[row]  (convnext_v2.py:53-54, dit.py:225)
+    EPI_GELU_ERF_BF16 = 8,  // out_bf = bf16(gelu_erf(acc + bias))              (Vocos ConvNeXt block)
+};
 
 // ---- error handling (never throw across the C ABI) -------------------------------------------
 void f5_set_error(const char* fmt, ...);
@@ -35,41 +45,61 @@ void f5_set_error(const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
-// ---- bf16 helpers ----------------------------------------------------------------------------
-// float -> bf16 round-to-nearest-even (same rounding as torch's .to(bfloat16)); hi/lo split for the
-// 3-pass "bf16x3" precision mode: x ~= hi + lo with |x - hi - lo| <= 2^-17 |x|.
-__host__ __device__ inline u16 f5_f2bf_bits(float f) {
+// ---- host-side float <-> 16-bit operand bits (weight upload), round to nearest even -----------------------
+// bf16: same rounding as torch's .to(bfloat16); fp16: same as torch's .to(float16) except that finite values beyond
+// +-65504 saturate instead of becoming inf (the device producers saturate too, op16.hpp).
+inline u16 f5_f2bf_bits(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // NaN
     uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
     return (u16)(r >> 16);
 }
-__host__ __device__ inline float f5_bf_bits2f(u16 h) {
+inline float f5_bf_bits2f(u16 h) {
     uint32_t u = ((uint32_t)h) << 16;
     float f;
     memcpy(&f, &u, 4);
     return f;
 }
-__device__ inline bf16_t f5_f2bf(float f) { return static_cast<bf16_t>(f); }
-__device__ inline float f5_bf2f(bf16_t h) { return static_cast<float>(h); }
-__device__ inline void f5_split(float f, bf16_t& hi, bf16_t& lo) {
-    hi = static_cast<bf16_t>(f);
-    lo = static_cast<bf16_t>(f - static_cast<float>(hi));
+inline u16 f5_f2h_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const u16 sign = (u16)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (u16)(sign | 0x7e00u);                    // NaN
+    if (a >= 0x477ff000u) return (u16)(sign | 0x7bffu);                   // >= 65520 (would round to inf), inf: saturate
+    if (a < 0x33000001u) return sign;                                     // <= 2^-25: rounds to zero
+    const int e = (int)(a >> 23) - 127;                                   // unbiased exponent, in [-25, 15]
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;                             // 24-bit significand
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);                           // bits dropped (subnormals drop more)
+    const uint32_t half = 1u << (shift - 1), mask = (1u << shift) - 1u;
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & mask;
+    if (rem > half || (rem == half && (q & 1u))) ++q;
+    // q is the 11-bit significand (normal) or the subnormal mantissa; adding the biased exponent lets a carry roll over
+    const uint32_t he = e >= -14 ? (uint32_t)(e + 15 - 1) << 10 : 0u;     // exponent field minus the implicit bit of q
+    return (u16)(sign | (u16)(he + q));
 }
-
-// pack two floats to bf16 pairs (element 0 in the low half); *_lo packs the rounding residuals
-typedef float f5_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 f5_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ inline uint32_t f5_pack2(float a, float b) {
-    // one v_cvt_pk_bf16_f32 (RNE); the scalar-cast form compiled to two converts + an SDWA or
-    const f5_f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f5_bf16x2));
-}
-__device__ inline uint32_t f5_pack2_lo(float a, float b) {
-    const float ra = a - static_cast<float>(static_cast<bf16_t>(a));
-    const float rb = b - static_cast<float>(static_cast<bf16_t>(b));
-    return f5_pack2(ra, rb);
+inline float f5_h_bits2f(u16 h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 31u, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) {
+            u = sign;
+        } else {                                                         // subnormal: m * 2^-24
+            float f = (float)m * (1.0f / 16777216.0f);
+            memcpy(&u, &f, 4);
+            u |= sign;
+        }
+    } else if (e == 31) {
+        u = sign | 0x7f800000u | (m << 13);
+    } else {
+        u = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
 }
 
 // ---- activations (MLX semantics, see oracle/f5_oracle.py) ------------------------------------

@@ -6,6 +6,8 @@
 // Sequence edges are zero padded per batch element (Conv1d padding); no mask (dit.py:251 passes none).
 #include "convpos.hpp"
 
+namespace F5_NS {
+
 #define XLD 72  // LDS row stride (elements) for both tiles: 144 B rows => conflict-free ds_read_b128
 #define CP_ROWS 128
 #define CP_MAXTAPS 31
@@ -14,8 +16,8 @@ template <bool HP>
 __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
     constexpr int NP = HP ? 2 : 1;
     constexpr int HALO = CP_ROWS + CP_MAXTAPS - 1;
-    __shared__ __attribute__((aligned(16))) bf16_t sX[NP][HALO * XLD];
-    __shared__ __attribute__((aligned(16))) bf16_t sW[2][NP][64 * XLD];
+    __shared__ __attribute__((aligned(16))) op16_t sX[NP][HALO * XLD];
+    __shared__ __attribute__((aligned(16))) op16_t sW[2][NP][64 * XLD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lr = lane & 31;
@@ -79,18 +81,18 @@ __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int aoff = (wave * 32 + lr + t) * XLD + ks * 16 + hi * 8;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sX[0][aoff]);
-            bf16x8 al = a;
-            if (HP) al = *reinterpret_cast<const bf16x8*>(&sX[NP - 1][aoff]);
+            const op16x8 a = *reinterpret_cast<const op16x8*>(&sX[0][aoff]);
+            op16x8 al = a;
+            if (HP) al = *reinterpret_cast<const op16x8*>(&sX[NP - 1][aoff]);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 const int boff = (nb * 32 + lr) * XLD + ks * 16 + hi * 8;
-                const bf16x8 w = *reinterpret_cast<const bf16x8*>(&sW[cur][0][boff]);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[nb], 0, 0, 0);
+                const op16x8 w = *reinterpret_cast<const op16x8*>(&sW[cur][0][boff]);
+                acc[nb] = F5_MFMA32(a, w, acc[nb], 0, 0, 0);
                 if (HP) {
-                    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&sW[cur][NP - 1][boff]);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, w, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wl, acc[nb], 0, 0, 0);
+                    const op16x8 wl = *reinterpret_cast<const op16x8*>(&sW[cur][NP - 1][boff]);
+                    acc[nb] = F5_MFMA32(al, w, acc[nb], 0, 0, 0);
+                    acc[nb] = F5_MFMA32(a, wl, acc[nb], 0, 0, 0);
                 }
             }
         }
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
                 const float v = f5_mish(acc[nb][r] + bias);
                 const size_t off = (rowbase + n) * p.ldo + co;
                 if (p.mode == 0) {
-                    bf16_t h, l;
+                    op16_t h, l;
                     f5_split(v, h, l);
                     p.out_bf[0][off] = h;
                     if (p.out_bf[1]) p.out_bf[1][off] = l;
@@ -137,3 +139,4 @@ int f5_launch_convpos(const F5ConvPosArgs& a, hipStream_t stream) {
     F5_LAUNCH_CHECK();
     return 0;
 }
+}  // namespace F5_NS

@@ -13,10 +13,99 @@
 #include <vector>
 
 #include "../../include/f5tts_hip.h"
+// the kernel sources are built twice (bf16 operands: namespace f5bf, fp16 operands: namespace f5hf, op16.hpp); this file is
+// built once and sees both sets of declarations
+#define F5_F16 0
 #include "attention.hpp"
 #include "convpos.hpp"
 #include "gemm.hpp"
 #include "rowops.hpp"
+#undef F5_F16
+#define F5_F16 1
+#include "attention.hpp"
+#include "convpos.hpp"
+#include "gemm.hpp"
+#include "rowops.hpp"
+#undef F5_F16
+
+// Host-side view: 16-bit operand buffers are opaque storage (typed as the bf16 build's op16_t), argument structs are the
+// bf16 build's; the fp16 build's structs have the same layout (only the pointee type of the operand pointers differs).
+typedef f5bf::op16_t op16_t;
+using f5bf::F5AttnArgs;
+using f5bf::F5ConvPosArgs;
+using f5bf::F5GemmArgs;
+using f5bf::F5OdeArgs;
+// launches that do not touch 16-bit operands (or are bf16-only by definition: the MX-fp8 mode) come from the bf16 build
+using f5bf::f5_grn_partial_floats;
+using f5bf::f5_launch_duration_head;
+using f5bf::f5_launch_gemm_f8;
+using f5bf::f5_launch_ln_modulate_f8;
+using f5bf::f5_launch_quantize_mx;
+using f5bf::f5_launch_quantize_mx_bf16;
+using f5bf::f5_launch_rope_table;
+using f5bf::f5_launch_rowkeep;
+using f5bf::f5_launch_skinny_gemm;
+using f5bf::f5_launch_splice;
+using f5bf::f5_launch_text_embed;
+using f5bf::f5_launch_text_pos_table;
+using f5bf::f5_launch_time_sinus;
+
+// Kernels of one operand type.  `h` selects the fp16 build.
+struct Ops {
+    bool h = false;
+    static f5hf::op16_t* H(op16_t* p) { return reinterpret_cast<f5hf::op16_t*>(p); }
+    int gemm(const F5GemmArgs& a, int epi, hipStream_t s) const {
+        return h ? f5hf::f5_launch_gemm(reinterpret_cast<const f5hf::F5GemmArgs&>(a), epi, s) : f5bf::f5_launch_gemm(a, epi, s);
+    }
+    int attention(const F5AttnArgs& a, hipStream_t s) const {
+        return h ? f5hf::f5_launch_attention(reinterpret_cast<const f5hf::F5AttnArgs&>(a), s) : f5bf::f5_launch_attention(a, s);
+    }
+    int convpos(const F5ConvPosArgs& a, hipStream_t s) const {
+        return h ? f5hf::f5_launch_convpos(reinterpret_cast<const f5hf::F5ConvPosArgs&>(a), s) : f5bf::f5_launch_convpos(a, s);
+    }
+    int ode_stage(const F5OdeArgs& a, hipStream_t s) const {
+        return h ? f5hf::f5_launch_ode_stage(reinterpret_cast<const f5hf::F5OdeArgs&>(a), s) : f5bf::f5_launch_ode_stage(a, s);
+    }
+    int ln_modulate(const float* x, const float* scale, const float* shift, op16_t* hi, op16_t* lo, int rows, int dim, float eps,
+                    hipStream_t s) const {
+        return h ? f5hf::f5_launch_ln_modulate(x, scale, shift, H(hi), H(lo), rows, dim, eps, s)
+                 : f5bf::f5_launch_ln_modulate(x, scale, shift, hi, lo, rows, dim, eps, s);
+    }
+    int dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b, op16_t* hi, op16_t* lo,
+                  int nbatch, int seq_len, int dim, float eps, hipStream_t s) const {
+        return h ? f5hf::f5_launch_dwconv_ln(x, dw_w, dw_b, ln_w, ln_b, H(hi), H(lo), nbatch, seq_len, dim, eps, s)
+                 : f5bf::f5_launch_dwconv_ln(x, dw_w, dw_b, ln_w, ln_b, hi, lo, nbatch, seq_len, dim, eps, s);
+    }
+    int grn(const float* g, const float* gamma, const float* beta, float* partial, float* nx, op16_t* hi, op16_t* lo, int nbatch,
+            int seq_len, int dim, hipStream_t s) const {
+        return h ? f5hf::f5_launch_grn(g, gamma, beta, partial, nx, H(hi), H(lo), nbatch, seq_len, dim, s)
+                 : f5bf::f5_launch_grn(g, gamma, beta, partial, nx, hi, lo, nbatch, seq_len, dim, s);
+    }
+    int pack_cond_text(const float* cond, const int* lens, const float* text_emb, op16_t* hi, op16_t* lo, int B, int seq_len,
+                       int mel_dim, int dt, hipStream_t s) const {
+        return h ? f5hf::f5_launch_pack_cond_text(cond, lens, text_emb, H(hi), H(lo), B, seq_len, mel_dim, dt, s)
+                 : f5bf::f5_launch_pack_cond_text(cond, lens, text_emb, hi, lo, B, seq_len, mel_dim, dt, s);
+    }
+    int pack_x(const float* y, op16_t* hi, op16_t* lo, int rows, int mel_dim, hipStream_t s) const {
+        return h ? f5hf::f5_launch_pack_x(y, H(hi), H(lo), rows, mel_dim, s) : f5bf::f5_launch_pack_x(y, hi, lo, rows, mel_dim, s);
+    }
+    int layernorm(const float* x, const float* w, const float* b, float* out_f32, op16_t* hi, op16_t* lo, int rows, int dim,
+                  float eps, hipStream_t s) const {
+        return h ? f5hf::f5_launch_layernorm(x, w, b, out_f32, H(hi), H(lo), rows, dim, eps, s)
+                 : f5bf::f5_launch_layernorm(x, w, b, out_f32, hi, lo, rows, dim, eps, s);
+    }
+    int im2col7(const float* x, op16_t* hi, op16_t* lo, int nbatch, int seq_len, int channels, hipStream_t s) const {
+        return h ? f5hf::f5_launch_im2col7(x, H(hi), H(lo), nbatch, seq_len, channels, s)
+                 : f5bf::f5_launch_im2col7(x, hi, lo, nbatch, seq_len, channels, s);
+    }
+    int pack_bf16(const float* src, const uint8_t* rowkeep, op16_t* hi, op16_t* lo, int rows, int cols, int ld, int col0,
+                  hipStream_t s) const {
+        return h ? f5hf::f5_launch_pack_bf16(src, rowkeep, H(hi), H(lo), rows, cols, ld, col0, s)
+                 : f5bf::f5_launch_pack_bf16(src, rowkeep, hi, lo, rows, cols, ld, col0, s);
+    }
+};
+// operand type of the per-op entry points (f5_op_*), set by f5_op_set_operand_type; engines carry their own
+static Ops g_ops;
 
 // ------------------------------------------------------------------------------------------------
 // error string
@@ -76,7 +165,7 @@ struct TextBlockW {
 struct Workspace {
     size_t total = 0;
     size_t lens, dur2, text, ids, keep, rowkeep;
-    size_t tgrid, dt, sinus, th, temb, mod;
+    size_t tgrid, dt, cfgv, sinus, th, temb, mod;
     size_t rope_cos, rope_sin;
     size_t cond, traj, ytmp, kst, vel;
     size_t xin[2];
@@ -91,6 +180,8 @@ struct Workspace {
 struct GraphEntry {
     std::string key;
     hipGraphExec_t exec;
+    const void* workspace;   // the captured nodes reference this buffer
+    uint64_t stamp;          // last use (LRU)
 };
 
 struct f5_engine {
@@ -114,7 +205,11 @@ struct f5_engine {
     std::vector<BlockW> blocks;
     MatBF wout;
     size_t bout;
-    std::vector<GraphEntry> graphs;
+    Ops ops;                          // kernels of this engine's operand type
+    std::vector<GraphEntry> graphs;   // cached hipGraphExecs, at most graph_cap (least recently used is destroyed)
+    std::vector<std::string> seen;    // signatures sampled once in "auto" graph mode (captured on the second sighting)
+    int graph_cap = 8;
+    uint64_t clock = 0;
 };
 
 static int nfe_per_step(int method) { return method == F5_EULER ? 1 : (method == F5_MIDPOINT ? 2 : 4); }
@@ -270,7 +365,8 @@ static int build_arena_plan(f5_engine* e) {
 extern "C" int f5_engine_create(const f5_config* cfg, int precision, f5_engine** out) {
     F5_REQUIRE(cfg && out, "f5_engine_create: null argument");
     const f5_config& c = *cfg;
-    F5_REQUIRE(precision == F5_PREC_BF16 || precision == F5_PREC_BF16X3 || precision == F5_PREC_MXFP8, "unknown precision %d", precision);
+    F5_REQUIRE(precision == F5_PREC_BF16 || precision == F5_PREC_BF16X3 || precision == F5_PREC_MXFP8 || precision == F5_PREC_F16,
+               "unknown precision %d", precision);
     F5_REQUIRE(precision != F5_PREC_MXFP8 || (cfg->ff_dim % 256 == 0 && cfg->dim % 256 == 0), "mxfp8 needs dim and ff_dim to be multiples of 256");
     F5_REQUIRE(c.dim_head == 64, "dim_head must be 64 (got %d)", c.dim_head);
     F5_REQUIRE(c.heads * c.dim_head == c.dim, "heads * dim_head must equal dim (%d * %d != %d)", c.heads, c.dim_head, c.dim);
@@ -286,6 +382,7 @@ extern "C" int f5_engine_create(const f5_config* cfg, int precision, f5_engine**
     e->cfg = c;
     e->prec = precision;
     e->np = precision == F5_PREC_BF16X3 ? 2 : 1;
+    e->ops.h = precision == F5_PREC_F16;
     build_arena_plan(e);
     *out = e;
     return 0;
@@ -296,6 +393,20 @@ extern "C" void f5_engine_destroy(f5_engine* e) {
     for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     delete e;
 }
+
+extern "C" int f5_engine_set_graph_cache(f5_engine* e, int max_graphs) {
+    F5_REQUIRE(e && max_graphs >= 1 && max_graphs <= 1024, "graph cache size must be in [1, 1024]");
+    e->graph_cap = max_graphs;
+    while ((int)e->graphs.size() > e->graph_cap) {
+        size_t lru = 0;
+        for (size_t i = 1; i < e->graphs.size(); ++i)
+            if (e->graphs[i].stamp < e->graphs[lru].stamp) lru = i;
+        (void)hipGraphExecDestroy(e->graphs[lru].exec);
+        e->graphs.erase(e->graphs.begin() + lru);
+    }
+    return 0;
+}
+extern "C" int f5_engine_graph_count(f5_engine* e) { return e ? (int)e->graphs.size() : -1; }
 
 extern "C" int f5_weights_bytes(f5_engine* e, size_t* bytes) {
     F5_REQUIRE(e && bytes, "null argument");
@@ -336,7 +447,7 @@ extern "C" int f5_load_tensor(f5_engine* e, const char* name, const float* host,
             for (int r = 0; r < d.src_rows; ++r)
                 for (int cc = 0; cc < ncol; ++cc) {
                     const float v = host[(size_t)r * d.src_cols + d.c0 + cc];
-                    const u16 h = f5_f2bf_bits(v);
+                    const u16 h = e->ops.h ? f5_f2h_bits(v) : f5_f2bf_bits(v);
                     hi[(size_t)r * ncol + cc] = h;
                     if (e->np == 2) lo[(size_t)r * ncol + cc] = f5_f2bf_bits(v - f5_bf_bits2f(h));
                 }
@@ -371,7 +482,7 @@ extern "C" int f5_finalize_weights(f5_engine* e, void* stream) {
             const MatBF* src[4] = {&w.qkv, &w.o, &w.ff1, &w.ff2};
             const MatF8* dst[4] = {&w.qkv8, &w.o8, &w.ff1_8, &w.ff2_8};
             for (int k = 0; k < 4; ++k) {
-                rc = f5_launch_quantize_mx_bf16((const bf16_t*)(e->arena + src[k]->hi), src[k]->ld, (uint8_t*)(e->arena + dst[k]->q),
+                rc = f5_launch_quantize_mx_bf16((const op16_t*)(e->arena + src[k]->hi), src[k]->ld, (uint8_t*)(e->arena + dst[k]->q),
                                                 dst[k]->ld, (uint8_t*)(e->arena + dst[k]->s), src[k]->rows, src[k]->ld,
                                                 (hipStream_t)stream);
                 if (rc) return rc;
@@ -402,6 +513,7 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
     w.rowkeep = b.take(M2);
     w.tgrid = b.take((size_t)(nfe > 0 ? nfe : 1) * 4);
     w.dt = b.take((size_t)steps * 4);
+    w.cfgv = b.take(4);
     w.sinus = b.take((size_t)(nfe + 1) * c.freq_embed_dim * 4);
     w.th = b.take((size_t)(nfe + 1) * D * 4);
     w.temb = b.take((size_t)(nfe + 1) * D * 4);
@@ -468,16 +580,17 @@ struct Ctx {
     int B, N, nt, nb;   // nb = branches evaluated per function evaluation (1 or 2)
     int npad;
     bool use_mask;
+    Ops ops;
     template <typename T>
     T* p(size_t off) const { return reinterpret_cast<T*>(ws + off); }
     template <typename T>
     T* a(size_t off) const { return reinterpret_cast<T*>(e->arena + off); }
-    bf16_t* pb(const size_t (&offs)[2], int part) const {
-        return (part < e->np) ? reinterpret_cast<bf16_t*>(ws + offs[part]) : nullptr;
+    op16_t* pb(const size_t (&offs)[2], int part) const {
+        return (part < e->np) ? reinterpret_cast<op16_t*>(ws + offs[part]) : nullptr;
     }
-    const bf16_t* wm(const MatBF& m, int part) const {
-        if (part == 0) return reinterpret_cast<const bf16_t*>(e->arena + m.hi);
-        return e->np == 2 ? reinterpret_cast<const bf16_t*>(e->arena + m.lo) : nullptr;
+    const op16_t* wm(const MatBF& m, int part) const {
+        if (part == 0) return reinterpret_cast<const op16_t*>(e->arena + m.hi);
+        return e->np == 2 ? reinterpret_cast<const op16_t*>(e->arena + m.lo) : nullptr;
     }
     int nseg() const { return e->np == 2 ? 3 : 1; }
 };
@@ -488,7 +601,7 @@ struct Ctx {
         if (_rc) return _rc; \
     } while (0)
 
-static F5GemmArgs gemm_base(const Ctx& c, const bf16_t* a_hi, const bf16_t* a_lo, int lda, const MatBF& w, int M, int N, int K,
+static F5GemmArgs gemm_base(const Ctx& c, const op16_t* a_hi, const op16_t* a_lo, int lda, const MatBF& w, int M, int N, int K,
                             const float* bias) {
     F5GemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -514,6 +627,7 @@ static int run_prep(const Ctx& c, int nfe) {
     const int D = cf.dim, Dt = cf.text_dim, TF = cf.text_ff_dim, L = cf.depth;
     const int M1 = c.B * c.N, M2 = 2 * M1;
     hipStream_t s = c.s;
+    const Ops& K = c.ops;
 
     // --- t-only tables (dit.py:61-82, 267, 286)
     if (nfe > 0) {
@@ -535,13 +649,13 @@ static int run_prep(const Ctx& c, int nfe) {
     int cur = 0;
     for (int i = 0; i < cf.conv_layers; ++i) {
         const TextBlockW& t = e->tblocks[i];
-        RC(f5_launch_dwconv_ln(c.p<float>(w.te[cur]), c.a<float>(t.dw_w), c.a<float>(t.dw_b), c.a<float>(t.ln_w),
+        RC(K.dwconv_ln(c.p<float>(w.te[cur]), c.a<float>(t.dw_w), c.a<float>(t.dw_b), c.a<float>(t.ln_w),
                                c.a<float>(t.ln_b), c.pb(w.tln, 0), c.pb(w.tln, 1), 2 * c.B, c.N, Dt, 1e-6f, s));
         F5GemmArgs g1 = gemm_base(c, c.pb(w.tln, 0), c.pb(w.tln, 1), Dt, t.pw1, M2, TF, Dt, c.a<float>(t.b1));
         g1.out_f32 = c.p<float>(w.tg);
         g1.ldo = TF;
-        RC(f5_launch_gemm(g1, EPI_GELU_ERF, s));
-        RC(f5_launch_grn(c.p<float>(w.tg), c.a<float>(t.gamma), c.a<float>(t.beta), c.p<float>(w.grn_partial),
+        RC(K.gemm(g1, EPI_GELU_ERF, s));
+        RC(K.grn(c.p<float>(w.tg), c.a<float>(t.gamma), c.a<float>(t.beta), c.p<float>(w.grn_partial),
                          c.p<float>(w.grn_nx), c.pb(w.tg2, 0), c.pb(w.tg2, 1), 2 * c.B, c.N, TF, s));
         F5GemmArgs g2 = gemm_base(c, c.pb(w.tg2, 0), c.pb(w.tg2, 1), TF, t.pw2, M2, Dt, TF, c.a<float>(t.b2));
         g2.out_f32 = c.p<float>(w.te[cur ^ 1]);
@@ -549,16 +663,16 @@ static int run_prep(const Ctx& c, int nfe) {
         g2.resid = c.p<float>(w.te[cur]);
         g2.ldres = Dt;
         g2.rowkeep = c.p<uint8_t>(w.keep);
-        RC(f5_launch_gemm(g2, EPI_RESID_KEEP, s));
+        RC(K.gemm(g2, EPI_RESID_KEEP, s));
         cur ^= 1;
     }
     // --- hoisted part of the input projection: Hc = [cond | text] * Wct^T + b   (dit.py:249-250)
-    RC(f5_launch_pack_cond_text(c.p<float>(w.cond), c.p<int>(w.lens), c.p<float>(w.te[cur]), c.pb(w.ct, 0), c.pb(w.ct, 1), c.B,
+    RC(K.pack_cond_text(c.p<float>(w.cond), c.p<int>(w.lens), c.p<float>(w.te[cur]), c.pb(w.ct, 0), c.pb(w.ct, 1), c.B,
                                 c.N, cf.mel_dim, Dt, s));
     F5GemmArgs gh = gemm_base(c, c.pb(w.ct, 0), c.pb(w.ct, 1), 128 + Dt, e->wct, M2, D, 128 + Dt, c.a<float>(e->bproj));
     gh.out_f32 = c.p<float>(w.hc);
     gh.ldo = D;
-    RC(f5_launch_gemm(gh, EPI_F32, s));
+    RC(K.gemm(gh, EPI_F32, s));
     return 0;
 }
 
@@ -570,6 +684,7 @@ static int run_dit(const Ctx& c, int j) {
     const int D = cf.dim, FF = cf.ff_dim, L = cf.depth, H = cf.heads;
     const int M1 = c.B * c.N, M = c.nb * M1;
     hipStream_t s = c.s;
+    const Ops& K = c.ops;
     const float* mod = c.p<float>(w.mod) + (size_t)j * (6 * L + 2) * D;
     const uint8_t* rowkeep = c.use_mask ? c.p<uint8_t>(w.rowkeep) : nullptr;
     const int* kvlen = c.use_mask ? c.p<int>(w.dur2) : nullptr;
@@ -584,7 +699,7 @@ static int run_dit(const Ctx& c, int j) {
     g0.out_bf[0] = c.pb(w.xb, 0);
     g0.out_bf[1] = c.pb(w.xb, 1);
     g0.ldob = D;
-    RC(f5_launch_gemm(g0, EPI_ADDROWS, s));
+    RC(K.gemm(g0, EPI_ADDROWS, s));
 
     // x += conv_pos_embed(x)  (dit.py:251)
     F5ConvPosArgs cp;
@@ -605,7 +720,7 @@ static int run_dit(const Ctx& c, int j) {
     cp.mode = 0;
     cp.out_bf[0] = c.pb(w.c1, 0);
     cp.out_bf[1] = c.pb(w.c1, 1);
-    RC(f5_launch_convpos(cp, s));
+    RC(K.convpos(cp, s));
     cp.in[0] = c.pb(w.c1, 0);
     cp.in[1] = c.pb(w.c1, 1);
     cp.W[0] = c.wm(e->conv_w[1], 0);
@@ -614,7 +729,7 @@ static int run_dit(const Ctx& c, int j) {
     cp.mode = 1;
     cp.out_bf[0] = cp.out_bf[1] = nullptr;
     cp.out_f32 = c.p<float>(w.x);
-    RC(f5_launch_convpos(cp, s));
+    RC(K.convpos(cp, s));
 
     for (int i = 0; i < L && e->prec == F5_PREC_MXFP8; ++i) {
         // MX-fp8 block: the four GEMMs run on e4m3 operands with E8M0 block scales (v_mfma_scale_f32_32x32x64_f8f6f4); their A
@@ -668,7 +783,7 @@ static int run_dit(const Ctx& c, int j) {
         at.dmodel = D;
         at.hp = 0;
         at.scale = 1.0f / sqrtf((float)cf.dim_head);
-        RC(f5_launch_attention(at, s));
+        RC(K.attention(at, s));
 
         F5GemmArgs go = f8args(c.p<uint8_t>(w.ao8), c.p<uint8_t>(w.ao8s), D, bw.o8, D, D, c.a<float>(bw.bo));
         go.out_f32 = c.p<float>(w.x);
@@ -692,7 +807,7 @@ static int run_dit(const Ctx& c, int j) {
     for (int i = 0; i < L && e->prec != F5_PREC_MXFP8; ++i) {
         const BlockW& bw = e->blocks[i];
         const float* m6 = mod + (size_t)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        RC(f5_launch_ln_modulate(c.p<float>(w.x), m6 + D, m6, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+        RC(K.ln_modulate(c.p<float>(w.x), m6 + D, m6, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
         F5GemmArgs gq = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.qkv, M, 3 * D, D, c.a<float>(bw.bqkv));
         gq.out_bf[0] = c.pb(w.qk, 0);
         gq.out_bf[1] = c.pb(w.qk, 1);
@@ -705,7 +820,7 @@ static int run_dit(const Ctx& c, int j) {
         gq.dmodel = D;
         gq.vt[0] = c.pb(w.vt, 0);
         gq.vt[1] = c.pb(w.vt, 1);
-        RC(f5_launch_gemm(gq, EPI_QKV_ROPE, s));
+        RC(K.gemm(gq, EPI_QKV_ROPE, s));
 
         F5AttnArgs at;
         memset(&at, 0, sizeof(at));
@@ -724,33 +839,33 @@ static int run_dit(const Ctx& c, int j) {
         at.dmodel = D;
         at.hp = e->np == 2;
         at.scale = 1.0f / sqrtf((float)cf.dim_head);
-        RC(f5_launch_attention(at, s));
+        RC(K.attention(at, s));
 
         F5GemmArgs go = gemm_base(c, c.pb(w.ao, 0), c.pb(w.ao, 1), D, bw.o, M, D, D, c.a<float>(bw.bo));
         go.out_f32 = c.p<float>(w.x);
         go.ldo = D;
         go.gate = m6 + 2 * D;
         go.rowkeep = rowkeep;
-        RC(f5_launch_gemm(go, EPI_RESID_GATE, s));
+        RC(K.gemm(go, EPI_RESID_GATE, s));
 
-        RC(f5_launch_ln_modulate(c.p<float>(w.x), m6 + 4 * D, m6 + 3 * D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+        RC(K.ln_modulate(c.p<float>(w.x), m6 + 4 * D, m6 + 3 * D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
         F5GemmArgs g1 = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.ff1, M, FF, D, c.a<float>(bw.bff1));
         g1.out_bf[0] = c.pb(w.ffh, 0);
         g1.out_bf[1] = c.pb(w.ffh, 1);
         g1.ldob = FF;
-        RC(f5_launch_gemm(g1, EPI_GELU_TANH, s));
+        RC(K.gemm(g1, EPI_GELU_TANH, s));
         F5GemmArgs g2 = gemm_base(c, c.pb(w.ffh, 0), c.pb(w.ffh, 1), FF, bw.ff2, M, D, FF, c.a<float>(bw.bff2));
         g2.out_f32 = c.p<float>(w.x);
         g2.ldo = D;
         g2.gate = m6 + 5 * D;
-        RC(f5_launch_gemm(g2, EPI_RESID_GATE, s));
+        RC(K.gemm(g2, EPI_RESID_GATE, s));
     }
     const float* mf = mod + (size_t)L * 6 * D;  // (scale, shift) order, dit.py:287
-    RC(f5_launch_ln_modulate(c.p<float>(w.x), mf, mf + D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+    RC(K.ln_modulate(c.p<float>(w.x), mf, mf + D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
     F5GemmArgs gf = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, e->wout, M, cf.mel_dim, D, c.a<float>(e->bout));
     gf.out_f32 = c.p<float>(w.vel);
     gf.ldo = cf.mel_dim;
-    RC(f5_launch_gemm(gf, EPI_F32, s));
+    RC(K.gemm(gf, EPI_F32, s));
     return 0;
 }
 
@@ -762,9 +877,10 @@ static int run_sample_body(const Ctx& c, const f5_sample_args* a) {
     const int per = nfe_per_step(a->method);
     const int nfe = (a->steps - 1) * per;
     hipStream_t s = c.s;
+    const Ops& K = c.ops;
     RC(run_prep(c, nfe));
     float* traj = c.p<float>(w.traj);
-    RC(f5_launch_pack_x(traj, c.pb(w.xin, 0), c.pb(w.xin, 1), (int)M1, mel, s));
+    RC(K.pack_x(traj, c.pb(w.xin, 0), c.pb(w.xin, 1), (int)M1, mel, s));
     const float* pred = c.p<float>(w.vel);
     const float* nullp = c.nb == 2 ? pred + M1 * mel : nullptr;
     float* kst = c.p<float>(w.kst);
@@ -776,7 +892,7 @@ static int run_sample_body(const Ctx& c, const f5_sample_args* a) {
         memset(&o, 0, sizeof(o));
         o.pred = pred;
         o.null_pred = nullp;
-        o.cfg = a->cfg_strength;
+        o.cfg_ptr = c.p<float>(w.cfgv);   // staged per call: a by-value scalar would be frozen into the cached hipGraph
         o.base = y;
         o.dt_ptr = c.p<float>(w.dt) + i;
         o.divisor = 1.0f;
@@ -788,29 +904,29 @@ static int run_sample_body(const Ctx& c, const f5_sample_args* a) {
             RC(run_dit(c, i));
             o.coef = 1.0f;
             o.out = ynext;
-            RC(f5_launch_ode_stage(o, s));
+            RC(K.ode_stage(o, s));
         } else if (a->method == F5_MIDPOINT) {
             RC(run_dit(c, 2 * i));
             o.coef = 0.5f;
             o.out = ytmp;
-            RC(f5_launch_ode_stage(o, s));
+            RC(K.ode_stage(o, s));
             RC(run_dit(c, 2 * i + 1));
             o.coef = 1.0f;
             o.out = ynext;
-            RC(f5_launch_ode_stage(o, s));
+            RC(K.ode_stage(o, s));
         } else {
             RC(run_dit(c, 4 * i));
             o.coef = 0.5f;
             o.out = ytmp;
             o.kstore = kst;
-            RC(f5_launch_ode_stage(o, s));
+            RC(K.ode_stage(o, s));
             RC(run_dit(c, 4 * i + 1));
             o.kstore = kst + M1 * mel;
-            RC(f5_launch_ode_stage(o, s));
+            RC(K.ode_stage(o, s));
             RC(run_dit(c, 4 * i + 2));
             o.coef = 1.0f;
             o.kstore = kst + 2 * M1 * mel;
-            RC(f5_launch_ode_stage(o, s));
+            RC(K.ode_stage(o, s));
             RC(run_dit(c, 4 * i + 3));
             o.kstore = nullptr;
             o.mode = 1;
@@ -819,7 +935,7 @@ static int run_sample_body(const Ctx& c, const f5_sample_args* a) {
             o.k2 = kst + M1 * mel;
             o.k3 = kst + 2 * M1 * mel;
             o.out = ynext;
-            RC(f5_launch_ode_stage(o, s));
+            RC(K.ode_stage(o, s));
         }
     }
     return 0;
@@ -856,6 +972,7 @@ static int stage_inputs(Ctx& c, const f5_sample_args* a, const float* x_override
     F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.dur2, dur2.data(), (size_t)2 * c.B * 4, hipMemcpyHostToDevice, s));
     if (!tnfe.empty()) F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.tgrid, tnfe.data(), tnfe.size() * 4, hipMemcpyHostToDevice, s));
     if (!dts.empty()) F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.dt, dts.data(), dts.size() * 4, hipMemcpyHostToDevice, s));
+    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.cfgv, &a->cfg_strength, 4, hipMemcpyHostToDevice, s));
     F5_HIP_CHECK(hipStreamSynchronize(s));  // host staging vectors die at scope exit
     F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.text, a->text, (size_t)c.B * c.nt * 4, hipMemcpyDeviceToDevice, s));
     F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.cond, a->cond, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
@@ -877,6 +994,7 @@ static Ctx make_ctx(f5_engine* e, const f5_sample_args* a, hipStream_t s) {
     c.nb = a->cfg_strength < 1e-5f ? 1 : 2;
     c.npad = (a->N + 63) / 64 * 64;
     c.use_mask = a->use_mask != 0;
+    c.ops = e->ops;
     return c;
 }
 
@@ -909,26 +1027,61 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     }
     RC(stage_inputs(c, a, nullptr, tnfe, dts));
 
-    if (a->use_graph) {
-        char key[256];
-        snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-                 (int)c.use_mask, a->workspace);
+    // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
+    // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
+    char key[256];
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb, (int)c.use_mask,
+             a->workspace);
+    bool graph = a->use_graph == 1;
+    if (a->use_graph == F5_GRAPH_AUTO) {
+        // a text-to-speech service sees a new (N, nt) on almost every call and capture + instantiate of ~5000 nodes costs more
+        // than one eager pass: run a signature eagerly the first time, capture it when it comes back
+        bool cached = false;
+        for (auto& g : e->graphs) cached |= g.key == key;
+        bool seen = false;
+        for (auto& k : e->seen) seen |= k == key;
+        graph = cached || seen;
+        if (!graph) {
+            if (e->seen.size() >= 64) e->seen.erase(e->seen.begin());
+            e->seen.push_back(key);
+        }
+    }
+    if (graph) {
         hipGraphExec_t exec = nullptr;
         for (auto& g : e->graphs)
-            if (g.key == key) exec = g.exec;
+            if (g.key == key) {
+                exec = g.exec;
+                g.stamp = ++e->clock;
+            }
         if (!exec) {
-            hipGraph_t graph = nullptr;
+            // entries captured against another workspace are dead (the caller re-allocated it); then make room (LRU)
+            for (size_t i = 0; i < e->graphs.size();) {
+                if (e->graphs[i].workspace != a->workspace) {
+                    (void)hipGraphExecDestroy(e->graphs[i].exec);
+                    e->graphs.erase(e->graphs.begin() + i);
+                } else {
+                    ++i;
+                }
+            }
+            while ((int)e->graphs.size() >= e->graph_cap && !e->graphs.empty()) {
+                size_t lru = 0;
+                for (size_t i = 1; i < e->graphs.size(); ++i)
+                    if (e->graphs[i].stamp < e->graphs[lru].stamp) lru = i;
+                (void)hipGraphExecDestroy(e->graphs[lru].exec);
+                e->graphs.erase(e->graphs.begin() + lru);
+            }
+            hipGraph_t graph_h = nullptr;
             F5_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             const int rc = run_sample_body(c, a);
-            const hipError_t ec = hipStreamEndCapture(s, &graph);
+            const hipError_t ec = hipStreamEndCapture(s, &graph_h);
             if (rc) {
-                if (graph) (void)hipGraphDestroy(graph);
+                if (graph_h) (void)hipGraphDestroy(graph_h);
                 return rc;
             }
             F5_HIP_CHECK(ec);
-            F5_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-            e->graphs.push_back({key, exec});
+            F5_HIP_CHECK(hipGraphInstantiate(&exec, graph_h, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph_h);
+            e->graphs.push_back({key, exec, a->workspace, ++e->clock});
         }
         F5_HIP_CHECK(hipGraphLaunch(exec, s));
     } else {
@@ -955,8 +1108,9 @@ extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float
     const size_t M1 = (size_t)c.B * c.N;
     std::vector<float> tnfe(1, t), dts(1, 0.0f);
     RC(stage_inputs(c, &a2, x, tnfe, dts));
+    const Ops& K = c.ops;
     RC(run_prep(c, 1));
-    RC(f5_launch_pack_x(c.p<float>(c.w.traj), c.pb(c.w.xin, 0), c.pb(c.w.xin, 1), (int)M1, mel, s));
+    RC(K.pack_x(c.p<float>(c.w.traj), c.pb(c.w.xin, 0), c.pb(c.w.xin, 1), (int)M1, mel, s));
     RC(run_dit(c, 0));
     F5_HIP_CHECK(hipMemcpyAsync(pred, c.ws + c.w.vel, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
     if (null_pred && c.nb == 2)
@@ -967,64 +1121,79 @@ extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float
 // ------------------------------------------------------------------------------------------------
 // per-op entry points
 // ------------------------------------------------------------------------------------------------
-extern int f5_attn_version;
+// debug knobs live in both kernel builds
+#define F5_DECL_KNOB(v) namespace f5bf { extern int v; } namespace f5hf { extern int v; }
+#define F5_SET_BOTH(v, x) do { f5bf::v = (x); f5hf::v = (x); } while (0)
+F5_DECL_KNOB(f5_attn_version)
+F5_DECL_KNOB(f5_attn_ablation)
+F5_DECL_KNOB(f5_attn_wide)
+F5_DECL_KNOB(f5_attn_kvsplit)
+F5_DECL_KNOB(f5_gemm_big_kernel)
+F5_DECL_KNOB(f5_gemm_v3_stagger)
+F5_DECL_KNOB(f5_gemm_ring_default)
+F5_DECL_KNOB(f5_gemm_order)
+F5_DECL_KNOB(f5_gemm_debug_flags)
+F5_DECL_KNOB(f5_gemm_tile_override)
+extern "C" int f5_op_set_operand_type(int fp16) {
+    F5_REQUIRE(fp16 == 0 || fp16 == 1, "operand type must be 0 (bf16) or 1 (fp16)");
+    g_ops.h = fp16 != 0;
+    return 0;
+}
+// host-side conversions used by f5_load_tensor, exported for the CPU tests (no GPU needed)
+extern "C" uint16_t f5_debug_f2h_bits(float f) { return f5_f2h_bits(f); }
+extern "C" float f5_debug_h_bits2f(uint16_t h) { return f5_h_bits2f(h); }
+extern "C" uint16_t f5_debug_f2bf_bits(float f) { return f5_f2bf_bits(f); }
 extern "C" int f5_debug_set_attn_version(int v) {
     F5_REQUIRE(v >= 1 && v <= 4, "attention version must be 1..4");
-    f5_attn_version = v;
+    F5_SET_BOTH(f5_attn_version, v);
     return 0;
 }
-extern int f5_attn_ablation;
 extern "C" int f5_debug_set_attn_ablation(int v) {
-    f5_attn_ablation = v;
+    F5_SET_BOTH(f5_attn_ablation, v);
     return 0;
 }
-extern int f5_attn_wide;
 extern "C" int f5_debug_set_attn_wide(int v) {
     F5_REQUIRE(v >= -1 && v <= 1, "attention wide-workgroup switch must be -1 (auto), 0 or 1");
-    f5_attn_wide = v;
+    F5_SET_BOTH(f5_attn_wide, v);
     return 0;
 }
-extern int f5_attn_kvsplit;
 extern "C" int f5_debug_set_attn_kvsplit(int v) {
     F5_REQUIRE(v == -1 || v == 1 || v == 2 || v == 4, "attention KV split must be -1 (auto), 1, 2 or 4");
-    f5_attn_kvsplit = v;
+    F5_SET_BOTH(f5_attn_kvsplit, v);
     return 0;
 }
 extern "C" int f5_debug_set_gemm_streamk(int v) {
     F5_REQUIRE(v >= 0 && v <= 2, "stream-K switch must be 0 (off), 1 (full) or 2 (hybrid)");
-    if (v != 0) RC(f5_gemm_streamk_init());   // scratch on the CURRENT device; call outside of any stream capture
-    f5_gemm_streamk = v;
+    if (v != 0) {
+        RC(f5bf::f5_gemm_streamk_init());   // scratch on the CURRENT device; call outside of any stream capture
+        RC(f5hf::f5_gemm_streamk_init());
+    }
+    F5_SET_BOTH(f5_gemm_streamk, v);
     return 0;
 }
-extern "C" int f5_debug_gemm_streamk_error() { return f5_gemm_streamk_error(); }
-extern int f5_gemm_big_kernel;
-extern int f5_gemm_v3_stagger;
+extern "C" int f5_debug_gemm_streamk_error() { return f5bf::f5_gemm_streamk_error() | f5hf::f5_gemm_streamk_error(); }
 extern "C" int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles) {
     F5_REQUIRE(v == 2 || v == 3, "big GEMM kernel must be 2 (256x256) or 3 (128x256, two workgroups per CU)");
-    f5_gemm_big_kernel = v;
-    f5_gemm_v3_stagger = stagger_cycles;
+    F5_SET_BOTH(f5_gemm_big_kernel, v);
+    F5_SET_BOTH(f5_gemm_v3_stagger, stagger_cycles);
     return 0;
 }
-extern int f5_gemm_ring_default;
 extern "C" int f5_debug_set_gemm_ring(int v) {
-    f5_gemm_ring_default = v ? 1 : 0;
+    F5_SET_BOTH(f5_gemm_ring_default, v ? 1 : 0);
     return 0;
 }
-extern int f5_gemm_order;
 extern "C" int f5_debug_set_gemm_order(int v) {
     F5_REQUIRE(v >= 0 && v <= 2, "gemm order must be 0 (auto), 1 (n fastest) or 2 (m fastest)");
-    f5_gemm_order = v;
+    F5_SET_BOTH(f5_gemm_order, v);
     return 0;
 }
-extern int f5_gemm_debug_flags;
 extern "C" int f5_debug_set_gemm_flags(int v) {
-    f5_gemm_debug_flags = v;
+    F5_SET_BOTH(f5_gemm_debug_flags, v);
     return 0;
 }
-extern int f5_gemm_tile_override;
 extern "C" int f5_debug_set_gemm_tile(int sel) {
     F5_REQUIRE(sel >= 0 && sel <= 13, "gemm tile override must be 0 (auto) .. 13");
-    f5_gemm_tile_override = sel;
+    F5_SET_BOTH(f5_gemm_tile_override, sel);
     return 0;
 }
 
@@ -1035,10 +1204,10 @@ extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, 
                "f5_op_gemm supports epilogues 0-3 and 8 only");
     F5GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A[0] = (const bf16_t*)a_hi;
-    g.A[1] = (const bf16_t*)a_lo;
-    g.W[0] = (const bf16_t*)w_hi;
-    g.W[1] = (const bf16_t*)w_lo;
+    g.A[0] = (const op16_t*)a_hi;
+    g.A[1] = (const op16_t*)a_lo;
+    g.W[0] = (const op16_t*)w_hi;
+    g.W[1] = (const op16_t*)w_lo;
     g.lda = lda;
     g.ldw = ldw;
     g.M = M;
@@ -1048,10 +1217,10 @@ extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, 
     g.bias = bias;
     g.out_f32 = out_f32;
     g.ldo = ldo;
-    g.out_bf[0] = (bf16_t*)out_bf_hi;
-    g.out_bf[1] = (bf16_t*)out_bf_lo;
+    g.out_bf[0] = (op16_t*)out_bf_hi;
+    g.out_bf[1] = (op16_t*)out_bf_lo;
     g.ldob = ldo;
-    return f5_launch_gemm(g, epi, (hipStream_t)stream);
+    return g_ops.gemm(g, epi, (hipStream_t)stream);
 }
 
 // MX-fp8 GEMM: A8/W8 e4m3 [rows][ld] + E8M0 scales [rows][K/32].  epi 0: out_f32 = acc + bias; 1: out_bf = bf16(acc + bias);
@@ -1078,7 +1247,7 @@ extern "C" int f5_op_gemm_f8(const void* a8, const void* a_scales, const void* w
     g.rowkeep = rowkeep;
     g.out_f32 = out_f32;
     g.ldo = ldo;
-    g.out_bf[0] = (bf16_t*)out_bf;
+    g.out_bf[0] = (op16_t*)out_bf;
     g.ldob = ldo;
     g.out8 = (uint8_t*)out8;
     g.out8s = (uint8_t*)out8_scales;
@@ -1094,12 +1263,12 @@ extern "C" int f5_op_attention(const void* qk_hi, const void* qk_lo, const void*
                                int hp, void* stream) {
     F5AttnArgs at;
     memset(&at, 0, sizeof(at));
-    at.qk[0] = (const bf16_t*)qk_hi;
-    at.qk[1] = (const bf16_t*)qk_lo;
-    at.vt[0] = (const bf16_t*)vt_hi;
-    at.vt[1] = (const bf16_t*)vt_lo;
-    at.out[0] = (bf16_t*)out_hi;
-    at.out[1] = (bf16_t*)out_lo;
+    at.qk[0] = (const op16_t*)qk_hi;
+    at.qk[1] = (const op16_t*)qk_lo;
+    at.vt[0] = (const op16_t*)vt_hi;
+    at.vt[1] = (const op16_t*)vt_lo;
+    at.out[0] = (op16_t*)out_hi;
+    at.out[1] = (op16_t*)out_lo;
     at.kv_len = kv_len;
     at.B = B;
     at.H = H;
@@ -1110,7 +1279,7 @@ extern "C" int f5_op_attention(const void* qk_hi, const void* qk_lo, const void*
     at.dmodel = dmodel;
     at.hp = hp;
     at.scale = scale;
-    return f5_launch_attention(at, (hipStream_t)stream);
+    return g_ops.attention(at, (hipStream_t)stream);
 }
 
 extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
@@ -1118,10 +1287,10 @@ extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_
                               int B, int seq_len, int npad, int heads, int dmodel, int nseg, void* stream) {
     F5GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A[0] = (const bf16_t*)a_hi;
-    g.A[1] = (const bf16_t*)a_lo;
-    g.W[0] = (const bf16_t*)w_hi;
-    g.W[1] = (const bf16_t*)w_lo;
+    g.A[0] = (const op16_t*)a_hi;
+    g.A[1] = (const op16_t*)a_lo;
+    g.W[0] = (const op16_t*)w_hi;
+    g.W[1] = (const op16_t*)w_lo;
     g.lda = dmodel;
     g.ldw = dmodel;
     g.M = B * seq_len;
@@ -1129,8 +1298,8 @@ extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_
     g.K = dmodel;
     g.nseg = nseg;
     g.bias = bias;
-    g.out_bf[0] = (bf16_t*)qk_hi;
-    g.out_bf[1] = (bf16_t*)qk_lo;
+    g.out_bf[0] = (op16_t*)qk_hi;
+    g.out_bf[1] = (op16_t*)qk_lo;
     g.ldob = 2 * dmodel;
     g.rope_cos = rope_cos;
     g.rope_sin = rope_sin;
@@ -1138,9 +1307,9 @@ extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_
     g.npad = npad;
     g.heads = heads;
     g.dmodel = dmodel;
-    g.vt[0] = (bf16_t*)vt_hi;
-    g.vt[1] = (bf16_t*)vt_lo;
-    return f5_launch_gemm(g, EPI_QKV_ROPE, (hipStream_t)stream);
+    g.vt[0] = (op16_t*)vt_hi;
+    g.vt[1] = (op16_t*)vt_lo;
+    return g_ops.gemm(g, EPI_QKV_ROPE, (hipStream_t)stream);
 }
 
 extern "C" int f5_op_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, void* stream) {
@@ -1152,10 +1321,10 @@ extern "C" int f5_op_convpos(const void* in_hi, const void* in_lo, const void* w
                              int nseg, int mode, void* stream) {
     F5ConvPosArgs cp;
     memset(&cp, 0, sizeof(cp));
-    cp.in[0] = (const bf16_t*)in_hi;
-    cp.in[1] = (const bf16_t*)in_lo;
-    cp.W[0] = (const bf16_t*)w_hi;
-    cp.W[1] = (const bf16_t*)w_lo;
+    cp.in[0] = (const op16_t*)in_hi;
+    cp.in[1] = (const op16_t*)in_lo;
+    cp.W[0] = (const op16_t*)w_hi;
+    cp.W[1] = (const op16_t*)w_lo;
     cp.bias = bias;
     cp.B = B;
     cp.seq_len = seq_len;
@@ -1166,20 +1335,20 @@ extern "C" int f5_op_convpos(const void* in_hi, const void* in_lo, const void* w
     cp.ldo = C;
     cp.nseg = nseg;
     cp.mode = mode;
-    cp.out_bf[0] = (bf16_t*)out_hi;
-    cp.out_bf[1] = (bf16_t*)out_lo;
+    cp.out_bf[0] = (op16_t*)out_hi;
+    cp.out_bf[1] = (op16_t*)out_lo;
     cp.out_f32 = out_f32;
-    return f5_launch_convpos(cp, (hipStream_t)stream);
+    return g_ops.convpos(cp, (hipStream_t)stream);
 }
 
 extern "C" int f5_op_ln_modulate(const float* x, const float* scale, const float* shift, void* out_hi, void* out_lo, int rows,
                                  int dim, void* stream) {
-    return f5_launch_ln_modulate(x, scale, shift, (bf16_t*)out_hi, (bf16_t*)out_lo, rows, dim, 1e-6f, (hipStream_t)stream);
+    return g_ops.ln_modulate(x, scale, shift, (op16_t*)out_hi, (op16_t*)out_lo, rows, dim, 1e-6f, (hipStream_t)stream);
 }
 
 extern "C" int f5_op_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                                void* out_hi, void* out_lo, int nbatch, int seq_len, int dim, void* stream) {
-    return f5_launch_dwconv_ln(x, dw_w, dw_b, ln_w, ln_b, (bf16_t*)out_hi, (bf16_t*)out_lo, nbatch, seq_len, dim, 1e-6f,
+    return g_ops.dwconv_ln(x, dw_w, dw_b, ln_w, ln_b, (op16_t*)out_hi, (op16_t*)out_lo, nbatch, seq_len, dim, 1e-6f,
                                (hipStream_t)stream);
 }
 
@@ -1189,7 +1358,7 @@ extern "C" size_t f5_op_grn_scratch_floats(int nbatch, int seq_len, int dim) {
 extern "C" int f5_op_grn(const float* g, const float* gamma, const float* beta, float* scratch, void* out_hi, void* out_lo,
                          int nbatch, int seq_len, int dim, void* stream) {
     float* nx = scratch + f5_grn_partial_floats(nbatch, seq_len, dim);
-    return f5_launch_grn(g, gamma, beta, scratch, nx, (bf16_t*)out_hi, (bf16_t*)out_lo, nbatch, seq_len, dim, (hipStream_t)stream);
+    return g_ops.grn(g, gamma, beta, scratch, nx, (op16_t*)out_hi, (op16_t*)out_lo, nbatch, seq_len, dim, (hipStream_t)stream);
 }
 
 extern "C" int f5_op_text_embed(const int32_t* text, int nt, const float* table, const float* pos_table, int max_pos, float* out,
@@ -1206,10 +1375,10 @@ extern "C" int f5_op_gemm_resid_keep(const void* a_hi, const void* a_lo, const v
                                      int ldo, int nseg, void* stream) {
     F5GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A[0] = (const bf16_t*)a_hi;
-    g.A[1] = (const bf16_t*)a_lo;
-    g.W[0] = (const bf16_t*)w_hi;
-    g.W[1] = (const bf16_t*)w_lo;
+    g.A[0] = (const op16_t*)a_hi;
+    g.A[1] = (const op16_t*)a_lo;
+    g.W[0] = (const op16_t*)w_hi;
+    g.W[1] = (const op16_t*)w_lo;
     g.lda = lda;
     g.ldw = ldw;
     g.M = M;
@@ -1223,11 +1392,11 @@ extern "C" int f5_op_gemm_resid_keep(const void* a_hi, const void* a_lo, const v
     g.out_f32 = out;
     g.ldo = ldo;
     F5_REQUIRE(resid != nullptr && out != nullptr, "gemm_resid_keep: null resid / out");
-    return f5_launch_gemm(g, EPI_RESID_KEEP, (hipStream_t)stream);
+    return g_ops.gemm(g, EPI_RESID_KEEP, (hipStream_t)stream);
 }
 extern "C" int f5_op_pack_bf16(const float* src, const uint8_t* rowkeep, void* out_hi, void* out_lo, int rows, int cols, int ld,
                                int col0, void* stream) {
-    return f5_launch_pack_bf16(src, rowkeep, (bf16_t*)out_hi, (bf16_t*)out_lo, rows, cols, ld, col0, (hipStream_t)stream);
+    return g_ops.pack_bf16(src, rowkeep, (op16_t*)out_hi, (op16_t*)out_lo, rows, cols, ld, col0, (hipStream_t)stream);
 }
 extern "C" int f5_op_duration_head(const float* x, const float* g, const float* w, const uint8_t* mask, float* out, int B,
                                    int seq_len, int dim, float eps, void* stream) {
@@ -1256,11 +1425,11 @@ extern "C" int f5_op_cfg_axpy(const float* pred, const float* null_pred, float c
     o.coef = coef;
     o.divisor = divisor;
     o.out = out;
-    o.xin_hi = (bf16_t*)xin_hi;
-    o.xin_lo = (bf16_t*)xin_lo;
+    o.xin_hi = (op16_t*)xin_hi;
+    o.xin_lo = (op16_t*)xin_lo;
     o.rows = rows;
     o.mel_dim = mel_dim;
-    return f5_launch_ode_stage(o, (hipStream_t)stream);
+    return g_ops.ode_stage(o, (hipStream_t)stream);
 }
 
 // x[row][col] += gate[col] * ((A W^T + bias)[row][col] * keep[row])   (dit.py:319,323; Vocos layer scale + residual)
@@ -1269,10 +1438,10 @@ extern "C" int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const v
                                      int ldx, int nseg, void* stream) {
     F5GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.A[0] = (const bf16_t*)a_hi;
-    g.A[1] = (const bf16_t*)a_lo;
-    g.W[0] = (const bf16_t*)w_hi;
-    g.W[1] = (const bf16_t*)w_lo;
+    g.A[0] = (const op16_t*)a_hi;
+    g.A[1] = (const op16_t*)a_lo;
+    g.W[0] = (const op16_t*)w_hi;
+    g.W[1] = (const op16_t*)w_lo;
     g.lda = lda;
     g.ldw = ldw;
     g.M = M;
@@ -1285,12 +1454,40 @@ extern "C" int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const v
     g.out_f32 = x;
     g.ldo = ldx;
     F5_REQUIRE(gate != nullptr && x != nullptr, "gemm_resid_gate: null gate / x");
-    return f5_launch_gemm(g, EPI_RESID_GATE, (hipStream_t)stream);
+    return g_ops.gemm(g, EPI_RESID_GATE, (hipStream_t)stream);
+}
+// out_f32 = A[row % a_row_mod] W^T + addrows[row], out_bf = the same rounded to the operand type (dit.py:250: the per-step
+// x projection added to the hoisted cond / text part; both CFG branches share the x rows through a_row_mod)
+extern "C" int f5_op_gemm_addrows(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* addrows,
+                                  int a_row_mod, float* out_f32, void* out_hi, void* out_lo, int M, int N, int K, int lda, int ldw,
+                                  int ldo, int nseg, void* stream) {
+    F5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = (const op16_t*)a_hi;
+    g.A[1] = (const op16_t*)a_lo;
+    g.W[0] = (const op16_t*)w_hi;
+    g.W[1] = (const op16_t*)w_lo;
+    g.lda = lda;
+    g.ldw = ldw;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.nseg = nseg;
+    g.a_row_mod = a_row_mod;
+    g.addrows = addrows;
+    g.ldadd = ldo;
+    g.out_f32 = out_f32;
+    g.ldo = ldo;
+    g.out_bf[0] = (op16_t*)out_hi;
+    g.out_bf[1] = (op16_t*)out_lo;
+    g.ldob = ldo;
+    F5_REQUIRE(addrows != nullptr && out_f32 != nullptr && out_hi != nullptr, "gemm_addrows: null addrows / out");
+    return g_ops.gemm(g, EPI_ADDROWS, (hipStream_t)stream);
 }
 extern "C" int f5_op_layernorm(const float* x, const float* w, const float* b, float* out_f32, void* out_hi, void* out_lo,
                                int rows, int dim, void* stream) {
-    return f5_launch_layernorm(x, w, b, out_f32, (bf16_t*)out_hi, (bf16_t*)out_lo, rows, dim, 1e-6f, (hipStream_t)stream);
+    return g_ops.layernorm(x, w, b, out_f32, (op16_t*)out_hi, (op16_t*)out_lo, rows, dim, 1e-6f, (hipStream_t)stream);
 }
 extern "C" int f5_op_im2col7(const float* x, void* out_hi, void* out_lo, int nbatch, int seq_len, int channels, void* stream) {
-    return f5_launch_im2col7(x, (bf16_t*)out_hi, (bf16_t*)out_lo, nbatch, seq_len, channels, (hipStream_t)stream);
+    return g_ops.im2col7(x, (op16_t*)out_hi, (op16_t*)out_lo, nbatch, seq_len, channels, (hipStream_t)stream);
 }

@@ -12,6 +12,8 @@
 // at 3x the matrix work.
 #include "gemm.hpp"
 
+namespace F5_NS {
+
 #define BK 64
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {
@@ -104,7 +106,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                             if (c < 2 * p.dmodel) {
                                 const float o = (c & 1) ? (v * rc[ri][nb] + partner * rs[ri][nb])
                                                         : (v * rc[ri][nb] - partner * rs[ri][nb]);
-                                bf16_t h, l;
+                                op16_t h, l;
                                 f5_split(o, h, l);
                                 p.out_bf[0][(size_t)row * p.ldob + c] = h;
                                 if (p.out_bf[1]) p.out_bf[1][(size_t)row * p.ldob + c] = l;
@@ -112,7 +114,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                                 const int c2 = c - 2 * p.dmodel;
                                 const int head = c2 >> 6, d = c2 & 63;
                                 const size_t off = ((size_t)(b * p.heads + head) * 64 + d) * p.npad + n;
-                                bf16_t h, l;
+                                op16_t h, l;
                                 f5_split(v, h, l);
                                 p.vt[0][off] = h;
                                 if (p.vt[1]) p.vt[1][off] = l;
@@ -124,7 +126,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                         } else if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16) {
                             if (EPI == EPI_GELU_TANH) v = f5_gelu_tanh(v);
                             if (EPI == EPI_GELU_ERF_BF16) v = f5_gelu_erf(v);
-                            bf16_t h, l;
+                            op16_t h, l;
                             f5_split(v, h, l);
                             p.out_bf[0][(size_t)row * p.ldob + c] = h;
                             if (p.out_bf[1]) p.out_bf[1][(size_t)row * p.ldob + c] = l;
@@ -136,7 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                         } else if (EPI == EPI_ADDROWS) {
                             v += pre[r][nb];
                             p.out_f32[(size_t)row * p.ldo + c] = v;
-                            bf16_t h, l;
+                            op16_t h, l;
                             f5_split(v, h, l);
                             p.out_bf[0][(size_t)row * p.ldob + c] = h;
                             if (p.out_bf[1]) p.out_bf[1][(size_t)row * p.ldob + c] = l;
@@ -170,7 +172,7 @@ template <int EPI, int MB, int NB>
 __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
     constexpr int BMt = 64 * MB, BNt = 64 * NB;
     constexpr int NA = MB * 2, NW = NB * 2;      // 16-byte chunks staged per thread for A / W
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2][(BMt + BNt) * BK];  // [buffer][A tile | W tile]
+    __shared__ __attribute__((aligned(16))) op16_t smem[2][(BMt + BNt) * BK];  // [buffer][A tile | W tile]
 
     // XCD-aware, bijective remap: workgroup b runs on XCD b % 8; give each XCD a contiguous range
     const int bid = blockIdx.x;
@@ -254,8 +256,8 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
     const int frow = lane & 31;
     const int fk = lane >> 5;
     // fragment read pointers per K sub-step; buffer, row block and A / W part are ds_read immediates (K loop unrolled 2x)
-    const bf16_t* pa[4];
-    const bf16_t* pb[4];
+    const op16_t* pa[4];
+    const op16_t* pb[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         pa[ks] = &smem[0][0] + swz_off(wm * (32 * MB) + frow, ks * 2 + fk);
@@ -266,14 +268,14 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
     {                                                                                                         \
         if ((tt_) + 1 < T) LOAD_TILE();                                                                       \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
-            bf16x8 af[MB], bfr[NB];                                                                           \
+            op16x8 af[MB], bfr[NB];                                                                           \
             _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                 \
-                af[mb] = *reinterpret_cast<const bf16x8*>(pa[ks] + (CUR) * (BMt + BNt) * BK + mb * 32 * BK);  \
+                af[mb] = *reinterpret_cast<const op16x8*>(pa[ks] + (CUR) * (BMt + BNt) * BK + mb * 32 * BK);  \
             _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                 \
-                bfr[nb] = *reinterpret_cast<const bf16x8*>(pb[ks] + (CUR) * (BMt + BNt) * BK + nb * 32 * BK); \
+                bfr[nb] = *reinterpret_cast<const op16x8*>(pb[ks] + (CUR) * (BMt + BNt) * BK + nb * 32 * BK); \
             _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                 \
                 _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                             \
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0); \
+                    acc[mb][nb] = F5_MFMA32(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0); \
         }                                                                                                     \
         if ((tt_) + 1 < T) STORE_TILE(1 - (CUR));                                                             \
         __syncthreads();                                                                                      \
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
 // =================================================================================================
 #define V2_HALF_ELEMS (128 * BK)
 
-__device__ __forceinline__ void glds16(const bf16_t* gptr, bf16_t* lds_wave_base) {
+__device__ __forceinline__ void glds16(const op16_t* gptr, op16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
@@ -325,7 +327,7 @@ __device__ __forceinline__ void glds16(const bf16_t* gptr, bf16_t* lds_wave_base
 // the token axis; those 16-byte stores may be only 2-byte aligned (legal on gfx950, tools/probes/unaligned.hip) and
 // are split element-wise where a chunk crosses a batch-element boundary.
 template <int EPI, int MBW, int NBW>
-__device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], bf16_t* reg, int row0,
+__device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
                                                      int colbase, int lane) {
     constexpr int W = 32 * NBW;
     constexpr int LD = W + 8;
@@ -339,8 +341,8 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
     const bool is_v = (EPI == EPI_QKV_ROPE) && (colbase >= 2 * p.dmodel);
 
     if (!is_v) {
-        bf16_t* rh = reg;
-        bf16_t* rl = reg + 32 * LD;
+        op16_t* rh = reg;
+        op16_t* rl = reg + 32 * LD;
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) {
             const int rowblk = row0 + mb * 32;
@@ -382,7 +384,7 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
                             const float c = rc[rg][ri][nb & (PAR - 1)], sn = rs[rg][ri][nb & (PAR - 1)];
                             v = (lcol & 1) ? (v * c + partner * sn) : (v * c - partner * sn);
                         }
-                        bf16_t h, l;
+                        op16_t h, l;
                         f5_split(v, h, l);
                         rh[lrow * LD + nb * 32 + lcol] = h;
                         if (two) rl[lrow * LD + nb * 32 + lcol] = l;
@@ -532,7 +534,7 @@ __device__ __forceinline__ const char* v2_uniform_ptr(const void* ptr) {
 template <int EPI, bool SK>
 __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles_n, int ntiles, float* sk_part, int* sk_flag,
                                                          int* sk_err, int sk_hybrid) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * V2_HALF_ELEMS];   // [A0,A1,B0,B1][ring buffer][128*64]
+    __shared__ __attribute__((aligned(16))) op16_t smem[2 * 4 * V2_HALF_ELEMS];   // [A0,A1,B0,B1][ring buffer][128*64]
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
@@ -585,8 +587,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     // chip nothing else issues on a SIMD while an MFMA is in flight, tools/probes/coissue.hip: every non-MFMA instruction of
     // the loop is paid in full)
     // (LDS layout [A0,A1,B0,B1][ring buffer][128 x 64]: the ring-buffer offset, 16 KB, is an immediate as well)
-    const bf16_t* pa[4];
-    const bf16_t* pb[4];
+    const op16_t* pa[4];
+    const op16_t* pb[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         pa[ks] = smem + (wm * 2) * V2_HALF_ELEMS + swz_off(frow, ks * 2 + fk);
@@ -653,19 +655,19 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     // and sat in front of every one of the four issue points of a K step)
 #define V2_ISSUE_A(par_, h_, Ap_, k0_)                                                              \
     {                                                                                               \
-        bf16_t* dst_ = smem + ((h_) * 2 + (par_)) * V2_HALF_ELEMS;                                  \
+        op16_t* dst_ = smem + ((h_) * 2 + (par_)) * V2_HALF_ELEMS;                                  \
         const char* src_ = reinterpret_cast<const char*>(Ap_);                                      \
         const uint32_t kb_ = (uint32_t)(k0_) * 2u;                                                  \
-        glds16(reinterpret_cast<const bf16_t*>(src_ + (srcA[(h_)][0] + kb_)), dst_ + ldsoff[0]);    \
-        glds16(reinterpret_cast<const bf16_t*>(src_ + (srcA[(h_)][1] + kb_)), dst_ + ldsoff[1]);    \
+        glds16(reinterpret_cast<const op16_t*>(src_ + (srcA[(h_)][0] + kb_)), dst_ + ldsoff[0]);    \
+        glds16(reinterpret_cast<const op16_t*>(src_ + (srcA[(h_)][1] + kb_)), dst_ + ldsoff[1]);    \
     }
 #define V2_ISSUE_B(par_, h_, Wp_, k0_)                                                              \
     {                                                                                               \
-        bf16_t* dst_ = smem + ((2 + (h_)) * 2 + (par_)) * V2_HALF_ELEMS;                            \
+        op16_t* dst_ = smem + ((2 + (h_)) * 2 + (par_)) * V2_HALF_ELEMS;                            \
         const char* src_ = reinterpret_cast<const char*>(Wp_);                                      \
         const uint32_t kb_ = (uint32_t)(k0_) * 2u;                                                  \
-        glds16(reinterpret_cast<const bf16_t*>(src_ + (srcB[(h_)][0] + kb_)), dst_ + ldsoff[0]);    \
-        glds16(reinterpret_cast<const bf16_t*>(src_ + (srcB[(h_)][1] + kb_)), dst_ + ldsoff[1]);    \
+        glds16(reinterpret_cast<const op16_t*>(src_ + (srcB[(h_)][0] + kb_)), dst_ + ldsoff[0]);    \
+        glds16(reinterpret_cast<const op16_t*>(src_ + (srcB[(h_)][1] + kb_)), dst_ + ldsoff[1]);    \
     }
     // (segment, K offset) of K-tile tt: segment 0 = A.hi W.hi, 1 = A.lo W.hi, 2 = A.hi W.lo
 #define V2_SEGK(tt_, seg_, k0_)              \
@@ -690,8 +692,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     int a_seg, a_k0, b_seg, b_k0;                     // running state: tile tt+1 (A halves) and tile tt+2 (B halves)
     {
         V2_SEGK(t0, s0_, k00_);
-        const bf16_t* Ap0 = s0_ == 1 ? p.A[1] : p.A[0];
-        const bf16_t* Wp0 = s0_ == 2 ? p.W[1] : p.W[0];
+        const op16_t* Ap0 = s0_ == 1 ? p.A[1] : p.A[0];
+        const op16_t* Wp0 = s0_ == 2 ? p.W[1] : p.W[0];
         V2_ISSUE_A(0, 0, Ap0, k00_);
         V2_ISSUE_A(0, 1, Ap0, k00_);
         V2_ISSUE_B(0, 0, Wp0, k00_);
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         b_k0 = a_k0;
     }
     if (t0 + 1 < t1) {
-        const bf16_t* Wp1 = b_seg == 2 ? p.W[1] : p.W[0];
+        const op16_t* Wp1 = b_seg == 2 ? p.W[1] : p.W[0];
         V2_ISSUE_B(1, 0, Wp1, b_k0);
         V2_ISSUE_B(1, 1, Wp1, b_k0);
         b_k0 += BK;
@@ -721,9 +723,9 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     V2_BARRIER();
 
     // one K tile out of ring buffer PAR (compile-time): 4 phases of 8 MFMAs, each issuing one half tile of a later K tile
-    bf16x8 af[2][4], bfr[2][4];
-#define V2_FRAG_A(PAR, ks, rowoff) (*reinterpret_cast<const bf16x8*>(pa[ks] + (PAR) * V2_HALF_ELEMS + (rowoff) * BK))
-#define V2_FRAG_B(PAR, ks, rowoff) (*reinterpret_cast<const bf16x8*>(pb[ks] + (PAR) * V2_HALF_ELEMS + (rowoff) * BK))
+    op16x8 af[2][4], bfr[2][4];
+#define V2_FRAG_A(PAR, ks, rowoff) (*reinterpret_cast<const op16x8*>(pa[ks] + (PAR) * V2_HALF_ELEMS + (rowoff) * BK))
+#define V2_FRAG_B(PAR, ks, rowoff) (*reinterpret_cast<const op16x8*>(pb[ks] + (PAR) * V2_HALF_ELEMS + (rowoff) * BK))
 #define V2_KSTEP(PAR, tt)                                                                                               \
     {                                                                                                                   \
         /* phase 1: A(mq=0), B(nq=0); quadrant (0,0); issue A0(t+1) */                                                  \
@@ -734,13 +736,13 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         if ((tt) + 1 < t1) V2_ISSUE_A(1 - PAR, 0, Apn, a_k0);                                            \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
-                acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[0][ks], acc[mb][0], 0, 0, 0);      \
+                acc[mb][0] = F5_MFMA32(af[mb][ks], bfr[0][ks], acc[mb][0], 0, 0, 0);      \
         /* phase 2: B(nq=1); quadrant (0,1); issue A1(t+1) */                                                           \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) bfr[1][ks] = V2_FRAG_B(PAR, ks, 32);                           \
         if ((tt) + 1 < t1) V2_ISSUE_A(1 - PAR, 1, Apn, a_k0);                                            \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
-                acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[1][ks], acc[mb][1], 0, 0, 0);      \
+                acc[mb][1] = F5_MFMA32(af[mb][ks], bfr[1][ks], acc[mb][1], 0, 0, 0);      \
         V2_BARRIER(); /* every wave has finished reading the B halves of this tile */                                   \
         /* phase 3: A(mq=1); quadrant (1,1); issue B0(t+2) */                                                           \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
@@ -748,13 +750,13 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         if ((tt) + 2 < t1) V2_ISSUE_B(PAR, 0, Wpn, b_k0);                                                \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
-                acc[2 + mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[1][ks], acc[2 + mb][1], 0, 0, 0); \
+                acc[2 + mb][1] = F5_MFMA32(af[mb][ks], bfr[1][ks], acc[2 + mb][1], 0, 0, 0); \
         V2_BARRIER(); /* every wave has finished reading the A halves of this tile */                                   \
         /* phase 4: quadrant (1,0) from registers; issue B1(t+2) */                                                     \
         if ((tt) + 2 < t1) V2_ISSUE_B(PAR, 1, Wpn, b_k0);                                                \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
-                acc[2 + mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb][ks], bfr[0][ks], acc[2 + mb][0], 0, 0, 0); \
+                acc[2 + mb][0] = F5_MFMA32(af[mb][ks], bfr[0][ks], acc[2 + mb][0], 0, 0, 0); \
         /* next tile's operands: everything but the two B halves just issued for tile t+2 must have landed */           \
         if ((tt) + 2 < t1) {                                                                             \
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                            \
@@ -775,8 +777,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             Wpn = b_seg == 2 ? p.W[1] : p.W[0];                                                                         \
         }                                                                                                               \
     }
-    const bf16_t* Apn = a_seg == 1 ? p.A[1] : p.A[0];   // operand (bf16x3 segment) pointers of the tiles being staged
-    const bf16_t* Wpn = b_seg == 2 ? p.W[1] : p.W[0];
+    const op16_t* Apn = a_seg == 1 ? p.A[1] : p.A[0];   // operand (bf16x3 segment) pointers of the tiles being staged
+    const op16_t* Wpn = b_seg == 2 ? p.W[1] : p.W[0];
     for (int tt = t0; tt < t1; tt += 2) {
         V2_KSTEP(0, tt);
         if (tt + 1 < t1) V2_KSTEP(1, tt + 1);
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     constexpr int STAGE = (BMt + BNt) * BK;             // elements
     constexpr int RING = NST * STAGE;
     static_assert(KS * RING * 2 <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) bf16_t smem_all[KS * RING];
+    __shared__ __attribute__((aligned(16))) op16_t smem_all[KS * RING];
 
     const int bid = blockIdx.x;
     const int q = ntiles >> 3, r = ntiles & 7;
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     const int grp = wave_all / (WM * WN), wave = wave_all % (WM * WN);
     const int tg = tid - grp * NTG;
     const int wm = wave / WN, wn = wave % WN;
-    bf16_t* smem = smem_all + grp * RING;
+    op16_t* smem = smem_all + grp * RING;
 
     // staging: 32-bit BYTE offsets added to a uniform operand pointer (SGPR base + VGPR offset form of global_load_lds)
     uint32_t a_src[NA], w_src[NW];
@@ -979,14 +981,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     }
 #define RING_ISSUE(ST_)                                                                                      \
     {                                                                                                        \
-        bf16_t* st_ = smem + (ST_) * STAGE;                                                                  \
+        op16_t* st_ = smem + (ST_) * STAGE;                                                                  \
         const char* Ap_ = reinterpret_cast<const char*>((is_seg == 1) ? p.A[1] : p.A[0]);                    \
         const char* Wp_ = reinterpret_cast<const char*>((is_seg == 2) ? p.W[1] : p.W[0]);                    \
         const uint32_t kb_ = (uint32_t)is_k0 * 2u;                                                           \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                       \
-            glds16(reinterpret_cast<const bf16_t*>(Ap_ + (a_src[i] + kb_)), st_ + a_dst[i]);                 \
+            glds16(reinterpret_cast<const op16_t*>(Ap_ + (a_src[i] + kb_)), st_ + a_dst[i]);                 \
         _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                       \
-            glds16(reinterpret_cast<const bf16_t*>(Wp_ + (w_src[i] + kb_)), st_ + w_dst[i]);                 \
+            glds16(reinterpret_cast<const op16_t*>(Wp_ + (w_src[i] + kb_)), st_ + w_dst[i]);                 \
         is_k0 += KS * BK;                                                                                    \
         while (is_k0 >= p.K) {                   /* at most once unless K < KS * 64 */                       \
             is_k0 -= p.K;                                                                                    \
@@ -1014,8 +1016,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     constexpr int SPS = 65536 / (STAGE * 2) < NST ? 65536 / (STAGE * 2) : NST;   // stages per 64 KB window (16-bit ds_read offsets)
     static_assert(SPS >= 1, "a stage must fit the ds_read offset field");
     constexpr int NSET = (NST + SPS - 1) / SPS;                      // windows = pointer sets
-    const bf16_t* pa[NSET][4];
-    const bf16_t* pb[NSET][4];
+    const op16_t* pa[NSET][4];
+    const op16_t* pb[NSET][4];
 #pragma unroll
     for (int w2 = 0; w2 < NSET; ++w2)
 #pragma unroll
@@ -1023,9 +1025,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
             pa[w2][ks] = smem + w2 * SPS * STAGE + swz_off(wm * (32 * MB) + frow, ks * 2 + fk);
             pb[w2][ks] = smem + w2 * SPS * STAGE + BMt * BK + swz_off(wn * (32 * NB) + frow, ks * 2 + fk);
         }
-    bf16x8 abl_frag;
+    op16x8 abl_frag;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) abl_frag[e] = (bf16_t)0;
+    for (int e = 0; e < 8; ++e) abl_frag[e] = (op16_t)0;
     if (ABL & 4) asm volatile("" : "+v"(abl_frag));
 #define RING_STEP(ST_, jj_)                                                                                         \
     {                                                                                                               \
@@ -1044,15 +1046,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
         if (!(KS > 1 && (jj_) >= Tg)) {              /* wave-uniform: a group without a tile left still meets the barrier */ \
             constexpr int W2 = (ST_) / SPS, SL = (ST_) % SPS;                                                        \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                      \
-                bf16x8 af[MB], bfr[NB];                                                                             \
+                op16x8 af[MB], bfr[NB];                                                                             \
                 _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                   \
-                    af[mb] = (ABL & 4) ? abl_frag : *reinterpret_cast<const bf16x8*>(pa[W2][ks] + SL * STAGE + mb * 32 * BK); \
+                    af[mb] = (ABL & 4) ? abl_frag : *reinterpret_cast<const op16x8*>(pa[W2][ks] + SL * STAGE + mb * 32 * BK); \
                 _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                   \
-                    bfr[nb] = (ABL & 4) ? abl_frag : *reinterpret_cast<const bf16x8*>(pb[W2][ks] + SL * STAGE + nb * 32 * BK); \
+                    bfr[nb] = (ABL & 4) ? abl_frag : *reinterpret_cast<const op16x8*>(pb[W2][ks] + SL * STAGE + nb * 32 * BK); \
                 _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                   \
                     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                             \
                         if (ABL & 2) asm volatile("" ::"v"(af[mb]), "v"(bfr[nb]));                                  \
-                        else acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0); \
+                        else acc[mb][nb] = F5_MFMA32(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0); \
                     }                                                                                               \
             }                                                                                                       \
         }                                                                                                           \
@@ -1200,7 +1202,7 @@ __global__ __launch_bounds__(256, 2) void f5_gemm_v3_kernel(F5GemmArgs p, int ti
     constexpr int BMt = 128, BNt = 256, NST = 3;
     constexpr int NA = 2, NW = 4, G = NA + NW;
     constexpr int STAGE = (BMt + BNt) * V3_BK;          // 12288 elements = 24 KB
-    __shared__ __attribute__((aligned(16))) bf16_t smem[NST * STAGE];
+    __shared__ __attribute__((aligned(16))) op16_t smem[NST * STAGE];
 
     const int bid = blockIdx.x;
     const int q = ntiles >> 3, r = ntiles & 7;
@@ -1253,9 +1255,9 @@ __global__ __launch_bounds__(256, 2) void f5_gemm_v3_kernel(F5GemmArgs p, int ti
     {                                                                                                        \
         const int seg_ = (tt_) / kt;                                                                         \
         const int k0_ = ((tt_) - seg_ * kt) * V3_BK;                                                         \
-        bf16_t* st_ = smem + ((tt_) % NST) * STAGE;                                                          \
-        const bf16_t* Ap_ = (seg_ == 1) ? p.A[1] : p.A[0];                                                   \
-        const bf16_t* Wp_ = (seg_ == 2) ? p.W[1] : p.W[0];                                                   \
+        op16_t* st_ = smem + ((tt_) % NST) * STAGE;                                                          \
+        const op16_t* Ap_ = (seg_ == 1) ? p.A[1] : p.A[0];                                                   \
+        const op16_t* Wp_ = (seg_ == 2) ? p.W[1] : p.W[0];                                                   \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) glds16(Ap_ + a_src[i] + k0_, st_ + a_dst[i]);         \
         _Pragma("unroll") for (int i = 0; i < NW; ++i) glds16(Wp_ + w_src[i] + k0_, st_ + w_dst[i]);         \
     }
@@ -1284,21 +1286,21 @@ __global__ __launch_bounds__(256, 2) void f5_gemm_v3_kernel(F5GemmArgs p, int ti
         asm volatile("" ::: "memory");
         if (tt + 2 < T) V3_ISSUE(tt + 2);                                 // slot of tile tt-1: every wave is past it
 
-        const bf16_t* sA = smem + (tt % NST) * STAGE;
-        const bf16_t* sB = sA + BMt * V3_BK;
+        const op16_t* sA = smem + (tt % NST) * STAGE;
+        const op16_t* sB = sA + BMt * V3_BK;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2], bfr[4];
+            op16x8 af[2], bfr[4];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) af[mb] = *reinterpret_cast<const bf16x8*>(&sA[swz32(wm * 64 + mb * 32 + frow, ks * 2 + fk)]);
+            for (int mb = 0; mb < 2; ++mb) af[mb] = *reinterpret_cast<const op16x8*>(&sA[swz32(wm * 64 + mb * 32 + frow, ks * 2 + fk)]);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const bf16x8*>(&sB[swz32(wn * 128 + nb * 32 + frow, ks * 2 + fk)]);
+            for (int nb = 0; nb < 4; ++nb) bfr[nb] = *reinterpret_cast<const op16x8*>(&sB[swz32(wn * 128 + nb * 32 + frow, ks * 2 + fk)]);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = F5_MFMA32(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
     }
@@ -1313,7 +1315,7 @@ __global__ __launch_bounds__(256, 2) void f5_gemm_v3_kernel(F5GemmArgs p, int ti
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    bf16_t* reg = smem + wave * 9216;     // 18 KB per wave
+    op16_t* reg = smem + wave * 9216;     // 18 KB per wave
     if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
         staged_epilogue_bf16<EPI, 2, 4>(p, acc, reg, m0 + wm * 64, n0 + wn * 128, lane);
     } else if (EPI == EPI_RESID_GATE) {
@@ -1581,7 +1583,7 @@ __global__ __launch_bounds__(512) void f5_gemm256f8_kernel(F5GemmArgs p, int til
 #undef F8_ISSUE_S
 #undef F8_BARRIER
 
-    bf16_t* stage = reinterpret_cast<bf16_t*>(smem) + wave * 8192;
+    op16_t* stage = reinterpret_cast<op16_t*>(smem) + wave * 8192;
     if (EPI == EPI_BF16 || EPI == EPI_QKV_ROPE) {
         staged_epilogue_bf16<EPI, 4, 2>(p, acc, stage, m0 + wm * 128, n0 + wn * 64, lane);
     } else if (EPI == EPI_GELU_TANH) {
@@ -1735,3 +1737,4 @@ int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
         default: f5_set_error("gemm: unknown epilogue %d", epi); return 2;
     }
 }
+}  // namespace F5_NS

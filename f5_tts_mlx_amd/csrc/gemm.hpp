@@ -1,22 +1,26 @@
 // bf16 MFMA GEMM  C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogues) for gfx950.
-#pragma once
-#include "common.hpp"
+#include "op16.hpp"
 
-enum F5Epi : int {
-    EPI_F32 = 0,         // out_f32 = acc + bias
-    EPI_BF16 = 1,        // out_bf  = bf16(acc + bias)
-    EPI_GELU_TANH = 2,   // out_bf  = bf16(gelu_tanh(acc + bias))                 (dit.py:94-99)
-    EPI_GELU_ERF = 3,    // out_f32 = gelu_erf(acc + bias)                        (convnext_v2.py:50-51)
-    EPI_RESID_GATE = 4,  // out_f32 += gate[col] * ((acc + bias) * keep[row])     (dit.py:172-173,319,323)
-    EPI_QKV_ROPE = 5,    // q,k: rope(acc + bias) -> qk[row][col]; v -> vt[b,h][d][n] (dit.py:136-158)
-    EPI_ADDROWS = 6,     // out_f32 = acc + addrows[row][col]; out_bf = bf16(same)  (dit.py:250 split GEMM)
-    EPI_RESID_KEEP = 7,  // out_f32 = (resid[row][col] + acc + bias) * keep[row]  (convnext_v2.py:53-54, dit.py:225)
-    EPI_GELU_ERF_BF16 = 8,  // out_bf = bf16(gelu_erf(acc + bias))              (Vocos ConvNeXt block)
-};
+// one body per operand build (this header is included once per F5_F16 value)
+#if F5_F16
+#ifndef F5_GEMM_HPP_F16
+#define F5_GEMM_HPP_F16
+#define F5_GEMM_HPP_BODY
+#endif
+#else
+#ifndef F5_GEMM_HPP_BF16
+#define F5_GEMM_HPP_BF16
+#define F5_GEMM_HPP_BODY
+#endif
+#endif
+#ifdef F5_GEMM_HPP_BODY
+#undef F5_GEMM_HPP_BODY
+namespace F5_NS {
+
 
 struct F5GemmArgs {
-    const bf16_t* A[2];   // hi, lo   [a_rows][lda]
-    const bf16_t* W[2];   // hi, lo   [>=ceil128(N)][ldw]  (row = output feature, K contiguous)
+    const op16_t* A[2];   // hi, lo   [a_rows][lda]
+    const op16_t* W[2];   // hi, lo   [>=ceil128(N)][ldw]  (row = output feature, K contiguous)
     int lda, ldw;
     int M, N, K;          // K % 64 == 0
     int nseg;             // 1 = bf16, 3 = bf16x3 (hi*hi + lo*hi + hi*lo)
@@ -24,7 +28,7 @@ struct F5GemmArgs {
     const float* bias;    // [N] or null
     float* out_f32;
     int ldo;
-    bf16_t* out_bf[2];    // hi, lo (lo may be null)
+    op16_t* out_bf[2];    // hi, lo (lo may be null)
     int ldob;
     const float* gate;        // [N]
     const uint8_t* rowkeep;   // [M] or null
@@ -35,7 +39,7 @@ struct F5GemmArgs {
     const float* rope_cos;    // [seq_len][dim_head/2]
     const float* rope_sin;
     int seq_len, npad, heads, dmodel;
-    bf16_t* vt[2];            // [B*heads][64][npad]
+    op16_t* vt[2];            // [B*heads][64][npad]
     int debug_flags;          // bit 0: skip the epilogue (timing experiments only)
     // ---- MX-fp8 path (f5_launch_gemm_f8): e4m3 operands with one E8M0 scale per 32 consecutive K elements
     const uint8_t* A8;        // [a_rows][lda8] bytes
@@ -61,3 +65,5 @@ extern int f5_gemm_streamk;
 int f5_launch_gemm_f8(const F5GemmArgs& a, int epi, hipStream_t stream);
 // rows of fp32 -> e4m3 + E8M0 block scales (scale = 2^ceil(log2(amax/448)), round to nearest even, no saturation needed)
 int f5_launch_quantize_mx(const float* x, int ldx, uint8_t* q, int ldq, uint8_t* sc, int rows, int cols, hipStream_t stream);
+}  // namespace F5_NS
+#endif

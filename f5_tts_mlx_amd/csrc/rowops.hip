@@ -3,13 +3,15 @@
 // the MFMA kernels.  Loads/stores are 16 B per lane wherever the layout allows it.
 #include "rowops.hpp"
 
+namespace F5_NS {
+
 // =================================================================================================
 // LayerNorm (no affine) + adaLN modulation: one wave per row, NV float4 per lane (dim = NV*256)
 // =================================================================================================
 template <int NV>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, bf16_t* __restrict__ out_hi,
-                                                          bf16_t* __restrict__ out_lo, int rows, float eps) {
+                                                          const float* __restrict__ shift, op16_t* __restrict__ out_hi,
+                                                          op16_t* __restrict__ out_lo, int rows, float eps) {
     constexpr int DIM = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     }
 }
 
-int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, bf16_t* out_hi, bf16_t* out_lo,
+int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, op16_t* out_hi, op16_t* out_lo,
                           int rows, int dim, float eps, hipStream_t s) {
     F5_REQUIRE(dim % 256 == 0 && dim >= 256 && dim <= 1024, "ln_modulate: dim must be 256/512/768/1024 (got %d)", dim);
     const dim3 grid(f5_cdiv(rows, 4)), block(256);
@@ -122,15 +124,14 @@ int f5_launch_ln_modulate_f8(const float* x, const float* scale, const float* sh
     return 0;
 }
 // bf16 rows -> MX-fp8 (weights at finalize time; the bf16 copy is the source so both precisions see the same rounding)
-__global__ __launch_bounds__(256) void quantize_mx_bf16_kernel(const bf16_t* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256) void quantize_mx_bf16_kernel(const op16_t* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq,
                                                                uint8_t* __restrict__ sc, int rows, int cols) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     for (int c0 = lane * 4; c0 < cols; c0 += 256) {
-        const u32x2 raw = *reinterpret_cast<const u32x2*>(x + (size_t)row * ldx + c0);
-        const float v0 = __uint_as_float(raw[0] << 16), v1 = __uint_as_float(raw[0] & 0xFFFF0000u);
-        const float v2 = __uint_as_float(raw[1] << 16), v3 = __uint_as_float(raw[1] & 0xFFFF0000u);
+        const op16x4 raw = *reinterpret_cast<const op16x4*>(x + (size_t)row * ldx + c0);
+        const float v0 = (float)raw[0], v1 = (float)raw[1], v2 = (float)raw[2], v3 = (float)raw[3];
         float am = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
         am = fmaxf(am, __shfl_xor(am, 1, 64));
         am = fmaxf(am, __shfl_xor(am, 2, 64));
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void quantize_mx_bf16_kernel(const bf16_t* __r
         if ((lane & 7) == 0) sc[(size_t)row * (cols >> 5) + (c0 >> 5)] = (uint8_t)e8;
     }
 }
-int f5_launch_quantize_mx_bf16(const bf16_t* x, int ldx, uint8_t* q, int ldq, uint8_t* sc, int rows, int cols, hipStream_t stream) {
+int f5_launch_quantize_mx_bf16(const op16_t* x, int ldx, uint8_t* q, int ldq, uint8_t* sc, int rows, int cols, hipStream_t stream) {
     F5_REQUIRE(rows > 0 && cols > 0 && cols % 32 == 0 && ldx % 4 == 0 && ldq % 4 == 0, "quantize_mx_bf16: cols must be a multiple of 32");
     hipLaunchKernelGGL(quantize_mx_bf16_kernel, dim3(f5_cdiv(rows, 4)), dim3(256), 0, stream, x, ldx, q, ldq, sc, rows, cols);
     F5_LAUNCH_CHECK();
@@ -155,8 +156,8 @@ int f5_launch_quantize_mx_bf16(const bf16_t* x, int ldx, uint8_t* q, int ldq, ui
 template <int NV>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
                                                         const float* __restrict__ dw_b, const float* __restrict__ ln_w,
-                                                        const float* __restrict__ ln_b, bf16_t* __restrict__ out_hi,
-                                                        bf16_t* __restrict__ out_lo, int rows, int seq_len, float eps) {
+                                                        const float* __restrict__ ln_b, op16_t* __restrict__ out_hi,
+                                                        op16_t* __restrict__ out_lo, int rows, int seq_len, float eps) {
     constexpr int DIM = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
 }
 
 int f5_launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
-                        bf16_t* out_hi, bf16_t* out_lo, int nbatch, int seq_len, int dim, float eps, hipStream_t s) {
+                        op16_t* out_hi, op16_t* out_lo, int nbatch, int seq_len, int dim, float eps, hipStream_t s) {
     F5_REQUIRE(dim % 256 == 0 && dim >= 256 && dim <= 1024, "dwconv_ln: dim must be 256/512/768/1024 (got %d)", dim);
     const int rows = nbatch * seq_len;
     const dim3 grid(f5_cdiv(rows, 4)), block(256);
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void grn_finish_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict__ g, const float* __restrict__ nx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int seq_len,
+                                                        op16_t* __restrict__ out_hi, op16_t* __restrict__ out_lo, int seq_len,
                                                         int dim, size_t total4) {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i4 >= total4) return;
@@ -286,8 +287,8 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict_
     if (out_lo) *reinterpret_cast<u32x2*>(out_lo + idx) = u32x2{f5_pack2_lo(y[0], y[1]), f5_pack2_lo(y[2], y[3])};
 }
 
-int f5_launch_grn(const float* g, const float* gamma, const float* beta, float* partial, float* nx, bf16_t* out_hi,
-                  bf16_t* out_lo, int nbatch, int seq_len, int dim, hipStream_t s) {
+int f5_launch_grn(const float* g, const float* gamma, const float* beta, float* partial, float* nx, op16_t* out_hi,
+                  op16_t* out_lo, int nbatch, int seq_len, int dim, hipStream_t s) {
     F5_REQUIRE(dim % 4 == 0, "grn: dim must be a multiple of 4");
     const int nchunk = f5_cdiv(seq_len, GRN_CHUNK);
     hipLaunchKernelGGL(grn_partial_kernel, dim3(f5_cdiv(dim, 256), nchunk, nbatch), dim3(256), 0, s, g, partial, seq_len, dim,
@@ -345,8 +346,8 @@ int f5_launch_text_embed(const int* text, int nt, const float* table, const floa
 // branch 0: cond masked by n < lens[b] (step_cond, cfm.py:331); branch 1: cond dropped (dit.py:249)
 // =================================================================================================
 __global__ __launch_bounds__(256) void pack_cond_text_kernel(const float* __restrict__ cond, const int* __restrict__ lens,
-                                                             const float* __restrict__ text_emb, bf16_t* __restrict__ out_hi,
-                                                             bf16_t* __restrict__ out_lo, int B, int seq_len, int mel_dim,
+                                                             const float* __restrict__ text_emb, op16_t* __restrict__ out_hi,
+                                                             op16_t* __restrict__ out_lo, int B, int seq_len, int mel_dim,
                                                              int dt) {
     const int n = blockIdx.x, b = blockIdx.y, br = blockIdx.z;
     const int ld = 128 + dt;
@@ -359,14 +360,14 @@ __global__ __launch_bounds__(256) void pack_cond_text_kernel(const float* __rest
         } else {
             v = text_emb[(((size_t)br * B + b) * seq_len + n) * dt + (c - 128)];
         }
-        bf16_t h, l;
+        op16_t h, l;
         f5_split(v, h, l);
         out_hi[orow + c] = h;
         if (out_lo) out_lo[orow + c] = l;
     }
 }
 
-int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, bf16_t* out_hi, bf16_t* out_lo,
+int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, op16_t* out_hi, op16_t* out_lo,
                              int B, int seq_len, int mel_dim, int dt, hipStream_t s) {
     F5_REQUIRE(mel_dim <= 128, "pack_cond_text: mel_dim must be <= 128");
     hipLaunchKernelGGL(pack_cond_text_kernel, dim3(seq_len, B, 2), dim3(256), 0, s, cond, lens, text_emb, out_hi, out_lo, B,
@@ -511,19 +512,19 @@ int f5_launch_text_pos_table(float* table, int max_pos, int dim, hipStream_t s) 
 // =================================================================================================
 // ODE state plumbing
 // =================================================================================================
-__global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ y, bf16_t* __restrict__ out_hi,
-                                                     bf16_t* __restrict__ out_lo, int rows, int mel_dim) {
+__global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ y, op16_t* __restrict__ out_hi,
+                                                     op16_t* __restrict__ out_lo, int rows, int mel_dim) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)rows * 128) return;
     const size_t row = i >> 7;
     const int c = (int)(i & 127);
     const float v = (c < mel_dim) ? y[row * mel_dim + c] : 0.0f;
-    bf16_t h, l;
+    op16_t h, l;
     f5_split(v, h, l);
     out_hi[i] = h;
     if (out_lo) out_lo[i] = l;
 }
-int f5_launch_pack_x(const float* y, bf16_t* out_hi, bf16_t* out_lo, int rows, int mel_dim, hipStream_t s) {
+int f5_launch_pack_x(const float* y, op16_t* out_hi, op16_t* out_lo, int rows, int mel_dim, hipStream_t s) {
     hipLaunchKernelGGL(pack_x_kernel, dim3(f5_cdiv((long)rows * 128, 256)), dim3(256), 0, s, y, out_hi, out_lo, rows, mel_dim);
     F5_LAUNCH_CHECK();
     return 0;
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256) void ode_stage_kernel(F5OdeArgs p) {
         const size_t idx = row * p.mel_dim + c;
         const float pr = p.pred[idx];
         float k = pr;
-        if (p.null_pred) k = pr + (pr - p.null_pred[idx]) * p.cfg;     // cfm.py:364
+        if (p.null_pred) k = pr + (pr - p.null_pred[idx]) * (p.cfg_ptr ? p.cfg_ptr[0] : p.cfg);     // cfm.py:364
         if (p.kstore) p.kstore[idx] = k;
         const float a = (p.coef * p.dt_ptr[0]) / p.divisor;
         float upd = k;
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) void ode_stage_kernel(F5OdeArgs p) {
         p.out[idx] = o;
     }
     if (p.xin_hi) {
-        bf16_t h, l;
+        op16_t h, l;
         f5_split(o, h, l);
         p.xin_hi[i] = h;
         if (p.xin_lo) p.xin_lo[i] = l;
@@ -600,7 +601,7 @@ int f5_launch_rowkeep(const int* dur, uint8_t* keep, int nbatch, int seq_len, hi
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ out_f32,
-                                                        bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int rows,
+                                                        op16_t* __restrict__ out_hi, op16_t* __restrict__ out_lo, int rows,
                                                         float eps) {
     constexpr int DIM = NV * 256;
     const int lane = threadIdx.x & 63;
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             *reinterpret_cast<u32x2*>(out_lo + (size_t)row * DIM + c) = u32x2{f5_pack2_lo(y[0], y[1]), f5_pack2_lo(y[2], y[3])};
     }
 }
-int f5_launch_layernorm(const float* x, const float* w, const float* b, float* out_f32, bf16_t* out_hi, bf16_t* out_lo,
+int f5_launch_layernorm(const float* x, const float* w, const float* b, float* out_f32, op16_t* out_hi, op16_t* out_lo,
                         int rows, int dim, float eps, hipStream_t s) {
     F5_REQUIRE(dim % 256 == 0 && dim >= 256 && dim <= 1024, "layernorm: dim must be 256/512/768/1024 (got %d)", dim);
     const dim3 grid(f5_cdiv(rows, 4)), block(256);
@@ -653,8 +654,8 @@ int f5_launch_layernorm(const float* x, const float* w, const float* b, float* o
     return 0;
 }
 
-__global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ x, bf16_t* __restrict__ out_hi,
-                                                      bf16_t* __restrict__ out_lo, int seq_len, int channels, size_t total) {
+__global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ x, op16_t* __restrict__ out_hi,
+                                                      op16_t* __restrict__ out_lo, int seq_len, int channels, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over rows * 7 * 128
     if (i >= total) return;
     const size_t row = i / (7 * 128);
@@ -664,12 +665,12 @@ __global__ __launch_bounds__(256) void im2col7_kernel(const float* __restrict__ 
     const int n = (int)(row - (size_t)b * seq_len) + t - 3;
     float v = 0.0f;
     if (c < channels && n >= 0 && n < seq_len) v = x[((size_t)b * seq_len + n) * channels + c];
-    bf16_t h, l;
+    op16_t h, l;
     f5_split(v, h, l);
     out_hi[i] = h;
     if (out_lo) out_lo[i] = l;
 }
-int f5_launch_im2col7(const float* x, bf16_t* out_hi, bf16_t* out_lo, int nbatch, int seq_len, int channels, hipStream_t s) {
+int f5_launch_im2col7(const float* x, op16_t* out_hi, op16_t* out_lo, int nbatch, int seq_len, int channels, hipStream_t s) {
     F5_REQUIRE(channels <= 128, "im2col7: channels must be <= 128");
     const size_t total = (size_t)nbatch * seq_len * 7 * 128;
     hipLaunchKernelGGL(im2col7_kernel, dim3(f5_cdiv((long)total, 256)), dim3(256), 0, s, x, out_hi, out_lo, seq_len, channels,
@@ -683,7 +684,7 @@ int f5_launch_im2col7(const float* x, bf16_t* out_hi, bf16_t* out_lo, int nbatch
 // =================================================================================================
 // fp32 [rows][cols] (optionally row-masked) -> bf16 (hi, lo) at column offset col0 of a [rows][ld] matrix
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, const uint8_t* __restrict__ rowkeep,
-                                                        bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int cols, int ld,
+                                                        op16_t* __restrict__ out_hi, op16_t* __restrict__ out_lo, int cols, int ld,
                                                         int col0, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -691,12 +692,12 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
     const int c = (int)(i - row * cols);
     float v = src[i];
     if (rowkeep != nullptr && rowkeep[row] == 0) v = 0.0f;
-    bf16_t h, l;
+    op16_t h, l;
     f5_split(v, h, l);
     out_hi[row * ld + col0 + c] = h;
     if (out_lo) out_lo[row * ld + col0 + c] = l;
 }
-int f5_launch_pack_bf16(const float* src, const uint8_t* rowkeep, bf16_t* out_hi, bf16_t* out_lo, int rows, int cols, int ld,
+int f5_launch_pack_bf16(const float* src, const uint8_t* rowkeep, op16_t* out_hi, op16_t* out_lo, int rows, int cols, int ld,
                         int col0, hipStream_t s) {
     F5_REQUIRE(col0 >= 0 && col0 + cols <= ld, "pack_bf16: column range out of bounds");
     const size_t total = (size_t)rows * cols;
@@ -746,3 +747,4 @@ int f5_launch_duration_head(const float* x, const float* g, const float* w, cons
     F5_LAUNCH_CHECK();
     return 0;
 }
+}  // namespace F5_NS

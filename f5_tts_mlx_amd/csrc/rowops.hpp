@@ -1,18 +1,33 @@
 // HBM-bound row / elementwise kernels of the sampling path (declarations).
-#pragma once
-#include "common.hpp"
+#include "op16.hpp"
+
+// one body per operand build (this header is included once per F5_F16 value)
+#if F5_F16
+#ifndef F5_ROWOPS_HPP_F16
+#define F5_ROWOPS_HPP_F16
+#define F5_ROWOPS_HPP_BODY
+#endif
+#else
+#ifndef F5_ROWOPS_HPP_BF16
+#define F5_ROWOPS_HPP_BF16
+#define F5_ROWOPS_HPP_BODY
+#endif
+#endif
+#ifdef F5_ROWOPS_HPP_BODY
+#undef F5_ROWOPS_HPP_BODY
+namespace F5_NS {
 
 // y = LN(x) * (1 + scale) + shift, LN without affine, eps (dit.py:270,289,321). One wave per row.
-int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, bf16_t* out_hi, bf16_t* out_lo,
+int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, op16_t* out_hi, op16_t* out_lo,
                           int rows, int dim, float eps, hipStream_t s);
 
 // ConvNeXtV2 front half (convnext_v2.py:46-48): depthwise Conv1d(k=7,pad=3)+bias -> LayerNorm(affine).
 int f5_launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
-                        bf16_t* out_hi, bf16_t* out_lo, int nbatch, int seq_len, int dim, float eps, hipStream_t s);
+                        op16_t* out_hi, op16_t* out_lo, int nbatch, int seq_len, int dim, float eps, hipStream_t s);
 
 // GRN (convnext_v2.py:15-18) over the SEQUENCE axis: three deterministic passes.
-int f5_launch_grn(const float* g, const float* gamma, const float* beta, float* partial, float* nx, bf16_t* out_hi,
-                  bf16_t* out_lo, int nbatch, int seq_len, int dim, hipStream_t s);
+int f5_launch_grn(const float* g, const float* gamma, const float* beta, float* partial, float* nx, op16_t* out_hi,
+                  op16_t* out_lo, int nbatch, int seq_len, int dim, hipStream_t s);
 size_t f5_grn_partial_floats(int nbatch, int seq_len, int dim);
 
 // TextEmbedding index path + gather (dit.py:196-222): ids (+1, pad 0, mask, drop) -> emb + pos.
@@ -20,7 +35,7 @@ int f5_launch_text_embed(const int* text, int nt, const float* table, const floa
                          int* ids_out, uint8_t* keep_out, int B, int seq_len, int dim, int mask_padding, hipStream_t s);
 
 // pack A operand of the hoisted input projection: [cond(128, zero padded) | text_embed(dt)] for both branches
-int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, bf16_t* out_hi, bf16_t* out_lo,
+int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, op16_t* out_hi, op16_t* out_lo,
                              int B, int seq_len, int mel_dim, int dt, hipStream_t s);
 
 // sinusoidal time embedding (dit.py:61-67)
@@ -35,7 +50,7 @@ int f5_launch_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, 
 int f5_launch_text_pos_table(float* table, int max_pos, int dim, hipStream_t s);
 
 // y (fp32 [rows][mel]) -> bf16 [rows][128] zero padded (A operand of the per-step x projection)
-int f5_launch_pack_x(const float* y, bf16_t* out_hi, bf16_t* out_lo, int rows, int mel_dim, hipStream_t s);
+int f5_launch_pack_x(const float* y, op16_t* out_hi, op16_t* out_lo, int rows, int mel_dim, hipStream_t s);
 
 // CFG combine + ODE stage (cfm.py:38-122, :364).  k = pred + (pred - null) * cfg  (pred only when !has_null)
 //   mode 0: out = base + a * k                         (optionally k -> kstore)
@@ -44,7 +59,8 @@ int f5_launch_pack_x(const float* y, bf16_t* out_hi, bf16_t* out_lo, int rows, i
 struct F5OdeArgs {
     const float* pred;
     const float* null_pred;  // may be null
-    float cfg;
+    float cfg;               // guidance scale when cfg_ptr is null
+    const float* cfg_ptr;    // device scalar (the engine stages it per call: a by-value scalar would be frozen into a hipGraph)
     const float* base;
     const float* dt_ptr;     // device scalar dt of this step
     float coef;
@@ -55,8 +71,8 @@ struct F5OdeArgs {
     const float* k2;
     const float* k3;
     float* out;
-    bf16_t* xin_hi;
-    bf16_t* xin_lo;
+    op16_t* xin_hi;
+    op16_t* xin_lo;
     int rows, mel_dim;
 };
 int f5_launch_ode_stage(const F5OdeArgs& a, hipStream_t s);
@@ -69,17 +85,19 @@ int f5_launch_splice(const float* cond, const float* y, const int* lens, float* 
 int f5_launch_rowkeep(const int* dur, uint8_t* keep, int nbatch, int seq_len, hipStream_t s);
 
 // LayerNorm with affine weight/bias over the last axis (dim = 256..1024), fp32 out and/or bf16 (hi, lo) out
-int f5_launch_layernorm(const float* x, const float* w, const float* b, float* out_f32, bf16_t* out_hi, bf16_t* out_lo,
+int f5_launch_layernorm(const float* x, const float* w, const float* b, float* out_f32, op16_t* out_hi, op16_t* out_lo,
                         int rows, int dim, float eps, hipStream_t s);
 // im2col for Conv1d(k=7, pad=3) on channels-last input (c <= 128): out[b*n][7*128] bf16, tap-major, zero padded
-int f5_launch_im2col7(const float* x, bf16_t* out_hi, bf16_t* out_lo, int nbatch, int seq_len, int channels, hipStream_t s);
+int f5_launch_im2col7(const float* x, op16_t* out_hi, op16_t* out_lo, int nbatch, int seq_len, int channels, hipStream_t s);
 
 // duration predictor helpers
-int f5_launch_pack_bf16(const float* src, const uint8_t* rowkeep, bf16_t* out_hi, bf16_t* out_lo, int rows, int cols, int ld,
+int f5_launch_pack_bf16(const float* src, const uint8_t* rowkeep, op16_t* out_hi, op16_t* out_lo, int rows, int cols, int ld,
                         int col0, hipStream_t s);
 int f5_launch_duration_head(const float* x, const float* g, const float* w, const uint8_t* mask, float* out, int B, int seq_len,
                             int dim, float eps, hipStream_t s);
 // MX-fp8 variants (engine precision mxfp8): LN + modulation straight to e4m3 + E8M0 scales; bf16 rows -> MX-fp8 (weights)
 int f5_launch_ln_modulate_f8(const float* x, const float* scale, const float* shift, uint8_t* q, uint8_t* qs, int rows, int dim,
                              float eps, hipStream_t s);
-int f5_launch_quantize_mx_bf16(const bf16_t* x, int ldx, uint8_t* q, int ldq, uint8_t* sc, int rows, int cols, hipStream_t stream);
+int f5_launch_quantize_mx_bf16(const op16_t* x, int ldx, uint8_t* q, int ldq, uint8_t* sc, int rows, int cols, hipStream_t stream);
+}  // namespace F5_NS
+#endif

@@ -67,9 +67,10 @@ def synthetic_duration_weights(seed: int = 11, **kw) -> Dict[str, np.ndarray]:
     return out
 
 
-def _split(x: torch.Tensor, two: bool):
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.to(torch.float32)).to(torch.bfloat16) if two else None
+def _split(x: torch.Tensor, two: bool, dtype: torch.dtype = torch.bfloat16):
+    """fp32 -> 16-bit MFMA operand (bf16, or fp16 saturated at +-65504 like the device producers) + optional residual."""
+    hi = (x.clamp(-65504.0, 65504.0) if dtype == torch.float16 else x).to(dtype)
+    lo = (x - hi.to(torch.float32)).to(dtype) if two else None
     return hi.contiguous(), (lo.contiguous() if two else None)
 
 
@@ -85,12 +86,15 @@ class DurationTransformer:
         self.dim, self.depth, self.heads, self.ff_dim = dim, depth, heads, int(dim * ff_mult)
         self.mel_dim, self.text_num_embeds, self.text_dim, self.conv_layers = mel_dim, text_num_embeds, text_dim, conv_layers
         self.device = torch.device(device)
+        self.precision = precision
+        self.op_dtype = E.operand_dtype(precision)        # bf16, or fp16 for precision "f16"
         self.two = precision == "bf16x3"
         self.nseg = 3 if self.two else 1
         self.w = None
 
     def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
         dev, two = self.device, self.two
+        _split_op = lambda x, two_: _split(x, two_, self.op_dtype)
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
         pad128 = lambda m: np.concatenate([m, np.zeros(((-m.shape[0]) % 128, m.shape[1]), np.float32)], axis=0)
         g = {k.replace("duration_predictor.", ""): np.asarray(v, dtype=np.float32) for k, v in weights.items()}
@@ -107,14 +111,14 @@ class DurationTransformer:
             q = f"transformer.text_embed.text_blocks.layers.{i}."
             W["tblocks"].append(dict(
                 dw_w=f(g[q + "dwconv.weight"].reshape(self.text_dim, 7)), dw_b=f(g[q + "dwconv.bias"]), ln_w=f(g[q + "norm.weight"]),
-                ln_b=f(g[q + "norm.bias"]), pw1=_split(f(pad128(g[q + "pwconv1.weight"])), two), b1=f(g[q + "pwconv1.bias"]),
+                ln_b=f(g[q + "norm.bias"]), pw1=_split_op(f(pad128(g[q + "pwconv1.weight"])), two), b1=f(g[q + "pwconv1.bias"]),
                 gamma=f(g[q + "grn.gamma"].reshape(-1)), beta=f(g[q + "grn.beta"].reshape(-1)),
-                pw2=_split(f(pad128(g[q + "pwconv2.weight"])), two), b2=f(g[q + "pwconv2.bias"])))
+                pw2=_split_op(f(pad128(g[q + "pwconv2.weight"])), two), b2=f(g[q + "pwconv2.bias"])))
         wp = g["transformer.input_embed.proj.weight"]                      # (dim, mel + text): input order x | text
         wcat = np.zeros((self.dim, 128 + self.text_dim), np.float32)
         wcat[:, : self.mel_dim] = wp[:, : self.mel_dim]
         wcat[:, 128:] = wp[:, self.mel_dim:]
-        W["proj"] = _split(f(pad128(wcat)), two)
+        W["proj"] = _split_op(f(pad128(wcat)), two)
         W["bproj"] = f(g["transformer.input_embed.proj.bias"])
         cg = self.dim // 16
         W["conv"] = []
@@ -127,7 +131,7 @@ class DurationTransformer:
                 for o in range(self.dim):
                     off = ((o // 32) % 2) * 32
                     wbd[o, :, off:off + 32] = w[o]
-            W["conv"].append((_split(f(wbd.reshape(self.dim, 31 * 64)), two),
+            W["conv"].append((_split_op(f(wbd.reshape(self.dim, 31 * 64)), two),
                               f(g[f"transformer.input_embed.conv_pos_embed.conv1d.layers.{j}.bias"])))
         W["blocks"] = []
         for i in range(self.depth):
@@ -135,9 +139,9 @@ class DurationTransformer:
             wqkv = np.concatenate([g[q + f"attn.{n}.weight"] for n in ("to_q", "to_k", "to_v")], axis=0)
             bqkv = np.concatenate([g[q + f"attn.{n}.bias"] for n in ("to_q", "to_k", "to_v")], axis=0)
             W["blocks"].append(dict(
-                qkv=_split(f(pad128(wqkv)), two), bqkv=f(bqkv), o=_split(f(pad128(g[q + "attn.to_out.layers.0.weight"])), two),
-                bo=f(g[q + "attn.to_out.layers.0.bias"]), ff1=_split(f(pad128(g[q + "ff.ff.layers.0.layers.0.weight"])), two),
-                bff1=f(g[q + "ff.ff.layers.0.layers.0.bias"]), ff2=_split(f(pad128(g[q + "ff.ff.layers.2.weight"])), two),
+                qkv=_split_op(f(pad128(wqkv)), two), bqkv=f(bqkv), o=_split_op(f(pad128(g[q + "attn.to_out.layers.0.weight"])), two),
+                bo=f(g[q + "attn.to_out.layers.0.bias"]), ff1=_split_op(f(pad128(g[q + "ff.ff.layers.0.layers.0.weight"])), two),
+                bff1=f(g[q + "ff.ff.layers.0.layers.0.bias"]), ff2=_split_op(f(pad128(g[q + "ff.ff.layers.2.weight"])), two),
                 bff2=f(g[q + "ff.ff.layers.2.bias"])))
         W["norm_out"] = f(g["transformer.norm_out.weight"])
         W["to_pred"] = f(g["to_pred.layers.0.weight"].reshape(-1))
@@ -188,12 +192,16 @@ class DurationPredictor:
         inp = inp.contiguous()
         text_d = text.contiguous().to(dev)
 
+        with E.operand_type(T.precision):                  # the f5_op_* entry points take this model's operand type
+            return self._run_ops(lib, dev, ns, W, T, inp, text, text_d, mask_d, batch, seq_len)
+
+    def _run_ops(self, lib, dev, ns, W, T, inp, text, text_d, mask_d, batch, seq_len):
         B, N, D, Dt, H = batch, seq_len, T.dim, T.text_dim, T.heads
         rows, npad = B * N, (N + 63) // 64 * 64
         P, st = E.ptr, E.stream_ptr(dev)
         two = T.two
-        bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)
-        bfz = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=dev)
+        bf = lambda *s: torch.empty(s, dtype=T.op_dtype, device=dev)
+        bfz = lambda *s: torch.zeros(s, dtype=T.op_dtype, device=dev)
         lo = lambda t: t if two else None
         ck = E.check
 

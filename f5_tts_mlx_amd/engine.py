@@ -19,7 +19,32 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libf5tts_hip.so"
 _lib = None
 
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2}
-PRECISIONS = {"bf16": 0, "bf16x3": 1, "mxfp8": 2}     # mxfp8: MX-fp8 block GEMMs (gfx950 scaled MFMA), everything else bf16
+# MFMA operand encodings (include/f5tts_hip.h).  "f16": IEEE half operands, the one-pass mode that meets the 1e-3 mel-L1 gate;
+# "bf16": bfloat16 operands (outside the gate by 2-4x); "bf16x3": hi/lo split, 3 passes, fp32-class; "mxfp8": MX-fp8 block GEMMs
+# (gfx950 scaled MFMA), everything else bf16
+PRECISIONS = {"bf16": 0, "bf16x3": 1, "mxfp8": 2, "f16": 3}
+GRAPH_MODES = {False: 0, True: 1, "off": 0, "on": 1, "auto": 2}
+
+
+def operand_dtype(precision: str) -> torch.dtype:
+    """torch dtype of the 16-bit MFMA operand buffers of a precision mode."""
+    return torch.float16 if precision == "f16" else torch.bfloat16
+
+
+class operand_type:
+    """Context manager: the per-op entry points (f5_op_*) take bf16 operands by default; inside this block they take the
+    operand type of `precision` (process-wide switch, not re-entrant -- same contract as an engine handle)."""
+
+    def __init__(self, precision: str):
+        self.fp16 = 1 if precision == "f16" else 0
+
+    def __enter__(self):
+        check(load_library().f5_op_set_operand_type(self.fp16), "f5_op_set_operand_type")
+        return self
+
+    def __exit__(self, *exc):
+        check(load_library().f5_op_set_operand_type(0), "f5_op_set_operand_type")
+        return False
 
 
 class F5Config(C.Structure):
@@ -58,6 +83,12 @@ def load_library() -> C.CDLL:
     lib.f5_version.restype = C.c_int
     lib.f5_op_grn_scratch_floats.restype = C.c_size_t
     lib.f5_engine_destroy.restype = None
+    lib.f5_debug_f2h_bits.restype = C.c_uint16
+    lib.f5_debug_f2h_bits.argtypes = [C.c_float]
+    lib.f5_debug_f2bf_bits.restype = C.c_uint16
+    lib.f5_debug_f2bf_bits.argtypes = [C.c_float]
+    lib.f5_debug_h_bits2f.restype = C.c_float
+    lib.f5_debug_h_bits2f.argtypes = [C.c_uint16]
     _lib = lib
     return lib
 
@@ -150,6 +181,13 @@ class Engine:
         check(self.lib.f5_finalize_weights(self._h, stream_ptr(self.device)), "f5_finalize_weights")
         self.weights_ready = True
 
+    def set_graph_cache(self, max_graphs: int) -> None:
+        """Bound the number of cached hipGraphExecs (default 8); the least recently used one is destroyed."""
+        check(self.lib.f5_engine_set_graph_cache(self._h, int(max_graphs)), "f5_engine_set_graph_cache")
+
+    def graph_count(self) -> int:
+        return int(self.lib.f5_engine_graph_count(self._h))
+
     def mark_loaded_from_broadcast(self) -> None:
         """Arena content arrived by a collective (dist.broadcast_weights) instead of load_weights."""
         check(self.lib.f5_mark_weights_loaded(self._h), "f5_mark_weights_loaded")
@@ -178,7 +216,9 @@ class Engine:
         a.y0 = 0 if y0 is None else y0.data_ptr()
         a.t = keep["t"].ctypes.data
         a.steps, a.method, a.cfg_strength = steps, METHODS[method], float(cfg_strength)
-        a.use_mask, a.use_graph = int(use_mask), int(use_graph)
+        if use_graph not in GRAPH_MODES:
+            raise ValueError(f"use_graph must be one of {list(GRAPH_MODES)}")
+        a.use_mask, a.use_graph = int(use_mask), GRAPH_MODES[use_graph]
         a.out = 0 if out is None else out.data_ptr()
         a.trajectory = 0 if traj is None else traj.data_ptr()
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -195,10 +235,11 @@ class Engine:
 
     def sample(self, text: torch.Tensor, cond: torch.Tensor, lens: Sequence[int], durations: Sequence[int], y0: torch.Tensor,
                t: np.ndarray, method: str = "euler", cfg_strength: float = 2.0, use_mask: Optional[bool] = None,
-               use_graph: bool = True, return_trajectory: bool = True, out: Optional[torch.Tensor] = None,
+               use_graph=True, return_trajectory: bool = True, out: Optional[torch.Tensor] = None,
                trajectory: Optional[torch.Tensor] = None):
         """ODE solve on the GPU. cond (B,N,mel) fp32 zero-padded to N=max(durations); text (B,nt) int32
-        (-1 padded); y0 (B,N,mel).  Returns (out (B,N,mel), trajectory (steps,B,N,mel) or None)."""
+        (-1 padded); y0 (B,N,mel).  use_graph: True / False / "auto" (eager on the first sighting of a shape
+        signature, captured hipGraph from the second on).  Returns (out (B,N,mel), trajectory (steps,B,N,mel) or None)."""
         if method not in METHODS:
             raise ValueError(f"Unknown method: {method}")
         self._check_inputs(text, cond, lens, durations)

@@ -89,6 +89,9 @@ def generate(
 ):
     if f5tts is None:
         f5tts = F5TTS.from_pretrained(model_name, quantization_bits=quantization_bits)
+    if getattr(f5tts, "_vocoder", None) is None:
+        # sample() would hand back mel frames; trimming them by audio samples and writing a WAV would produce garbage
+        raise RuntimeError("generate() needs a model with a vocoder (F5TTS(..., vocoder=...) / from_pretrained with Vocos)")
 
     if ref_audio_path is None:
         data = pkgutil.get_data("f5_tts_mlx_amd", "assets/test_en_1_ref_short.wav")   # generate.py:133-143
@@ -163,7 +166,11 @@ _CLI = (
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description="F5-TTS text to speech on MI355X (same flags as f5_tts_mlx.generate)")
+    ap = argparse.ArgumentParser(
+        description="F5-TTS text to speech on MI355X (same flags as f5_tts_mlx.generate)",
+        epilog="Text front-end: single-byte (ASCII / Latin) text is tokenised exactly like the reference; Chinese text needs "
+               "jieba and pypinyin (utils.py:139-173), which this package uses when they are importable and otherwise refuses "
+               "with an error rather than guessing.")
     for flag, kind, dflt, doc in _CLI:
         ap.add_argument(flag, type=kind, default=dflt, help=doc)
     ap.add_argument("--method", default="rk4", choices=("euler", "midpoint", "rk4"), help="ODE solver")
@@ -174,9 +181,9 @@ def main(argv=None):
     if text is None:
         if sys.stdin.isatty():
             print("Please enter the text to generate:")
-            text = input("> ")
+            text = input("> ").strip()
         else:
-            text = sys.stdin.read()
+            text = sys.stdin.read().strip()                            # generate.py:330-335 strips both
 
     generate(text, duration=ns.duration, estimate_duration=ns.estimate_duration, model_name=ns.model, ref_audio_path=ns.ref_audio,
              ref_audio_text=ns.ref_text, steps=ns.steps, method=ns.method, cfg_strength=ns.cfg, sway_sampling_coef=ns.sway_coef,

@@ -146,10 +146,33 @@ def convert_char_to_pinyin(text_list: List[str], polyphone: bool = True) -> List
 
 
 def _ascii_segments(text: str) -> List[str]:
-    """Segmentation jieba produces for single-byte text: its HMM fallback (`finalseg.re_skip`) keeps
-    alphanumeric runs `[a-zA-Z0-9]+(?:\\.\\d+)?%?` together and yields every other character on its own."""
+    """Segmentation jieba.cut (default mode, HMM on) produces for single-byte text, restated from jieba's published algorithm
+    (jieba/__init__.py `Tokenizer.cut`, jieba/finalseg `cut`; jieba itself is not installable here):
+    1. the sentence is split into blocks by `re_han_default = [\u4E00-\u9FD5a-zA-Z0-9+#&._%-]+`;
+    2. a matching block holds no dictionary word when it is single-byte, so it reaches the HMM fallback `finalseg.cut`, whose
+       `re_skip = [a-zA-Z0-9]+(?:\.\d+)?%?` keeps alphanumeric runs whole and yields the stretches BETWEEN them ("...", "--",
+       "+#") as ONE multi-character piece each (the reference then puts a space token in front of such a piece);
+    3. a non-matching block (whitespace, other punctuation) is split on `(\r\n|\s)`: whitespace items as they are, everything
+       else character by character."""
     import re
-    return re.findall(r"[a-zA-Z0-9]+(?:\.\d+)?%?|.", text, flags=re.S)
+    out: List[str] = []
+    for blk in re.split(r"([a-zA-Z0-9+#&._%\-]+)", text):
+        if not blk:
+            continue
+        if re.fullmatch(r"[a-zA-Z0-9+#&._%\-]+", blk):
+            if len(blk) == 1:
+                out.append(blk)
+            else:
+                out += [x for x in re.split(r"([a-zA-Z0-9]+(?:\.\d+)?%?)", blk) if x]
+        else:
+            for x in re.split(r"(\r\n|\s)", blk):
+                if not x:
+                    continue
+                if re.fullmatch(r"\r\n|\s", x):
+                    out.append(x)
+                else:
+                    out += list(x)
+    return out
 
 
 def fetch_from_hub(hf_repo: str, quantization_bits: Optional[int] = None):

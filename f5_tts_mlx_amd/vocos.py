@@ -56,9 +56,10 @@ def synthetic_vocos_weights(seed: int = 7) -> Dict[str, np.ndarray]:
     return out
 
 
-def _split(x: torch.Tensor, two: bool):
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.to(torch.float32)).to(torch.bfloat16) if two else None
+def _split(x: torch.Tensor, two: bool, dtype: torch.dtype = torch.bfloat16):
+    """fp32 -> 16-bit MFMA operand (bf16, or fp16 saturated at +-65504 like the device producers) + optional residual."""
+    hi = (x.clamp(-65504.0, 65504.0) if dtype == torch.float16 else x).to(dtype)
+    lo = (x - hi.to(torch.float32)).to(dtype) if two else None
     return hi.contiguous(), (lo.contiguous() if two else None)
 
 

@@ -42,7 +42,12 @@ typedef struct f5_config {
     int32_t text_max_pos;    /* 4096 */
 } f5_config;
 
-enum { F5_PREC_BF16 = 0, F5_PREC_BF16X3 = 1, F5_PREC_MXFP8 = 2 };   /* MFMA operand encoding (2: MX-fp8 block GEMMs, rest bf16) */
+/* MFMA operand encoding.  The reference computes in fp32 throughout (dit.py, cfm.py); measured mel-L1 drift of a full 32-point
+ * sample against the fp32 oracle: BF16 2-4e-3 (outside the 1e-3 gate), F16 (IEEE half operands, same MFMA rate, 11 significand
+ * bits, producers saturate at +-65504) inside the gate, BF16X3 (hi/lo split, 3 MFMA passes) ~5e-6; MXFP8: the four block GEMMs on
+ * MX-fp8 (e4m3 + E8M0 per 32), rest bf16 -- a reduced-precision mode. */
+enum { F5_PREC_BF16 = 0, F5_PREC_BF16X3 = 1, F5_PREC_MXFP8 = 2, F5_PREC_F16 = 3 };
+enum { F5_GRAPH_OFF = 0, F5_GRAPH_ON = 1, F5_GRAPH_AUTO = 2 };  /* f5_sample_args.use_graph */
 enum { F5_EULER = 0, F5_MIDPOINT = 1, F5_RK4 = 2 };       /* cfm.py:38-122 */
 
 const char* f5_last_error(void);
@@ -50,7 +55,10 @@ int f5_version(void);
 
 /* ---- engine lifetime ------------------------------------------------------------------------ */
 int f5_engine_create(const f5_config* cfg, int precision, f5_engine** out);
-void f5_engine_destroy(f5_engine* e);
+void f5_engine_destroy(f5_engine* e);   /* also destroys every cached hipGraphExec */
+/* at most `max_graphs` (default 8) captured sample graphs are kept per engine; the least recently used one is destroyed */
+int f5_engine_set_graph_cache(f5_engine* e, int max_graphs);
+int f5_engine_graph_count(f5_engine* e);
 
 /* ---- weights: replaces F5TTS.load_weights / from_pretrained upload (cfm.py:475-518) ------------
  * The caller allocates `f5_weights_bytes` of device memory (one contiguous arena, so that a single
@@ -82,7 +90,9 @@ typedef struct f5_sample_args {
     int32_t method;            /* F5_EULER / F5_MIDPOINT / F5_RK4                                */
     float cfg_strength;        /* < 1e-5 disables the null branch (cfm.py:352)                   */
     int32_t use_mask;          /* key-padding mask + output row mask; reference: batch > 1       */
-    int32_t use_graph;         /* capture/replay the whole call as one hipGraph                  */
+    int32_t use_graph;         /* F5_GRAPH_ON: capture/replay the whole call as one hipGraph (cached per shape signature,
+                                * LRU bounded); F5_GRAPH_AUTO: eager on the first sighting of a signature, graph from the
+                                * second on (mx.compile re-traces per call shape in the reference, cfm.py:392)       */
     float* out;                /* dev  [B][N][mel] where(cond_mask, cond, y_final)               */
     float* trajectory;         /* dev  [steps][B][N][mel] or NULL                                */
     void* workspace;           /* dev, f5_workspace_bytes                                        */
@@ -98,7 +108,10 @@ int f5_sample(f5_engine* e, const f5_sample_args* args, void* stream);
 int f5_dit_forward(f5_engine* e, const f5_sample_args* args, const float* x, float t, float* pred, float* null_pred,
                    void* stream);
 
-/* ---- per-op entry points (exported for the parity tests; all pointers are dev) ------------------ */
+/* ---- per-op entry points (exported for the parity tests; all pointers are dev) ------------------
+ * 16-bit operand buffers (a_hi, w_hi, qk_hi, out_hi ...) hold bf16 by default; f5_op_set_operand_type(1) switches every
+ * f5_op_* call of the process to IEEE fp16 operands (the kernels are built for both), 0 switches back. */
+int f5_op_set_operand_type(int fp16);
 /* C = A * W^T (+epilogue), bf16 MFMA; epi codes in csrc/gemm.hpp (0 = fp32 out + bias, 1 = bf16 out) */
 int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, float* out_f32,
                void* out_bf_hi, void* out_bf_lo, int M, int N, int K, int lda, int ldw, int ldo, int nseg, int epi,
@@ -154,6 +167,11 @@ int f5_op_cfg_axpy(const float* pred, const float* null_pred, float cfg, const f
 int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                           const float* gate, const uint8_t* rowkeep, float* x, int M, int N, int K, int lda, int ldw, int ldx,
                           int nseg, void* stream);
+/* out_f32 = A[row % a_row_mod] W^T + addrows[row]; (out_hi, out_lo) = the same as 16-bit operands: the split input projection of
+ * InputEmbedding (dit.py:250), x part per step + hoisted cond / text part, x rows shared by the two CFG branches */
+int f5_op_gemm_addrows(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* addrows,
+                       int a_row_mod, float* out_f32, void* out_hi, void* out_lo, int M, int N, int K, int lda, int ldw, int ldo,
+                       int nseg, void* stream);
 /* nn.LayerNorm with affine parameters, eps 1e-6; fp32 and/or bf16 (hi, lo) outputs (any may be NULL) */
 int f5_op_layernorm(const float* x, const float* w, const float* b, float* out_f32, void* out_hi, void* out_lo, int rows,
                     int dim, void* stream);
@@ -164,6 +182,11 @@ int f5_op_im2col7(const float* x, void* out_hi, void* out_lo, int nbatch, int se
 int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scratch, float* wave, int nframes, int n_fft,
                 int hop, void* stream);
 
+/* host-side float <-> 16-bit operand conversions used by f5_load_tensor (exported for the CPU tests): fp16 / bf16 round to
+ * nearest even; fp16 saturates at +-65504 instead of overflowing to inf */
+uint16_t f5_debug_f2h_bits(float f);
+float f5_debug_h_bits2f(uint16_t h);
+uint16_t f5_debug_f2bf_bits(float f);
 /* debug / benchmarking hook: force the GEMM block tile (0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 global_load_lds kernel,
  * 5 / 6 = ring 64x128 / 64x64, 7 = 128x256 two-per-CU, 8 / 9 = 8-wave ring 128x192 / 128x128, 10 / 11 = in-workgroup split-K
  * 64x128 / 128x128, 12 / 13 = 8-wave ring 128x256 with 64x64 / 32x128 wave tiles) */

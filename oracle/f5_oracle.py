@@ -21,6 +21,7 @@ Precision switches
   dtype            torch.float32 (reference arithmetic) or torch.float64 (ground truth)
   emulate_bf16     round GEMM/attention *operands* to bf16 at exactly the points where the HIP
                    engine does (fp32 accumulate).  Used to separate kernel bugs from bf16 drift.
+  emulate_f16      the same with IEEE fp16 operands (the engine's "f16" precision).
 
 All citations are file:line in /root/reference/f5_tts_mlx/.
 """
@@ -156,6 +157,11 @@ def _bf16(x: Tensor) -> Tensor:
     return x.to(torch.bfloat16).to(x.dtype)
 
 
+def _f16(x: Tensor) -> Tensor:
+    """IEEE half rounding with the engine's saturation at +-65504 (csrc/op16.hpp f5_sat)."""
+    return x.clamp(-65504.0, 65504.0).to(torch.float16).to(x.dtype)
+
+
 # ------------------------------------------------------------------------------------------------
 # positional tables (rope.py)
 # ------------------------------------------------------------------------------------------------
@@ -212,14 +218,15 @@ class DiTOracle:
     """
 
     def __init__(self, cfg, weights: Dict[str, np.ndarray], dtype=torch.float32, emulate_bf16: bool = False,
-                 emulate_mxfp8: bool = False):
+                 emulate_mxfp8: bool = False, emulate_f16: bool = False):
         """emulate_bf16: GEMM / attention operands rounded to bf16 like the engine's `bf16` mode.  emulate_mxfp8: the engine's
         `mxfp8` mode (BASELINE configs[4], no reference counterpart): as bf16, except that both operands of the four
         per-block linears (to_q/k/v, to_out, ff.0, ff.2) are MX-fp8 (oracle/mx_oracle.py), weights from their bf16 copies."""
         self.cfg = cfg
         self.dtype = dtype
-        self.emu = emulate_bf16 or emulate_mxfp8
+        self.emu = emulate_bf16 or emulate_mxfp8 or emulate_f16
         self.mx = emulate_mxfp8
+        self._r = _f16 if emulate_f16 else _bf16          # operand rounding of the emulated engine mode
         self.w = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in weights.items()}
         self._wb: Dict[str, Tensor] = {}
         self.freqs_cis = precompute_freqs_cis(cfg.text_dim, cfg.text_max_pos).to(dtype)   # dit.py:191
@@ -231,12 +238,12 @@ class DiTOracle:
         if not self.emu:
             return self.w[name]
         if name not in self._wb:
-            self._wb[name] = _bf16(self.w[name])
+            self._wb[name] = self._r(self.w[name])
         return self._wb[name]
 
     def _A(self, x: Tensor) -> Tensor:
         """GEMM activation operand."""
-        return _bf16(x) if self.emu else x
+        return self._r(x) if self.emu else x
 
     def linear(self, x: Tensor, name: str, lowp: bool = True) -> Tensor:
         """nn.Linear: x @ W.T + b, W (out, in)."""
@@ -348,7 +355,7 @@ class DiTOracle:
             # engine: P = exp(s - max) rounded to bf16 for the PV product, row-sum kept in fp32
             m = s.amax(dim=-1, keepdim=True)
             pexp = torch.exp(s - m)
-            o = (_bf16(pexp) @ v) / pexp.sum(dim=-1, keepdim=True)
+            o = (self._r(pexp) @ v) / pexp.sum(dim=-1, keepdim=True)
         else:
             o = torch.softmax(s, dim=-1) @ v
         o = o.transpose(1, 2).reshape(b, n, -1)

@@ -18,15 +18,44 @@ from f5_tts_mlx_amd.weights import TINY, F5TTS_335M, DiTConfig, synthetic_weight
 DEV = "cuda:0"
 
 
+# 16-bit MFMA operand type the per-op tests run with: bf16 (default) or fp16 (`with operand_mode("f16")`, which also flips
+# the library's f5_op_* entry points to the fp16 build of the kernels)
+_OP = {"dtype": torch.bfloat16}
+
+
+def op_dtype() -> torch.dtype:
+    return _OP["dtype"]
+
+
+class operand_mode:
+    def __init__(self, precision: str):
+        self.precision = precision
+
+    def __enter__(self):
+        self._ctx = E.operand_type(self.precision)
+        self._ctx.__enter__()
+        _OP["dtype"] = E.operand_dtype(self.precision)
+        return self
+
+    def __exit__(self, *exc):
+        _OP["dtype"] = torch.bfloat16
+        return self._ctx.__exit__(*exc)
+
+
+def _to_op(x: torch.Tensor) -> torch.Tensor:
+    return (x.clamp(-65504.0, 65504.0) if _OP["dtype"] == torch.float16 else x).to(_OP["dtype"])
+
+
 def split_bf16(x: torch.Tensor):
-    """fp32 -> (hi, lo) bf16 pair, same encoding as csrc/common.hpp f5_split."""
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.to(torch.float32)).to(torch.bfloat16)
+    """fp32 -> (hi, lo) operand pair (bf16, or fp16 under operand_mode("f16")), same encoding as csrc/op16.hpp f5_split."""
+    hi = _to_op(x)
+    lo = (x - hi.to(torch.float32)).to(_OP["dtype"])
     return hi.contiguous(), lo.contiguous()
 
 
 def bf16r(x: torch.Tensor) -> torch.Tensor:
-    return x.to(torch.bfloat16).to(torch.float32)
+    """round to the operand type and back (bf16 by default)"""
+    return _to_op(x).to(torch.float32)
 
 
 def join(hi: torch.Tensor, lo: torch.Tensor | None) -> torch.Tensor:

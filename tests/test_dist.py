@@ -63,3 +63,26 @@ def test_broadcast_and_gather_gloo_world2():
 
 def test_single_rank_needs_no_collective():
     assert broadcast_weights(_FakeEngine(0)) == 0.0
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` with no launcher environment must become TWO ranks by itself (it re-executes under
+    torch.distributed.run, rendezvous on 127.0.0.1) and report n_gpus == 2; --dry-run swaps the engine for a CPU step and
+    RCCL for gloo so this runs without a GPU.  Under a launcher (WORLD_SIZE set) it is one rank of that job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["gpus_arg"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["scaling"] == "weak" and rec["config"]["global_batch"] == 2 and rec["value"] > 0
+    # single process: no launcher, no collective
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0"],
+                        capture_output=True, text=True, timeout=120, env=env)
+    assert r1.returncode == 0 and json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1

@@ -12,7 +12,7 @@ import torch
 from f5test import O, ROOT, TINY, F5TTS_335M, synthetic_weights
 from f5_tts_mlx_amd import engine as E
 from f5_tts_mlx_amd import utils as U
-from f5_tts_mlx_amd.cfm import (odeint_euler, odeint_midpoint, odeint_rk4, prepare_lengths, time_grid)
+from f5_tts_mlx_amd.cfm import (prepare_lengths, time_grid)
 from f5_tts_mlx_amd.rng import mlx_like_normal, threefry2x32
 from f5_tts_mlx_amd.weights import check_weights, convert_upstream_weights, num_params, param_specs
 
@@ -74,14 +74,6 @@ def test_prepare_lengths_matches_oracle_and_raises():
         prepare_lengths(text, 12, 3, None, None, 4096, "euler")
     with pytest.raises(ValueError, match="Unknown method: heun"):
         prepare_lengths(text, 12, 3, 50, None, 4096, "heun")
-
-
-def test_host_ode_solvers_match_oracle():
-    f = lambda t, y: -1.3 * y + torch.sin(3 * t)
-    t = torch.linspace(0, 1, 9)
-    y0 = torch.tensor([1.0, -2.0])
-    for a, b in ((odeint_euler, O.odeint_euler), (odeint_midpoint, O.odeint_midpoint), (odeint_rk4, O.odeint_rk4)):
-        assert torch.equal(a(f, y0, t), b(f, y0, t))
 
 
 def test_rng_emulation_is_deterministic():
@@ -178,6 +170,62 @@ def test_engine_handle_errors_and_sizes_without_gpu():
     bad = E.to_c_config(type(F5TTS_335M)(dim=1000))
     hb = C.c_void_p()
     assert lib.f5_engine_create(C.byref(bad), 0, C.byref(hb)) != 0 and b"dim" in lib.f5_last_error()
+
+
+def test_f16_precision_and_host_half_conversion_without_gpu():
+    """precision "f16": an engine can be created / sized without a GPU, its arena equals the bf16 one (one 16-bit copy per
+    matrix), and the host-side float -> fp16 conversion used by f5_load_tensor is IEEE round-to-nearest-even with
+    saturation (checked exhaustively over all fp16 values and their midpoints, and on random floats against numpy)."""
+    lib = E.load_library()
+    cfg = E.to_c_config(F5TTS_335M)
+    sizes = {}
+    for prec in ("bf16", "f16"):
+        h, n = C.c_void_p(), C.c_size_t()
+        assert lib.f5_engine_create(C.byref(cfg), E.PRECISIONS[prec], C.byref(h)) == 0
+        assert lib.f5_weights_bytes(h, C.byref(n)) == 0
+        assert lib.f5_engine_graph_count(h) == 0 and lib.f5_engine_set_graph_cache(h, 4) == 0
+        assert lib.f5_engine_set_graph_cache(h, 0) != 0
+        sizes[prec] = n.value
+        lib.f5_engine_destroy(h)
+    assert sizes["bf16"] == sizes["f16"]
+    assert lib.f5_engine_create(C.byref(cfg), 9, C.byref(C.c_void_p())) != 0 and b"precision" in lib.f5_last_error()
+    assert lib.f5_op_set_operand_type(2) != 0 and lib.f5_op_set_operand_type(1) == 0 and lib.f5_op_set_operand_type(0) == 0
+    f2h = lambda x: int(lib.f5_debug_f2h_bits(C.c_float(float(x))))
+    # every finite fp16 value converts to itself and back
+    allh = np.arange(65536, dtype=np.uint16)
+    vals = allh.view(np.float16).astype(np.float32)
+    fin = np.isfinite(vals)
+    for hb, v in zip(allh[fin][::7], vals[fin][::7]):
+        assert f2h(v) == int(hb), (hb, v)
+        assert lib.f5_debug_h_bits2f(int(hb)) == float(v)
+    # random floats (normals, subnormal range, near-overflow) against numpy's RNE conversion
+    r = np.random.default_rng(0)
+    xs = np.concatenate([r.standard_normal(3000) * 3, r.standard_normal(2000) * 1e-6, r.standard_normal(2000) * 3e4,
+                         np.array([0.0, -0.0, 65504.0, 65519.9, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001, 6.1e-5])]).astype(np.float32)
+    xs = xs[np.abs(xs) < 65520]
+    want = xs.astype(np.float16).view(np.uint16)
+    got = np.array([f2h(x) for x in xs], dtype=np.uint16)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:5]
+    # beyond the fp16 range: saturate to +-65504 (numpy would give inf), like the device producers (csrc/op16.hpp f5_sat)
+    assert f2h(1e6) == 0x7BFF and f2h(-7e4) == 0xFBFF and f2h(float("inf")) == 0x7BFF
+    assert (f2h(float("nan")) & 0x7C00) == 0x7C00 and (f2h(float("nan")) & 0x3FF) != 0
+    # bf16 helper agrees with torch
+    xb = torch.from_numpy(xs[:2000])
+    wantb = xb.to(torch.bfloat16).view(torch.int16).numpy().astype(np.uint16)
+    gotb = np.array([int(lib.f5_debug_f2bf_bits(C.c_float(float(x)))) for x in xs[:2000]], dtype=np.uint16)
+    assert np.array_equal(gotb, wantb)
+
+
+def test_ascii_segmentation_follows_jieba_two_stage_split():
+    """utils._ascii_segments restates jieba.cut for single-byte text: runs of [a-zA-Z0-9+#&._%-] are blocks whose alphanumeric
+    parts stay whole and whose symbol stretches stay ONE piece (so the reference inserts a space token before them)."""
+    seg = U._ascii_segments
+    assert seg("wait... ok") == ["wait", "...", " ", "ok"]
+    assert seg("a--b") == ["a", "--", "b"]
+    assert seg("3.5% of C++") == ["3.5%", " ", "of", " ", "C", "++"]
+    assert seg("x, y!  z") == ["x", ",", " ", "y", "!", " ", " ", "z"]
+    assert U.convert_char_to_pinyin(["wait... ok"]) == [list("wait ... ok")]
+    assert U.convert_char_to_pinyin(["no--way"]) == [list("no --way")[:2] + [" ", "-", "-"] + [" ", "w", "a", "y"]]
 
 
 def test_engine_refuses_cpu_device():

@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from f5test import DEV, E, O, P, bf16r, join, randn, report, rng, split_bf16, stream
+from f5test import DEV, E, O, P, bf16r, join, op_dtype, randn, report, rng, split_bf16, stream
 
 pytestmark = pytest.mark.gpu
 
@@ -37,8 +37,8 @@ def _gemm(lib, a, w, bias, epi, nseg, N=None):
     wpad[: w.shape[0]] = w
     w_hi, w_lo = split_bf16(wpad.to(DEV))
     out_f = torch.full((M, N), float("nan"), device=DEV)
-    out_hi = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
-    out_lo = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    out_hi = torch.zeros((M, N), dtype=op_dtype(), device=DEV)
+    out_lo = torch.zeros((M, N), dtype=op_dtype(), device=DEV)
     b = bias.to(DEV) if bias is not None else None
     E.check(lib.f5_op_gemm(P(a_hi), P(a_lo), P(w_hi), P(w_lo), P(b), P(out_f), P(out_hi), P(out_lo), M, N, K, K, K, N, nseg, epi,
                            stream()), "f5_op_gemm")
@@ -105,12 +105,12 @@ def _attention_case(lib, B, H, N, kv_len, nseg, seed=0):
     cos_t = torch.empty((N, 32), device=DEV)
     sin_t = torch.empty((N, 32), device=DEV)
     E.check(lib.f5_op_rope_table(P(cos_t), P(sin_t), N, 64, stream()))
-    qk = [torch.zeros((B * N, 2 * D), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
-    vt = [torch.zeros((B * H, 64, npad), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    qk = [torch.zeros((B * N, 2 * D), dtype=op_dtype(), device=DEV) for _ in range(2)]
+    vt = [torch.zeros((B * H, 64, npad), dtype=op_dtype(), device=DEV) for _ in range(2)]
     bias_d = bias.to(DEV)
     E.check(lib.f5_op_qkv_rope(P(x_hi), P(x_lo), P(w_hi), P(w_lo), P(bias_d), P(cos_t), P(sin_t), P(qk[0]), P(qk[1]),
                                P(vt[0]), P(vt[1]), B, N, npad, H, D, nseg, stream()), "qkv_rope")
-    out = [torch.zeros((B * N, D), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    out = [torch.zeros((B * N, D), dtype=op_dtype(), device=DEV) for _ in range(2)]
     kv = torch.tensor(kv_len, dtype=torch.int32, device=DEV) if kv_len is not None else None
     E.check(lib.f5_op_attention(P(qk[0]), P(qk[1]), P(vt[0]), P(vt[1]), P(out[0]), P(out[1]), P(kv), B, H, N, npad, D,
                                 C.c_float(0.125), int(nseg == 3), stream()), "attention")
@@ -177,7 +177,7 @@ def test_attention_softmax_spike(lib):
     vt_full = torch.zeros((B * H, 64, npad))
     vt_full[..., :N] = v.reshape(N, H, 64).permute(1, 2, 0)
     vt_hi, vt_lo = split_bf16(vt_full.to(DEV))
-    out = [torch.zeros((B * N, D), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    out = [torch.zeros((B * N, D), dtype=op_dtype(), device=DEV) for _ in range(2)]
     E.check(lib.f5_op_attention(P(qk_hi), P(qk_lo), P(vt_hi), P(vt_lo), P(out[0]), P(out[1]), P(None), B, H, N, npad, D,
                                 C.c_float(0.125), 1, stream()))
     sync()
@@ -204,7 +204,7 @@ def test_convpos(lib, B, N, C, nseg):
     bias = randn(r, C, scale=0.1)
     x_hi, x_lo = split_bf16(x.reshape(B * N, C).to(DEV))
     w_hi, w_lo = split_bf16(w.reshape(C, taps * 64).to(DEV))
-    out = [torch.zeros((B * N, C), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    out = [torch.zeros((B * N, C), dtype=op_dtype(), device=DEV) for _ in range(2)]
     acc = randn(r, B * N, C).to(DEV)
     acc0 = acc.clone()
     bias_d = bias.to(DEV)
@@ -232,7 +232,7 @@ def test_convpos(lib, B, N, C, nseg):
 def test_ln_modulate(lib, rows, dim):
     r = rng(rows)
     x, sc, sh = randn(r, rows, dim) * 3 + 0.5, randn(r, dim, scale=0.5), randn(r, dim, scale=0.5)
-    hi = torch.zeros((rows, dim), dtype=torch.bfloat16, device=DEV)
+    hi = torch.zeros((rows, dim), dtype=op_dtype(), device=DEV)
     lo = torch.zeros_like(hi)
     xd, scd, shd = x.to(DEV), sc.to(DEV), sh.to(DEV)      # keep the device copies alive across the call
     E.check(lib.f5_op_ln_modulate(P(xd), P(scd), P(shd), P(hi), P(lo), rows, dim, stream()))
@@ -249,7 +249,7 @@ def test_dwconv_ln(lib, B, N, dim):
     x = randn(r, B, N, dim)
     dw_w, dw_b = randn(r, dim, 7, 1, scale=0.4), randn(r, dim, scale=0.1)
     ln_w, ln_b = 1 + randn(r, dim, scale=0.1), randn(r, dim, scale=0.1)
-    hi = torch.zeros((B * N, dim), dtype=torch.bfloat16, device=DEV)
+    hi = torch.zeros((B * N, dim), dtype=op_dtype(), device=DEV)
     lo = torch.zeros_like(hi)
     dev = [t.to(DEV) for t in (x, dw_w.reshape(dim, 7).contiguous(), dw_b, ln_w, ln_b)]
     E.check(lib.f5_op_dwconv_ln(P(dev[0]), P(dev[1]), P(dev[2]), P(dev[3]), P(dev[4]), P(hi), P(lo), B, N, dim, stream()))
@@ -265,7 +265,7 @@ def test_grn(lib, B, N, dim):
     r = rng(dim)
     g, gamma, beta = randn(r, B, N, dim), randn(r, dim, scale=0.1), randn(r, dim, scale=0.1)
     scratch = torch.zeros(lib.f5_op_grn_scratch_floats(B, N, dim), device=DEV)
-    hi = torch.zeros((B * N, dim), dtype=torch.bfloat16, device=DEV)
+    hi = torch.zeros((B * N, dim), dtype=op_dtype(), device=DEV)
     lo = torch.zeros_like(hi)
     dev = [t.to(DEV) for t in (g, gamma, beta)]
     E.check(lib.f5_op_grn(P(dev[0]), P(dev[1]), P(dev[2]), P(scratch), P(hi), P(lo), B, N, dim, stream()))
@@ -361,7 +361,7 @@ def test_cfg_axpy(lib):
     pred, null, base = randn(r, rows, mel), randn(r, rows, mel), randn(r, rows, mel)
     dt = torch.tensor([0.0506], device=DEV)
     out = torch.empty((rows, mel), device=DEV)
-    xin = [torch.full((rows, 128), 5.0, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    xin = [torch.full((rows, 128), 5.0, dtype=op_dtype(), device=DEV) for _ in range(2)]
     pred_d, null_d, base_d = pred.to(DEV), null.to(DEV), base.to(DEV)
     E.check(lib.f5_op_cfg_axpy(P(pred_d), P(null_d), C.c_float(2.0), P(base_d), P(dt), C.c_float(0.5), C.c_float(1.0), P(out),
                                P(xin[0]), P(xin[1]), rows, mel, stream()))
@@ -491,6 +491,40 @@ def test_gemm_resid_gate(lib, tile, nseg):
         ref = x0.double() + gate.double() * ((aa @ ww.T + bias.double()) * keep.double()[:, None])
         mx, _, _ = report(f"gemm resid_gate tile={tile} nseg={nseg}", x.cpu(), ref)
         assert mx <= (5e-5 if nseg == 3 else 2e-4) * max(1.0, float(ref.abs().max()))
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 4, 5])
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_gemm_addrows(lib, tile, nseg):
+    """EPI_ADDROWS: out = A[row % a_row_mod] W^T + addrows[row]  (+ the 16-bit copy) -- the per-step half of the split input
+    projection (dit.py:250), K = 128 (mel 100 zero padded), both CFG branches reading the same x rows."""
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        r = rng(77 + tile)
+        M1, N, K = 350, 512, 128
+        M = 2 * M1
+        a, w = randn(r, M1, K), randn(r, N, K, scale=K ** -0.5)
+        a[:, 100:] = 0.0
+        add = randn(r, M, N)
+        a_hi, a_lo = split_bf16(a.to(DEV))
+        w_hi, w_lo = split_bf16(w.to(DEV))
+        add_d = add.to(DEV)
+        out = torch.full((M, N), float("nan"), device=DEV)
+        hi = torch.zeros((M, N), dtype=op_dtype(), device=DEV)
+        lo = torch.zeros_like(hi)
+        E.check(lib.f5_op_gemm_addrows(P(a_hi), P(a_lo), P(w_hi), P(w_lo), P(add_d), M1, P(out), P(hi), P(lo), M, N, K, K, K, N, nseg,
+                                       stream()), "gemm_addrows")
+        sync()
+        aa = a.double() if nseg == 3 else bf16r(a).double()
+        ww = w.double() if nseg == 3 else bf16r(w).double()
+        ref = torch.cat([aa, aa]) @ ww.T + add.double()
+        mx, _, _ = report(f"gemm addrows tile={tile} nseg={nseg}", out.cpu(), ref)
+        assert mx <= (5e-5 if nseg == 3 else 2e-4) * max(1.0, float(ref.abs().max()))
+        assert torch.equal(hi.cpu(), bf16r(out.cpu()).to(op_dtype()))            # the 16-bit copy is the rounding of the fp32 value
+        if nseg == 3:
+            assert float((join(hi, lo).cpu().double() - out.cpu().double()).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
     finally:
         E.check(lib.f5_debug_set_gemm_tile(0))
 
