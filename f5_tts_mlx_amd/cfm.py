@@ -257,15 +257,16 @@ class F5TTS:
         vocoder = None
         import os
         from .vocos import Vocos
+        vprec = precision if precision in ("bf16", "bf16x3", "f16") else "bf16"     # the MX-fp8 mode covers the DiT block GEMMs only
         for cand in (vocoder_name_or_path, os.environ.get("F5_VOCOS_PATH")):
             if cand and Path(cand).exists():
-                vocoder = Vocos.from_pretrained(cand, precision=precision, device=device).decode
+                vocoder = Vocos.from_pretrained(cand, precision=vprec, device=device).decode
                 break
         if vocoder is None and vocoder_name_or_path:
             try:
                 from huggingface_hub import snapshot_download
                 vdir = snapshot_download(repo_id=vocoder_name_or_path, allow_patterns=["*.safetensors", "*.yaml", "*.json"])
-                vocoder = Vocos.from_pretrained(vdir, precision=precision, device=device).decode
+                vocoder = Vocos.from_pretrained(vdir, precision=vprec, device=device).decode
             except Exception as exc:
                 if not allow_missing_vocoder:
                     raise RuntimeError(

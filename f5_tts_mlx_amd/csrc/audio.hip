@@ -15,6 +15,8 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wave
     __shared__ float twc[MEL_NFFT / 2], tws[MEL_NFFT / 2];
     const int tid = threadIdx.x;
     const long frame = blockIdx.x;
+    wave += (long)blockIdx.y * L;                                   // batch element: waves are [B][L], outputs [B][frames][n_mels]
+    out += (long)blockIdx.y * (long)gridDim.x * n_mels;
     const long start = frame * hop - MEL_NFFT / 2;
     for (int i = tid; i < MEL_NFFT; i += 256) {
         const long si = start + i;
@@ -62,17 +64,21 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wave
     }
 }
 
-extern "C" int f5_mel_spectrogram(const float* wave, int64_t L, const float* window, const float* filterbank, int n_fft, int hop,
-                                  int n_mels, float* out, void* stream) {
+extern "C" int f5_mel_spectrogram_batch(const float* wave, int B, int64_t L, const float* window, const float* filterbank, int n_fft,
+                                        int hop, int n_mels, float* out, void* stream) {
     F5_REQUIRE(wave && window && filterbank && out, "mel: null pointer");
     F5_REQUIRE(n_fft == MEL_NFFT, "mel: only n_fft = 1024 is supported (got %d)", n_fft);
-    F5_REQUIRE(hop > 0 && n_mels > 0, "mel: bad hop / n_mels");
+    F5_REQUIRE(hop > 0 && n_mels > 0 && B >= 1 && B <= 65535, "mel: bad hop / n_mels / batch");
     const long frames = L / hop;
     if (frames <= 0) return 0;
-    hipLaunchKernelGGL(mel_kernel, dim3((unsigned)frames), dim3(256), 0, (hipStream_t)stream, wave, (long)L, window, filterbank,
-                       hop, n_mels, out);
+    hipLaunchKernelGGL(mel_kernel, dim3((unsigned)frames, (unsigned)B), dim3(256), 0, (hipStream_t)stream, wave, (long)L, window,
+                       filterbank, hop, n_mels, out);
     F5_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int f5_mel_spectrogram(const float* wave, int64_t L, const float* window, const float* filterbank, int n_fft, int hop,
+                                  int n_mels, float* out, void* stream) {
+    return f5_mel_spectrogram_batch(wave, 1, L, window, filterbank, n_fft, hop, n_mels, out, stream);
 }
 
 // =================================================================================================
@@ -133,6 +139,8 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
                                                         float* __restrict__ wave, int nframes, int hop, long out_len) {
     const long s = (long)blockIdx.x * 256 + threadIdx.x;
     if (s >= out_len) return;
+    frames += (long)blockIdx.y * nframes * MEL_NFFT;            // batch element
+    wave += (long)blockIdx.y * out_len;
     const long pos = s + MEL_NFFT / 2;                          // position in the untrimmed signal
     int f1 = (int)(pos / hop);
     if (f1 > nframes - 1) f1 = nframes - 1;
@@ -151,17 +159,26 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     wave[s] = acc / env;
 }
 
-extern "C" int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scratch, float* wave, int nframes,
-                           int n_fft, int hop, void* stream) {
+// x [B * nframes][ldx] (rows of utterance b are b*nframes ...), frames_scratch [B * nframes][n_fft], wave [B][hop * (nframes - 1)]:
+// two launches for the whole batch
+int f5_launch_istft(const float* x, int ldx, const float* window, float* frames_scratch, float* wave, int B, int nframes, int hop,
+                    hipStream_t s) {
     F5_REQUIRE(x && window && frames_scratch && wave, "istft: null pointer");
-    F5_REQUIRE(n_fft == MEL_NFFT, "istft: only n_fft = 1024 is supported (got %d)", n_fft);
-    F5_REQUIRE(nframes >= 1 && hop > 0 && ldx >= n_fft + 2, "istft: bad sizes");
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(istft_frames_kernel, dim3(nframes), dim3(256), 0, s, x, ldx, window, frames_scratch);
+    F5_REQUIRE(B >= 1 && B <= 65535 && nframes >= 1 && hop > 0 && ldx >= MEL_NFFT + 2, "istft: bad sizes");
+    hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)(B * nframes)), dim3(256), 0, s, x, ldx, window, frames_scratch);
     const long out_len = (long)hop * (nframes - 1);
     if (out_len > 0)
-        hipLaunchKernelGGL(istft_ola_kernel, dim3(f5_cdiv(out_len, 256)), dim3(256), 0, s, frames_scratch, window, wave, nframes, hop,
-                           out_len);
+        hipLaunchKernelGGL(istft_ola_kernel, dim3(f5_cdiv(out_len, 256), (unsigned)B), dim3(256), 0, s, frames_scratch, window, wave,
+                           nframes, hop, out_len);
     F5_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int f5_op_istft_batch(const float* x, int ldx, const float* window, float* frames_scratch, float* wave, int B, int nframes,
+                                 int n_fft, int hop, void* stream) {
+    F5_REQUIRE(n_fft == MEL_NFFT, "istft: only n_fft = 1024 is supported (got %d)", n_fft);
+    return f5_launch_istft(x, ldx, window, frames_scratch, wave, B, nframes, hop, (hipStream_t)stream);
+}
+extern "C" int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scratch, float* wave, int nframes,
+                           int n_fft, int hop, void* stream) {
+    return f5_op_istft_batch(x, ldx, window, frames_scratch, wave, 1, nframes, n_fft, hop, stream);
 }

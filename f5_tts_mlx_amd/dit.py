@@ -18,7 +18,7 @@ from .weights import DiTConfig
 
 class DiT:
     def __init__(self, *, dim, depth=8, heads=8, dim_head=64, dropout=0.0, ff_mult=4, mel_dim=100, text_num_embeds=256,
-                 text_dim=None, text_mask_padding=True, conv_layers=0, precision: str = "bf16",
+                 text_dim=None, text_mask_padding=True, conv_layers=0, precision: str = "f16",
                  device: str | torch.device = "cuda:0"):
         if text_dim is None:
             text_dim = mel_dim
@@ -38,7 +38,7 @@ class DiT:
         self._engine: Optional[Engine] = None
 
     @classmethod
-    def from_config(cls, cfg: DiTConfig, precision="bf16", device="cuda:0") -> "DiT":
+    def from_config(cls, cfg: DiTConfig, precision="f16", device="cuda:0") -> "DiT":
         m = cls(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, dim_head=cfg.dim_head, ff_mult=cfg.ff_mult, mel_dim=cfg.mel_dim,
                 text_num_embeds=cfg.text_num_embeds, text_dim=cfg.text_dim, conv_layers=cfg.conv_layers, precision=precision,
                 device=device)

@@ -7,12 +7,14 @@ GELU, Linear 1536->512, layer-scale gamma, residual] -> LayerNorm -> Linear(512-
 (mag = min(exp(.), 1e2), phase -> cos/sin, istft n_fft=1024 hop=256 hann center=True).  PARITY UNPINNED until a real
 checkpoint / vocos_mlx output is available; the structure is checked against oracle/vocos_oracle.py + torch.istft.
 
-Every layer is one HIP kernel launch through the C ABI (`f5_op_*`); Python only sequences them, like the reference's
-Python-level module tree.
+The whole decode is ONE C-ABI call (`f5_vocode`, csrc/vocoder.hip): weights arena + workspace owned by this object, the layer
+sequence captured as a hipGraph per (batch, frames), the ISTFT of the whole batch in two launches.  This class only owns the
+buffers and mirrors `vocos_mlx.Vocos` (`from_pretrained`, `decode`).
 """
 from __future__ import annotations
 
-from typing import Dict
+import ctypes as C
+from typing import Dict, Optional
 
 import numpy as np
 import torch
@@ -56,57 +58,63 @@ def synthetic_vocos_weights(seed: int = 7) -> Dict[str, np.ndarray]:
     return out
 
 
-def _split(x: torch.Tensor, two: bool, dtype: torch.dtype = torch.bfloat16):
-    """fp32 -> 16-bit MFMA operand (bf16, or fp16 saturated at +-65504 like the device producers) + optional residual."""
-    hi = (x.clamp(-65504.0, 65504.0) if dtype == torch.float16 else x).to(dtype)
-    lo = (x - hi.to(torch.float32)).to(dtype) if two else None
-    return hi.contiguous(), (lo.contiguous() if two else None)
+class VocosConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_mels", "dim", "intermediate_dim", "num_layers", "n_fft", "hop_length")]
+
+
+# state-dict entries of an upstream checkpoint that are buffers of the feature extractor / ISTFT module, not parameters of the
+# decode path (the window and the mel filterbank are recomputed)
+_IGNORED_PREFIXES = ("feature_extractor.", "head.istft.")
 
 
 class Vocos:
-    def __init__(self, weights: Dict[str, np.ndarray], precision: str = "bf16", device: str | torch.device = "cuda:0"):
+    def __init__(self, weights: Dict[str, np.ndarray], precision: str = "f16", device: str | torch.device = "cuda:0",
+                 use_graph: bool = True):
+        if precision not in ("bf16", "bf16x3", "f16"):
+            raise ValueError(f"vocoder precision must be bf16, bf16x3 or f16 (got {precision!r})")
         self.lib = E.load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the HIP vocoder needs a GPU device; there is no CPU path")
-        self.two = precision == "bf16x3"
-        self.nseg = 3 if self.two else 1
-        w = {k.replace("backbone.convnext.", "backbone.convnext."): np.asarray(v, dtype=np.float32) for k, v in weights.items()}
-        for name, shape in vocos_param_specs():
-            if name not in w:
-                raise ValueError(f"missing vocoder parameter {name}")
-            if name.endswith("embed.weight") and w[name].shape == (DIM, 7, N_MELS):      # MLX conv layout (out, k, in)
-                w[name] = np.ascontiguousarray(np.swapaxes(w[name], 1, 2))
-            if name.endswith("dwconv.weight") and w[name].shape == (DIM, 7, 1):
-                w[name] = np.ascontiguousarray(np.swapaxes(w[name], 1, 2))
-            if tuple(w[name].shape) != tuple(shape):
-                raise ValueError(f"shape mismatch for {name}: {w[name].shape} vs {shape}")
-        dev = self.device
-        f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        # embed conv as a GEMM over im2col rows: W[co][tap][c padded to 128]
-        we = np.zeros((DIM, 7, 128), np.float32)
-        we[:, :, :N_MELS] = np.transpose(w["backbone.embed.weight"], (0, 2, 1))
-        self.w_embed = _split(f(we.reshape(DIM, 7 * 128)), self.two)
-        self.b_embed = f(w["backbone.embed.bias"])
-        self.norm = (f(w["backbone.norm.weight"]), f(w["backbone.norm.bias"]))
-        self.blocks = []
-        for i in range(LAYERS):
-            p = f"backbone.convnext.{i}."
-            self.blocks.append(dict(
-                dw_w=f(w[p + "dwconv.weight"].reshape(DIM, 7)), dw_b=f(w[p + "dwconv.bias"]),
-                ln_w=f(w[p + "norm.weight"]), ln_b=f(w[p + "norm.bias"]),
-                pw1=_split(f(w[p + "pwconv1.weight"]), self.two), b1=f(w[p + "pwconv1.bias"]),
-                pw2=_split(f(w[p + "pwconv2.weight"]), self.two), b2=f(w[p + "pwconv2.bias"]), gamma=f(w[p + "gamma"])))
-        self.final_norm = (f(w["backbone.final_layer_norm.weight"]), f(w["backbone.final_layer_norm.bias"]))
-        wh = np.zeros(((N_FFT + 2 + 127) // 128 * 128, DIM), np.float32)
-        wh[: N_FFT + 2] = w["head.out.weight"]
-        self.w_head = _split(f(wh), self.two)
-        self.b_head = f(w["head.out.bias"])
-        self.window = f(np.hanning(N_FFT + 1)[:-1].astype(np.float32))
+        torch.cuda.set_device(self.device)
+        self.precision = precision
+        self.use_graph = use_graph
+        self._h = C.c_void_p()
+        cfg = VocosConfig(N_MELS, DIM, INTER, LAYERS, N_FFT, HOP)
+        E.check(self.lib.f5_vocoder_create(C.byref(cfg), E.PRECISIONS[precision], C.byref(self._h)), "f5_vocoder_create")
+        nbytes = C.c_size_t()
+        E.check(self.lib.f5_vocoder_weights_bytes(self._h, C.byref(nbytes)), "f5_vocoder_weights_bytes")
+        self.arena = E._aligned_bytes(nbytes.value, self.device)
+        E.check(self.lib.f5_vocoder_set_weights_arena(self._h, E.ptr(self.arena), C.c_size_t(self.arena.numel()),
+                                                      E.stream_ptr(self.device)), "f5_vocoder_set_weights_arena")
+        want = dict(vocos_param_specs())
+        for name, arr in weights.items():
+            if name.startswith(_IGNORED_PREFIXES):
+                continue
+            if name not in want:
+                raise ValueError(f"unexpected vocoder parameter {name}")
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            E.check(self.lib.f5_vocoder_load_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.ndim, shape),
+                    f"f5_vocoder_load_tensor({name})")
+        missing = [n for n in want if n not in weights]
+        if missing:
+            raise ValueError(f"missing vocoder parameter {missing[0]}")
+        E.check(self.lib.f5_vocoder_finalize(self._h, E.stream_ptr(self.device)), "f5_vocoder_finalize")
+        self._workspace: Optional[torch.Tensor] = None
+        self._stream = torch.cuda.Stream(device=self.device)      # hipGraph capture is illegal on the legacy default stream
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.lib.f5_vocoder_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
 
     @classmethod
-    def from_pretrained(cls, path: str, precision: str = "bf16", device: str = "cuda:0") -> "Vocos":
-        """Load `model.safetensors` / `pytorch_model.bin`-style weights from a local directory (no network here)."""
+    def from_pretrained(cls, path: str, precision: str = "f16", device: str = "cuda:0") -> "Vocos":
+        """Load `model.safetensors`-style weights (upstream Vocos names) from a local directory (no network here)."""
         from pathlib import Path
         p = Path(path)
         cands = [p] if p.is_file() else sorted(p.glob("*.safetensors"))
@@ -115,41 +123,28 @@ class Vocos:
         from safetensors.numpy import load_file
         return cls(load_file(str(cands[0])), precision=precision, device=device)
 
+    def _ws(self, B: int, N: int) -> torch.Tensor:
+        nbytes = C.c_size_t()
+        E.check(self.lib.f5_vocoder_workspace_bytes(self._h, B, N, C.byref(nbytes)), "f5_vocoder_workspace_bytes")
+        if self._workspace is None or self._workspace.numel() < nbytes.value:
+            self._workspace = None
+            self._workspace = E._aligned_bytes(nbytes.value, self.device)
+        return self._workspace
+
     def decode(self, mel: torch.Tensor) -> torch.Tensor:
         """mel (b, n, 100) -> wave: 1-D (256*(n-1),) for b == 1 (what generate.py:183 slices), else (b, 256*(n-1))."""
-        lib, dev, ns = self.lib, self.device, self.nseg
-        mel = mel.to(dev, torch.float32).contiguous()
+        mel = mel.to(self.device, torch.float32).contiguous()
         B, N, C_ = mel.shape
         assert C_ == N_MELS
-        rows = B * N
-        P, st = E.ptr, E.stream_ptr(dev)
-        bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)
-        a0, a0l = bf(rows, 7 * 128), (bf(rows, 7 * 128) if self.two else None)
-        E.check(lib.f5_op_im2col7(P(mel), P(a0), P(a0l), B, N, N_MELS, st), "im2col7")
-        x0 = torch.empty((rows, DIM), device=dev)
-        E.check(lib.f5_op_gemm(P(a0), P(a0l), P(self.w_embed[0]), P(self.w_embed[1]), P(self.b_embed), P(x0), P(None), P(None),
-                               rows, DIM, 7 * 128, 7 * 128, 7 * 128, DIM, ns, 0, st), "embed gemm")
-        x = torch.empty_like(x0)
-        E.check(lib.f5_op_layernorm(P(x0), P(self.norm[0]), P(self.norm[1]), P(x), P(None), P(None), rows, DIM, st), "norm")
-        h, hl = bf(rows, DIM), (bf(rows, DIM) if self.two else None)
-        g, gl = bf(rows, INTER), (bf(rows, INTER) if self.two else None)
-        for blk in self.blocks:
-            E.check(lib.f5_op_dwconv_ln(P(x), P(blk["dw_w"]), P(blk["dw_b"]), P(blk["ln_w"]), P(blk["ln_b"]), P(h), P(hl), B, N,
-                                        DIM, st), "dwconv_ln")
-            E.check(lib.f5_op_gemm(P(h), P(hl), P(blk["pw1"][0]), P(blk["pw1"][1]), P(blk["b1"]), P(None), P(g), P(gl), rows,
-                                   INTER, DIM, DIM, DIM, INTER, ns, 8, st), "pwconv1")
-            E.check(lib.f5_op_gemm_resid_gate(P(g), P(gl), P(blk["pw2"][0]), P(blk["pw2"][1]), P(blk["b2"]), P(blk["gamma"]),
-                                              P(None), P(x), rows, DIM, INTER, INTER, INTER, DIM, ns, st), "pwconv2")
-        E.check(lib.f5_op_layernorm(P(x), P(self.final_norm[0]), P(self.final_norm[1]), P(None), P(h), P(hl), rows, DIM, st),
-                "final norm")
-        y = torch.empty((rows, N_FFT + 2), device=dev)
-        E.check(lib.f5_op_gemm(P(h), P(hl), P(self.w_head[0]), P(self.w_head[1]), P(self.b_head), P(y), P(None), P(None), rows,
-                               N_FFT + 2, DIM, DIM, DIM, N_FFT + 2, ns, 0, st), "head gemm")
-        frames = torch.empty((N, N_FFT), device=dev)
-        wave = torch.empty((B, HOP * (N - 1)), device=dev)
-        for b in range(B):
-            E.check(lib.f5_op_istft(P(y[b * N:(b + 1) * N]), N_FFT + 2, P(self.window), P(frames), P(wave[b]), N, N_FFT, HOP, st),
-                    "istft")
+        ws = self._ws(B, N)
+        wave = torch.empty((B, HOP * (N - 1)), device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            E.check(self.lib.f5_vocode(self._h, E.ptr(mel), B, N, E.ptr(wave), E.ptr(ws), C.c_size_t(ws.numel()), int(self.use_graph),
+                                       C.c_void_p(self._stream.cuda_stream)), "f5_vocode")
+        cur.wait_stream(self._stream)
+        mel.record_stream(self._stream)
         return wave[0] if B == 1 else wave
 
     __call__ = decode

@@ -70,6 +70,11 @@ int f5_weights_bytes(f5_engine* e, size_t* bytes);
 int f5_set_weights_arena(f5_engine* e, void* dev_arena, size_t bytes, void* stream);
 int f5_load_tensor(f5_engine* e, const char* name, const float* host_data, int ndim, const int64_t* shape);
 int f5_finalize_weights(f5_engine* e, void* stream);
+/* Multi-GPU start-up (one process per GPU, utterances sharded, no per-step communication): replicate rank `root`'s arena over an
+ * RCCL communicator (`nccl_comm` = ncclComm_t) with ONE ncclBroadcast enqueued on `stream`; ranks other than root are marked
+ * loaded and then call f5_finalize_weights.  librccl.so is resolved with dlopen at the first call.  (A torch.distributed host
+ * does the same with dist.broadcast on the arena tensor, f5_tts_mlx_amd/dist.py.) */
+int f5_broadcast_weights(f5_engine* e, void* nccl_comm, int root, int rank, void* stream);
 /* for ranks that received the arena by broadcast instead of f5_load_tensor */
 int f5_mark_weights_loaded(f5_engine* e);
 
@@ -227,10 +232,46 @@ int f5_op_gemm_f8(const void* a8, const void* a_scales, const void* w8, const vo
                   const float* gate, const uint8_t* rowkeep, float* out_f32, void* out_bf, void* out8, void* out8_scales,
                   int M, int N, int K, int lda8, int ldw8, int ldo, int epi, void* stream);
 
-/* ---- audio (audio.py:115-210; vocoder = vocos_mlx, third party) -------------------------------- */
-/* log-mel spectrogram of one waveform: wave dev [L] fp32 -> out dev [L/256][n_mels] */
+/* ---- audio front-end (audio.py:115-230) ---------------------------------------------------------- */
+/* log-mel spectrogram (audio.py:162-210: zero centre padding, periodic Hann, |rfft|, HTK filterbank, log(max(., 1e-5))) of a
+ * batch of equally long waveforms in ONE launch: wave dev [B][L] fp32 -> out dev [B][L / hop][n_mels].  The reference loops
+ * over the batch in Python (audio.py:195). */
+int f5_mel_spectrogram_batch(const float* wave, int B, int64_t L, const float* window, const float* filterbank, int n_fft, int hop,
+                             int n_mels, float* out, void* stream);
+/* the same for one waveform: wave dev [L] -> out dev [L / hop][n_mels] */
 int f5_mel_spectrogram(const float* wave, int64_t L, const float* window, const float* filterbank, int n_fft, int hop,
                        int n_mels, float* out, void* stream);
+
+/* ---- vocoder: Vocos mel-24khz behind one call (replaces `self._vocoder(out)`, cfm.py:399-400; wiring cfm.py:446,471) ---------
+ * The reference delegates to the third-party `vocos_mlx` package (not in its repository); this is the published Vocos
+ * architecture (ConvNeXt backbone + ISTFT head) on the same kernels as the DiT.  Same ownership rules as the engine: the caller
+ * allocates the weights arena and the workspace; tensors are loaded by their upstream state-dict names
+ * ("backbone.embed.weight", "backbone.convnext.0.pwconv1.weight", ..., "head.out.bias"), conv weights in the PyTorch (out, in, k)
+ * or the MLX (out, k, in) layout.  PARITY UNPINNED against vocos_mlx (no vector, no checkpoint reachable offline). */
+typedef struct f5_vocoder f5_vocoder;
+typedef struct f5_vocos_config {
+    int32_t n_mels;            /* 100 */
+    int32_t dim;               /* 512 */
+    int32_t intermediate_dim;  /* 1536 */
+    int32_t num_layers;        /* 8 */
+    int32_t n_fft;             /* 1024 (only value supported) */
+    int32_t hop_length;        /* 256 */
+} f5_vocos_config;
+int f5_vocoder_create(const f5_vocos_config* cfg, int precision, f5_vocoder** out);   /* F5_PREC_BF16 / _BF16X3 / _F16 */
+void f5_vocoder_destroy(f5_vocoder* v);
+int f5_vocoder_weights_bytes(f5_vocoder* v, size_t* bytes);
+int f5_vocoder_set_weights_arena(f5_vocoder* v, void* dev_arena, size_t bytes, void* stream);
+int f5_vocoder_load_tensor(f5_vocoder* v, const char* name, const float* host_data, int ndim, const int64_t* shape);
+int f5_vocoder_mark_weights_loaded(f5_vocoder* v);     /* arena content arrived by a broadcast */
+int f5_vocoder_finalize(f5_vocoder* v, void* stream);
+int f5_vocoder_workspace_bytes(f5_vocoder* v, int B, int N, size_t* bytes);
+/* mel dev [B][N][n_mels] fp32 -> wave dev [B][hop * (N - 1)] fp32; use_graph != 0: captured per (B, N, workspace), <= 8 graphs kept */
+int f5_vocode(f5_vocoder* v, const float* mel, int B, int N, float* wave, void* workspace, size_t workspace_bytes, int use_graph,
+              void* stream);
+/* ISTFT head alone (per-op entry for tests): x dev [B * nframes][ldx >= n_fft + 2] (log-magnitude | phase) ->
+ * wave dev [B][hop * (nframes - 1)]; frames_scratch dev [B * nframes][n_fft]; two launches for the whole batch */
+int f5_op_istft_batch(const float* x, int ldx, const float* window, float* frames_scratch, float* wave, int B, int nframes,
+                      int n_fft, int hop, void* stream);
 
 #ifdef __cplusplus
 }

@@ -120,6 +120,13 @@ def _build_core() -> types.ModuleType:
     mx.matmul = lambda a, b: _wrap(np.matmul(_raw(a), _raw(b)))
     mx.einsum = lambda spec, *ops: _wrap(np.einsum(spec, *[_raw(o) for o in ops]))
     mx.eval = lambda *a, **k: None
+
+    def load(path, format=None):
+        """mx.load(path, format="safetensors") -> dict of arrays (cfm.py:441,474)"""
+        from safetensors.numpy import load_file
+        return {k: _wrap(v) for k, v in load_file(str(path)).items()}
+
+    mx.load = load
     mx.compile = lambda fn, *a, **k: fn
 
     def pad(a, pad_width, mode="constant", constant_values=0):
@@ -181,6 +188,31 @@ def _build_nn(mx) -> types.ModuleType:
 
         def train(self, mode=True):
             return self
+
+        def named_modules(self, prefix=""):
+            """(dotted path, module) for this module and everything below it: attributes that are Modules and the elements
+            of list / tuple attributes (MLX names list elements `attr.N`)."""
+            out = [(prefix, self)]
+            for name, val in vars(self).items():
+                if name.startswith("_"):
+                    continue                      # MLX: attributes starting with "_" are not part of the parameter tree
+                path = f"{prefix}.{name}" if prefix else name
+                if isinstance(val, Module):
+                    out += val.named_modules(path)
+                elif isinstance(val, (list, tuple)):
+                    for i, v in enumerate(val):
+                        if isinstance(v, Module):
+                            out += v.named_modules(f"{path}.{i}")
+            return out
+
+        def parameters(self):
+            """flat {dotted name: array} of every array attribute in the module tree (tree_flatten of MLX's nested dict)"""
+            out = {}
+            for path, mod in self.named_modules():
+                for name, val in vars(mod).items():
+                    if not name.startswith("_") and isinstance(val, np.ndarray):
+                        out[f"{path}.{name}" if path else name] = val
+            return out
 
         def load_weights(self, weights, strict=True):
             items = weights.items() if isinstance(weights, dict) else weights
@@ -336,7 +368,51 @@ def _build_nn(mx) -> types.ModuleType:
     nn.losses = losses
     for cls in (Module, Linear, Embedding, LayerNorm, RMSNorm, Conv1d, Sequential, GELU, SiLU, Mish, Softplus, Dropout):
         setattr(nn, cls.__name__, cls)
-    nn.quantize = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("nn.quantize is not emulated"))
+
+    class QuantizedLinear(Module):
+        """Parameter SHAPES of mlx.nn.QuantizedLinear (MLX documentation of `mx.quantize`: uint32 words holding 32 / bits
+        elements each along the input axis, one scale and one bias per group of `group_size` input elements); the packed matmul
+        itself is not emulated -- the loader tests only need the tree that `load_weights(strict)` validates against."""
+
+        def __init__(self, input_dims, output_dims, bias=True, group_size=64, bits=4):
+            super().__init__()
+            self.group_size, self.bits = group_size, bits
+            self.weight = _wrap(np.zeros((output_dims, input_dims * bits // 32), np.uint32))
+            self.scales = mx.zeros((output_dims, input_dims // group_size))
+            self.biases = mx.zeros((output_dims, input_dims // group_size))
+            if bias:
+                self.bias = mx.zeros((output_dims,))
+
+        def __call__(self, x):
+            raise NotImplementedError("QuantizedLinear matmul is not emulated")
+
+    def quantize(model, group_size=64, bits=4, class_predicate=None):
+        """nn.quantize: replace, in place, every leaf module for which class_predicate(path, module) holds (default: modules
+        with a `to_quantized` method, i.e. Linear and Embedding) by its quantised counterpart (cfm.py:510-515)."""
+        pred = class_predicate or (lambda p, m: isinstance(m, (Linear, Embedding)))
+        replaced = []
+        for path, mod in model.named_modules():
+            for name, val in list(vars(mod).items()):
+                if name.startswith("_"):
+                    continue
+                sub = f"{path}.{name}" if path else name
+                def swap(m, where):
+                    if isinstance(m, Linear) and pred(where, m):
+                        out_d, in_d = m.weight.shape
+                        replaced.append(where)
+                        return QuantizedLinear(in_d, out_d, bias=hasattr(m, "bias"), group_size=group_size, bits=bits)
+                    return m
+                if isinstance(val, Module):
+                    setattr(mod, name, swap(val, sub))
+                elif isinstance(val, list):
+                    for i, v in enumerate(val):
+                        if isinstance(v, Module):
+                            val[i] = swap(v, f"{sub}.{i}")
+        model._quantized_paths = replaced
+        return model
+
+    nn.QuantizedLinear = QuantizedLinear
+    nn.quantize = quantize
     return nn
 
 

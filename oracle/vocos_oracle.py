@@ -15,10 +15,15 @@ import torch
 import torch.nn.functional as F
 
 
-def decode(weights: Dict[str, np.ndarray], mel: torch.Tensor, dtype=torch.float64, emulate_bf16: bool = False) -> torch.Tensor:
-    """mel (b, n, 100) -> wave (b, 256 * (n - 1))."""
+def decode(weights: Dict[str, np.ndarray], mel: torch.Tensor, dtype=torch.float64, emulate_bf16: bool = False,
+           emulate_f16: bool = False) -> torch.Tensor:
+    """mel (b, n, 100) -> wave (b, 256 * (n - 1)).  emulate_*: GEMM operands rounded like the engine's bf16 / f16 modes."""
     w = {k: torch.from_numpy(np.asarray(v)).to(dtype) for k, v in weights.items()}
-    r = (lambda t: t.to(torch.bfloat16).to(dtype)) if emulate_bf16 else (lambda t: t)
+    r = (lambda t: t)
+    if emulate_bf16:
+        r = lambda t: t.to(torch.bfloat16).to(dtype)
+    if emulate_f16:
+        r = lambda t: t.clamp(-65504.0, 65504.0).to(torch.float16).to(dtype)
     x = mel.to(dtype).transpose(1, 2)                                                     # (b, 100, n)
     x = F.conv1d(r(x), r(w["backbone.embed.weight"]), w["backbone.embed.bias"], padding=3)
     x = F.layer_norm(x.transpose(1, 2), (x.shape[1],), w["backbone.norm.weight"], w["backbone.norm.bias"], 1e-6)

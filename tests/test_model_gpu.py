@@ -221,6 +221,37 @@ def test_graph_cache_is_bounded_and_auto_mode(tiny_weights):
     assert torch.equal(f5.sample(cond, text, use_graph="auto", **kw)[0], want)                                     # replayed
 
 
+def test_c_abi_weight_broadcast_over_rccl(tiny_weights):
+    """f5_broadcast_weights: the contiguous arena goes through ONE ncclBroadcast on a caller-owned RCCL communicator (here a
+    1-rank communicator created with ctypes on librccl, the way a non-Python host would own one); the receiving engine is
+    marked loaded.  The N-rank protocol itself is covered on CPU by tests/test_dist.py (gloo)."""
+    import ctypes as C
+    rccl = C.CDLL("librccl.so.1")
+    uid = (C.c_char * 128)()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char * 128, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        m = _model(TINY, tiny_weights, "f16")
+        before = m.engine.arena.clone()
+        lib = E.load_library()
+        E.check(lib.f5_broadcast_weights(m.engine._h, comm, 0, 0, E.stream_ptr(torch.device(DEV))), "f5_broadcast_weights")
+        torch.cuda.synchronize()
+        assert torch.equal(m.engine.arena, before)                      # root keeps its bytes
+        # a second engine that never saw f5_load_tensor: copy the arena (what a broadcast delivers), mark through the C call
+        m2 = DiT.from_config(TINY, precision="f16", device=DEV)
+        m2.engine.arena.copy_(m.engine.arena)
+        E.check(lib.f5_broadcast_weights(m2.engine._h, comm, 0, 1, E.stream_ptr(torch.device(DEV))), "f5_broadcast_weights")
+        torch.cuda.synchronize()
+        m2.engine.finalize()                                            # would raise "never loaded" without the mark
+        cond, text, durations, y0 = synth_inputs(TINY, 1, 48, nt=10, n_ref=12, seed=2)
+        kw = dict(duration=48, steps=3, method="euler", y0=y0)
+        assert torch.equal(F5TTS(transformer=m).sample(cond, text, **kw)[0], F5TTS(transformer=m2).sample(cond, text, **kw)[0])
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
 def test_sample_no_cfg_and_errors(tiny_bf16, tiny_weights):
     cfg = TINY
     cond, text, durations, y0 = synth_inputs(cfg, 1, 64, nt=12, n_ref=16, seed=8)
@@ -293,14 +324,16 @@ def test_istft_op_matches_torch_istft():
 
 @pytest.mark.parametrize("B,N", [(1, 60), (2, 131)])
 def test_vocos_decode_parity(B, N):
+    """f5_vocode (one C-ABI call, hipGraph) vs the CPU restatement of the published Vocos architecture: fp32-class in bf16x3,
+    and in the one-pass modes against the oracle with the same operand rounding."""
     from oracle import vocos_oracle as VO
     from f5_tts_mlx_amd.vocos import Vocos, synthetic_vocos_weights
     w = synthetic_vocos_weights(seed=7)
     r = np.random.default_rng(N)
     mel = torch.from_numpy((r.standard_normal((B, N, 100)) * 2.0 - 1.0).astype(np.float32))
     ref = VO.decode(w, mel, dtype=torch.float64)
-    ref_emu = VO.decode(w, mel, dtype=torch.float64, emulate_bf16=True)
-    for prec, want, tol in (("bf16x3", ref, 2e-4), ("bf16", ref_emu, 2e-3)):
+    for prec, want, tol in (("bf16x3", ref, 2e-4), ("bf16", VO.decode(w, mel, dtype=torch.float64, emulate_bf16=True), 2e-3),
+                            ("f16", VO.decode(w, mel, dtype=torch.float64, emulate_f16=True), 5e-4)):
         v = Vocos(w, precision=prec, device=DEV)
         wave = v.decode(mel)
         torch.cuda.synchronize()
@@ -308,6 +341,71 @@ def test_vocos_decode_parity(B, N):
         assert wave.shape == (B, 256 * (N - 1))
         mx, mean, refm = report(f"vocos decode [{prec}] B{B} N{N}", wave.cpu(), want)
         assert mean <= tol * max(1e-3, refm) + 1e-6 and torch.isfinite(wave).all()
+        if prec == "f16":
+            _, mean32, _ = report(f"vocos decode [f16] B{B} N{N} vs fp64 oracle", wave.cpu(), ref)
+            assert mean32 <= 2e-3 * max(1e-3, refm)
+
+
+def test_vocoder_c_abi_graph_batch_and_layouts():
+    """f5_vocode: a replayed graph equals the eager run bit for bit; a batch equals its utterances decoded one at a time (the
+    ISTFT of the whole batch is two launches); MLX-layout conv weights (out, k, in) load to the same model as PyTorch-layout
+    ones; unknown / missing tensors are refused."""
+    from f5_tts_mlx_amd.vocos import Vocos, synthetic_vocos_weights
+    w = synthetic_vocos_weights(seed=7)
+    r = np.random.default_rng(1)
+    mel = torch.from_numpy((r.standard_normal((3, 77, 100)) * 2.0 - 1.0).astype(np.float32)).to(DEV)
+    vg = Vocos(w, precision="f16", device=DEV, use_graph=True)
+    ve = Vocos(w, precision="f16", device=DEV, use_graph=False)
+    a, b, c = vg.decode(mel), vg.decode(mel), ve.decode(mel)
+    torch.cuda.synchronize()
+    assert a.shape == (3, 256 * 76) and torch.equal(a, b) and torch.equal(a, c)
+    for i in range(3):
+        one = ve.decode(mel[i:i + 1])
+        assert one.ndim == 1 and torch.equal(one, a[i])
+    w_mlx = dict(w)
+    w_mlx["backbone.embed.weight"] = np.ascontiguousarray(np.transpose(w["backbone.embed.weight"], (0, 2, 1)))       # (out, k, in)
+    for i in range(8):
+        k = f"backbone.convnext.{i}.dwconv.weight"
+        w_mlx[k] = np.ascontiguousarray(np.transpose(w[k], (0, 2, 1)))                                             # (dim, 7, 1)
+    w_mlx["feature_extractor.mel_spec.spectrogram.window"] = np.zeros(1024, np.float32)                               # ignored buffer
+    assert torch.equal(Vocos(w_mlx, precision="f16", device=DEV).decode(mel), a)
+    bad = dict(w)
+    bad.pop("head.out.bias")
+    with pytest.raises(ValueError, match="missing vocoder parameter"):
+        Vocos(bad, device=DEV)
+    bad = dict(w)
+    bad["backbone.convnext.0.extra"] = np.zeros(4, np.float32)
+    with pytest.raises(ValueError, match="unexpected vocoder parameter"):
+        Vocos(bad, device=DEV)
+    bad = dict(w)
+    bad["head.out.weight"] = np.zeros((1026, 511), np.float32)
+    with pytest.raises(RuntimeError, match="shape"):
+        Vocos(bad, device=DEV)
+
+
+def test_mel_front_end_batched_launch_equals_per_utterance():
+    """f5_mel_spectrogram_batch: one launch for (B, L) equals B single launches bit for bit."""
+    from f5_tts_mlx_amd.audio import log_mel_spectrogram
+    r = np.random.default_rng(9)
+    waves = torch.from_numpy((r.standard_normal((4, 256 * 33 + 17)) * 0.1).astype(np.float32)).to(DEV)
+    batch = log_mel_spectrogram(waves)
+    torch.cuda.synchronize()
+    assert batch.shape == (4, 33, 100)
+    for i in range(4):
+        assert torch.equal(log_mel_spectrogram(waves[i])[0], batch[i])
+    y = torch.from_numpy(r.standard_normal((3 * 21, 1026)).astype(np.float32)).to(DEV)
+    lib = E.load_library()
+    win = torch.hann_window(1024, device=DEV)
+    frames = torch.empty((3 * 21, 1024), device=DEV)
+    wave = torch.empty((3, 256 * 20), device=DEV)
+    st = E.stream_ptr(torch.device(DEV))
+    E.check(lib.f5_op_istft_batch(E.ptr(y), 1026, E.ptr(win), E.ptr(frames), E.ptr(wave), 3, 21, 1024, 256, st))
+    one = torch.empty(256 * 20, device=DEV)
+    fr1 = torch.empty((21, 1024), device=DEV)
+    for i in range(3):
+        E.check(lib.f5_op_istft(E.ptr(y[i * 21:(i + 1) * 21]), 1026, E.ptr(win), E.ptr(fr1), E.ptr(one), 21, 1024, 256, st))
+        torch.cuda.synchronize()
+        assert torch.equal(one, wave[i])
 
 
 def test_sample_with_vocoder_and_raw_wave(tiny_x3, tiny_weights):
@@ -553,7 +651,8 @@ def test_from_pretrained_local_checkpoints(tmp_path):
     assert f5._duration_predictor is not None and f5._vocoder is not None
     got = run(f5)
     assert got.ndim == 1 and got.shape[0] == 256 * 149 and torch.isfinite(got).all()
-    direct = DiT.from_config(cfg, precision="bf16", device=DEV)
+    assert f5.transformer.precision == "f16"                                      # the package default is the parity-valid mode
+    direct = DiT.from_config(cfg, precision="f16", device=DEV)
     direct.load_weights({k: v.astype(np.float32) for k, v in w.items()})
     ref = run(F5TTS(transformer=direct, vocab_char_map=vocab, vocoder=f5._vocoder))
     assert torch.equal(got, ref)
@@ -563,14 +662,17 @@ def test_from_pretrained_local_checkpoints(tmp_path):
 
     f8 = F5TTS.from_pretrained(str(mdir), quantization_bits=8, vocoder_name_or_path=str(vdir), device=str(DEV))
     got8 = run(f8)
-    deq = DiT.from_config(cfg, precision="bf16", device=DEV)
+    deq = DiT.from_config(cfg, precision="f16", device=DEV)
     deq.load_weights({k: np.asarray(v, np.float32) for k, v in dequantize_mlx_checkpoint(q, 8).items()})
     ref8 = run(F5TTS(transformer=deq, vocab_char_map=vocab, vocoder=f8._vocoder))
     assert torch.equal(got8, ref8)
     rel = float((got8 - got).abs().mean() / got.abs().mean())
     print(f"8-bit checkpoint vs full precision: relative wave L1 {rel:.3e}")
     assert rel < 0.5
-    # no vocoder anywhere -> model still loads, sample returns mel frames (documented difference)
+    # a vocoder that cannot be found raises like the reference's Vocos.from_pretrained (no network here) ...
+    with pytest.raises(RuntimeError, match="vocoder"):
+        F5TTS.from_pretrained(str(mdir), convert_weights=False, vocoder_name_or_path="no-such-org/no-such-vocos", device=str(DEV))
+    # ... unless the caller opts out: the model loads and sample returns mel frames (documented difference)
     fm = F5TTS.from_pretrained(str(mdir), convert_weights=False, vocoder_name_or_path=None, device=str(DEV))
     mel, _ = fm.sample(wave, text=text, duration=150, steps=2, method="euler", seed=1)
     assert tuple(mel.shape) == (1, 150, 100)

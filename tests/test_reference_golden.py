@@ -281,3 +281,134 @@ print('LIVE-OK worst', worst)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert "LIVE-OK" in r.stdout, (r.stdout[-800:], r.stderr[-3000:])
     print(r.stdout.strip().splitlines()[-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint conversion / quantisation predicate pinned against the reference's own from_pretrained (cfm.py:404-520)
+# ------------------------------------------------------------------------------------------------
+_UPSTREAM_RENAMES = (                      # MLX-tree name fragment -> upstream (PyTorch F5-TTS) fragment, SURVEY Appendix B
+    (".to_out.layers.", ".to_out."), (".text_blocks.layers.", ".text_blocks."), (".ff.ff.layers.0.layers.0.", ".ff.ff.0.0."),
+    (".ff.ff.layers.2.", ".ff.ff.2."), (".time_mlp.layers.", ".time_mlp."), (".conv1d.layers.", ".conv1d."))
+
+
+def _upstream_checkpoint(weights):
+    """An upstream-style (PyTorch F5-TTS) state dict holding `weights` (MLX-tree names / layouts): `ema_model.` prefix, PyTorch
+    module numbering, conv weights (out, in/groups, k), plus the non-parameter entries a real checkpoint carries."""
+    out = {}
+    for k, v in weights.items():
+        for mlx_frag, up_frag in _UPSTREAM_RENAMES:
+            if mlx_frag in k:
+                k = k.replace(mlx_frag, up_frag)
+                break
+        if k.endswith(".dwconv.weight") or ".conv1d." in k and k.endswith(".weight"):
+            v = np.ascontiguousarray(np.swapaxes(v, 1, 2))
+        out["ema_model." + k] = v
+    out["ema_model.mel_spec.mel_stft.spectrogram.window"] = np.zeros(1024, np.float32)
+    out["ema_model.mel_spec.mel_stft.mel_scale.fb"] = np.zeros((513, 100), np.float32)
+    out["initted"] = np.ones((), np.float32)
+    out["step"] = np.array(1200000, np.int64)
+    return out
+
+
+_LIVE_FROM_PRETRAINED = r"""
+import json, sys, numpy as np
+from pathlib import Path
+sys.path.insert(0, %(root)r); sys.path.insert(0, '/root/reference')
+from oracle import mlx_shim; mx, nn = mlx_shim.install()
+class _Vocos:                                   # vocos_mlx is a third-party package: stub (cfm.py:446)
+    @classmethod
+    def from_pretrained(cls, name): return cls()
+    def decode(self, mel): return mel
+sys.modules['vocos_mlx'].Vocos = _Vocos
+import f5_tts_mlx.cfm as RC
+RC.fetch_from_hub = lambda p, quantization_bits=None: Path(p)      # no network: the "hub" is a local directory
+depth = %(depth)d
+if depth != 22:                                 # from_pretrained hard-codes the 335M tree (cfm.py:459-469); a shallower tree exercises
+    _DiT = RC.DiT                               # the same per-key code in a fraction of the time (F5_FULL_DEPTH=1 runs all 22 blocks)
+    RC.DiT = lambda **kw: _DiT(**dict(kw, depth=depth))
+from safetensors.numpy import load_file
+from f5_tts_mlx_amd.weights import convert_upstream_weights, dequantize_mlx_checkpoint
+d = %(dir)r
+# ---- full precision, convert_weights=True (the default): cfm.py:477-508
+m = RC.F5TTS.from_pretrained(d)
+ref = {k: np.asarray(v) for k, v in m.parameters().items()}
+ours = convert_upstream_weights(load_file(d + '/model_v1.safetensors'))
+assert set(ref) == set(ours), (sorted(set(ref) - set(ours))[:5], sorted(set(ours) - set(ref))[:5])
+for k in ref:
+    assert ref[k].shape == ours[k].shape and ref[k].dtype == ours[k].dtype and np.array_equal(ref[k], ours[k]), k
+keymap = {k: list(v.shape) for k, v in sorted(ours.items())}
+# ---- 8-bit file: nn.quantize's predicate decides which modules expect (weight uint32, scales, biases); cfm.py:510-515
+q = RC.F5TTS.from_pretrained(d, quantization_bits=8)
+qpaths = sorted(q._quantized_paths)
+qfile = load_file(d + '/model_v1_8b.safetensors')
+ours_q = sorted(k[:-7] for k in qfile if k.endswith('.scales'))
+assert qpaths == ours_q, (qpaths[:3], ours_q[:3], len(qpaths), len(ours_q))
+qref = {k: np.asarray(v) for k, v in q.parameters().items()}
+assert set(qref) == set(qfile) and all(np.array_equal(qref[k], qfile[k]) for k in qfile)
+deq = dequantize_mlx_checkpoint(qfile, 8)
+assert set(deq) == set(ours) and all(deq[k].shape == ours[k].shape for k in ours)
+json.dump(dict(keymap=keymap, quantized=qpaths), open(d + '/result.json', 'w'))
+print('LIVE-OK', len(ref), len(qpaths))
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/f5_tts_mlx"), reason="reference checkout not present (GPU box)")
+def test_checkpoint_conversion_matches_reference_from_pretrained_live(tmp_path):
+    """The reference's own `F5TTS.from_pretrained` (unmodified, over the mlx emulation; hub access and the third-party vocoder
+    stubbed) loads a synthetic UPSTREAM-named 335M checkpoint directory: its key renames / axis swaps (cfm.py:477-508) and the
+    strict load into the reference's module tree define the truth; `weights.convert_upstream_weights` must yield the same
+    names and arrays bit for bit.  Then the 8-bit path: `nn.quantize` with the reference's predicate (cfm.py:510-515) decides
+    which Linears expect packed weights; a file written with the package's rule must load strictly, and the two module sets
+    must be equal.  The resulting name -> shape map is compared with the committed tests/golden/ref_checkpoint_keymap.json."""
+    import dataclasses
+    import subprocess
+    import sys
+    from safetensors.numpy import save_file
+    from f5_tts_mlx_amd.weights import F5TTS_335M, quantize_mlx_affine
+    vocab_text = open(os.path.join(ROOT, "f5_tts_mlx_amd", "assets", "vocab.txt")).read()
+    nvocab = len(vocab_text.split("\n"))
+    depth = 22 if os.environ.get("F5_FULL_DEPTH") == "1" else 2
+    cfg = dataclasses.replace(F5TTS_335M, text_num_embeds=nvocab - 1, depth=depth)
+    w = synthetic_weights(cfg, seed=9)
+    w["transformer.rotary_embed.inv_freq"] = (1.0 / (10000 ** (np.arange(0, 64, 2, dtype=np.float32) / 64))).astype(np.float32)
+    up = _upstream_checkpoint(w)
+    (tmp_path / "vocab.txt").write_text(vocab_text)
+    save_file(up, str(tmp_path / "model_v1.safetensors"))
+    q = {}
+    for k, v in w.items():          # the package's rule for an MLX 8-bit file: Linear weights whose input width is a multiple of 64
+        if k.endswith(".weight") and v.ndim == 2 and v.shape[1] % 64 == 0 and "text_embed.text_embed" not in k:
+            pk, sc, bi = quantize_mlx_affine(v, 8)
+            q[k], q[k[:-7] + ".scales"], q[k[:-7] + ".biases"] = pk, sc, bi
+        else:
+            q[k] = v
+    save_file(q, str(tmp_path / "model_v1_8b.safetensors"))
+    del up, q
+    r = subprocess.run([sys.executable, "-c", _LIVE_FROM_PRETRAINED % dict(root=ROOT, dir=str(tmp_path), depth=depth)],
+                       capture_output=True, text=True, timeout=1800)
+    assert "LIVE-OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    got = json.load(open(tmp_path / "result.json"))
+    want = json.load(open(os.path.join(GOLDEN, "ref_checkpoint_keymap.json")))      # written from a full-depth (22 blocks) run
+    if depth != 22:
+        keep = lambda k: ".transformer_blocks." not in k or int(k.split(".transformer_blocks.")[1].split(".")[0]) < depth
+        want = dict(keymap={k: v for k, v in want["keymap"].items() if keep(k)}, quantized=[k for k in want["quantized"] if keep(k)])
+    assert got == want, "tests/golden/ref_checkpoint_keymap.json is stale: regenerate it with F5_FULL_DEPTH=1 from result.json"
+
+
+def test_checkpoint_conversion_matches_committed_reference_keymap():
+    """Without the reference checkout (GPU box): `convert_upstream_weights` maps an upstream-named state dict onto exactly the
+    parameter names / shapes the reference's from_pretrained produced (tests/golden/ref_checkpoint_keymap.json, written by the
+    live test above), and the package's 8-bit rule selects exactly the modules the reference's `nn.quantize` predicate did."""
+    import dataclasses
+    from f5_tts_mlx_amd.weights import F5TTS_335M, convert_upstream_weights, param_specs
+    want = json.load(open(os.path.join(GOLDEN, "ref_checkpoint_keymap.json")))
+    nvocab = want["keymap"]["transformer.text_embed.text_embed.weight"][0]
+    cfg = dataclasses.replace(F5TTS_335M, text_num_embeds=nvocab - 1)
+    shapes = {n: tuple(s) for n, s, _ in param_specs(cfg)}
+    shapes["transformer.rotary_embed.inv_freq"] = (32,)
+    up = _upstream_checkpoint({k: np.zeros(s, np.float32) for k, s in shapes.items()})     # zero-filled: names / layouts only
+    ours = convert_upstream_weights(up)
+    assert {k: list(v.shape) for k, v in sorted(ours.items())} == want["keymap"]
+    rule = sorted(k[:-7] for k, s in shapes.items() if k.endswith(".weight") and len(s) == 2 and s[1] % 64 == 0
+                  and "text_embed.text_embed" not in k)
+    assert rule == want["quantized"]
+    assert "transformer.input_embed.proj" not in rule and "transformer.proj_out" in rule          # 712 % 64 != 0; 1024 % 64 == 0
