@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float p0 = s[kb][8 * sp + 2 * e], p1 = s[kb][8 * sp + 2 * e + 1];
-                pw[e] = f5_pack2(p0, p1);
+                pw[e] = f5_pack2_bounded(p0, p1);
                 if (HP) pwl[e] = f5_pack2_lo(p0, p1);
             }
             const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
                 const float v0 = o[db][rg * 4 + 0] * inv, v1 = o[db][rg * 4 + 1] * inv;
                 const float v2 = o[db][rg * 4 + 2] * inv, v3 = o[db][rg * 4 + 3] * inv;
                 const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
-                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2_bounded(v0, v1), f5_pack2_bounded(v2, v3)};
                 if (HP && p.out[1])
                     *reinterpret_cast<u32x2*>(p.out[1] + off) = u32x2{f5_pack2_lo(v0, v1), f5_pack2_lo(v2, v3)};
             }
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float p0 = s[kb][8 * sp + 2 * e], p1 = s[kb][8 * sp + 2 * e + 1];
-                pw[e] = f5_pack2(p0, p1);
+                pw[e] = f5_pack2_bounded(p0, p1);
                 if (HP) pwl[e] = f5_pack2_lo(p0, p1);
             }
             const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
                 const float v0 = o[db][rg * 4 + 0] * inv, v1 = o[db][rg * 4 + 1] * inv;
                 const float v2 = o[db][rg * 4 + 2] * inv, v3 = o[db][rg * 4 + 3] * inv;
                 const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
-                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2_bounded(v0, v1), f5_pack2_bounded(v2, v3)};
                 if (HP && p.out[1])
                     *reinterpret_cast<u32x2*>(p.out[1] + off) = u32x2{f5_pack2_lo(v0, v1), f5_pack2_lo(v2, v3)};
             }
@@ -515,6 +515,11 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 // two query blocks against each other with sched_group_barrier (S(q1) under softmax(q0), PV(q0) under softmax(q1)) measured
 // 515 TF (spills at 256 VGPRs, re-read fragments) and was dropped, like the in-wave pipelining of v3 / v4.
 // =================================================================================================
+// PRIO: which phase of a wave gets issue priority on its SIMD (two waves of DIFFERENT workgroups share a SIMD and drift in
+// phase): 0 = the MFMA clusters (s_setprio 1 around them), 1 = no priority changes, 2 = the softmax VALU section (the wave
+// sits at priority 1 and drops to 0 for its MFMA clusters, so a partner's transcendentals / VALU issue in the gaps of this
+// wave's MFMAs instead of queueing behind them)
+template <int PRIO>
 __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
     constexpr int NST = 3;
     constexpr int TILE = 64 * 64;
@@ -602,7 +607,8 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
         const op16_t* sV = sK + TILE;
 
         f32x16 s[2][2];                                   // [query block][key block]
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 0) __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -616,7 +622,8 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
                 s[1][kb] = F5_MFMA32(a, qf[1][ks], s[1][kb], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 0) __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 
         const int key0 = j * 64;
         if (key0 + 64 > kvlen) {
@@ -664,17 +671,19 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
             for (int qb = 0; qb < 2; ++qb) {
                 uint32_t pw[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pw[e] = f5_pack2(s[qb][kb][8 * sp + 2 * e], s[qb][kb][8 * sp + 2 * e + 1]);
+                for (int e = 0; e < 4; ++e) pw[e] = f5_pack2_bounded(s[qb][kb][8 * sp + 2 * e], s[qb][kb][8 * sp + 2 * e + 1]);
                 pb[qb] = __builtin_bit_cast(op16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
             }
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO == 0) __builtin_amdgcn_s_setprio(1);
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const op16x8 a = *reinterpret_cast<const op16x8*>(&sV[attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp)]);
                 o[0][db] = F5_MFMA32(a, pb[0], o[0][db], 0, 0, 0);
                 o[1][db] = F5_MFMA32(a, pb[1], o[1][db], 0, 0, 0);
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO == 0) __builtin_amdgcn_s_setprio(0);
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
         }
     }
 #undef A2W_ISSUE
@@ -695,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
                     const float v0 = o[qb][db][rg * 4 + 0] * inv, v1 = o[qb][db][rg * 4 + 1] * inv;
                     const float v2 = o[qb][db][rg * 4 + 2] * inv, v3 = o[qb][db][rg * 4 + 3] * inv;
                     const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
-                    *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+                    *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2_bounded(v0, v1), f5_pack2_bounded(v2, v3)};
                 }
         }
     }
@@ -874,7 +883,7 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float p0 = s[kb][8 * sp + 2 * e], p1 = s[kb][8 * sp + 2 * e + 1];
-                pw[e] = f5_pack2(p0, p1);
+                pw[e] = f5_pack2_bounded(p0, p1);
                 if (HP) pwl[e] = f5_pack2_lo(p0, p1);
             }
             const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
@@ -948,7 +957,7 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
                 const float v0 = o[db][rg * 4 + 0] * inv, v1 = o[db][rg * 4 + 1] * inv;
                 const float v2 = o[db][rg * 4 + 2] * inv, v3 = o[db][rg * 4 + 3] * inv;
                 const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
-                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2_bounded(v0, v1), f5_pack2_bounded(v2, v3)};
                 if (HP && p.out[1])
                     *reinterpret_cast<u32x2*>(p.out[1] + off) = u32x2{f5_pack2_lo(v0, v1), f5_pack2_lo(v2, v3)};
             }
@@ -1103,7 +1112,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
                 const float p0_ = __builtin_amdgcn_exp2f(cur_[kb][r] * c2 - mc_);                            \
                 const float p1_ = __builtin_amdgcn_exp2f(cur_[kb][r + 1] * c2 - mc_);                        \
                 psum_ += p0_ + p1_;                                                                          \
-                pw_[kb][r >> 1] = f5_pack2(p0_, p1_);                                                        \
+                pw_[kb][r >> 1] = f5_pack2_bounded(p0_, p1_);                                                        \
             }                                                                                                \
         l_run += psum_;                                                                                      \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                      \
@@ -1140,7 +1149,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
                 const float v0 = o[db][rg * 4 + 0] * inv, v1 = o[db][rg * 4 + 1] * inv;
                 const float v2 = o[db][rg * 4 + 2] * inv, v3 = o[db][rg * 4 + 3] * inv;
                 const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
-                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2(v0, v1), f5_pack2(v2, v3)};
+                *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2_bounded(v0, v1), f5_pack2_bounded(v2, v3)};
             }
     }
 }
@@ -1148,6 +1157,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
 int f5_attn_version = 2;   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower)
 int f5_attn_ablation = 0;  // timing experiments only
 int f5_attn_wide = -1;     // -1 auto (>= 1024 workgroups), 0 off, 1 force: 256-query workgroups, two query blocks per wave (bf16)
+int f5_attn_prio = 0;      // wide kernel: which phase holds issue priority (0 MFMA clusters, 1 none, 2 softmax section)
 int f5_attn_kvsplit = -1;  // -1 auto, 1 / 2 / 4 = force the in-workgroup KV split (debug hook)
 
 int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
@@ -1170,7 +1180,10 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     // large grids (bf16): two query blocks per wave (256 queries per workgroup)
     if (f5_attn_version == 2 && f5_attn_ablation == 0 && !a.hp && ks <= 1 &&
         (f5_attn_wide >= 1 || (f5_attn_wide < 0 && (long)f5_cdiv(a.seq_len, 256) * grid.y >= 512))) {
-        hipLaunchKernelGGL(f5_attn2w_kernel, dim3(f5_cdiv(a.seq_len, 256), a.B * a.H), dim3(256), 0, stream, a);
+        const dim3 gw(f5_cdiv(a.seq_len, 256), a.B * a.H);
+        if (f5_attn_prio == 1) hipLaunchKernelGGL(f5_attn2w_kernel<1>, gw, dim3(256), 0, stream, a);
+        else if (f5_attn_prio == 2) hipLaunchKernelGGL(f5_attn2w_kernel<2>, gw, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(f5_attn2w_kernel<0>, gw, dim3(256), 0, stream, a);
         F5_LAUNCH_CHECK();
         return 0;
     }

@@ -47,6 +47,7 @@ struct TextBlockW {
 
 struct Workspace {
     size_t total = 0;
+    size_t scal, scal_words;   // per-call host scalars, contiguous: [lens B | dur2 2B | tgrid nfe | dt steps | cfg 1] (32-bit words)
     size_t lens, dur2, text, ids, keep, rowkeep;
     size_t tgrid, dt, cfgv, sinus, th, temb, mod;
     size_t rope_cos, rope_sin;
@@ -386,15 +387,18 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
     const int npad = (N + 63) / 64 * 64;
     Bump b;
     Workspace w;
-    w.lens = b.take((size_t)B * 4);
-    w.dur2 = b.take((size_t)2 * B * 4);
+    const size_t nfe1 = (size_t)(nfe > 0 ? nfe : 1);
+    w.scal_words = (size_t)3 * B + nfe1 + steps + 1;
+    w.scal = b.take(w.scal_words * 4);
+    w.lens = w.scal;
+    w.dur2 = w.lens + (size_t)B * 4;
+    w.tgrid = w.dur2 + (size_t)2 * B * 4;
+    w.dt = w.tgrid + nfe1 * 4;
+    w.cfgv = w.dt + (size_t)steps * 4;
     w.text = b.take((size_t)B * (nt > 0 ? nt : 1) * 4);
     w.ids = b.take(M2 * 4);
     w.keep = b.take(M2);
     w.rowkeep = b.take(M2);
-    w.tgrid = b.take((size_t)(nfe > 0 ? nfe : 1) * 4);
-    w.dt = b.take((size_t)steps * 4);
-    w.cfgv = b.take(4);
     w.sinus = b.take((size_t)(nfe + 1) * c.freq_embed_dim * 4);
     w.th = b.take((size_t)(nfe + 1) * D * 4);
     w.temb = b.take((size_t)(nfe + 1) * D * 4);
@@ -516,7 +520,7 @@ static int run_prep(const Ctx& c, int nfe) {
     }
     RC(f5_launch_rope_table(c.p<float>(w.rope_cos), c.p<float>(w.rope_sin), c.N, cf.dim_head, s));
     RC(f5_launch_rowkeep(c.p<int>(w.dur2), c.p<uint8_t>(w.rowkeep), 2 * c.B, c.N, s));
-    for (int p = 0; p < e->np; ++p) F5_HIP_CHECK(hipMemsetAsync(c.ws + w.vt[p], 0, w.vt_bytes, s));
+    for (int p = 0; p < e->np; ++p) RC(K.zero_vt_pad(c.pb(w.vt, p), (size_t)2 * c.B * cf.heads * 64, c.N, c.npad, s));
 
     // --- text path for both branches (dit.py:196-229, convnext_v2.py:46-54)
     RC(f5_launch_text_embed(c.p<int>(w.text), c.nt, c.a<float>(e->text_table), c.a<float>(e->text_pos), cf.text_max_pos,
@@ -841,19 +845,22 @@ static int stage_inputs(Ctx& c, const f5_sample_args* a, const float* x_override
     const size_t M1 = (size_t)c.B * c.N;
     const int mel = c.e->cfg.mel_dim;
     hipStream_t s = c.s;
-    std::vector<int> dur2(2 * c.B);
-    for (int b = 0; b < c.B; ++b) dur2[b] = dur2[c.B + b] = a->durations[b];
-    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.lens, a->lens, (size_t)c.B * 4, hipMemcpyHostToDevice, s));
-    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.dur2, dur2.data(), (size_t)2 * c.B * 4, hipMemcpyHostToDevice, s));
-    if (!tnfe.empty()) F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.tgrid, tnfe.data(), tnfe.size() * 4, hipMemcpyHostToDevice, s));
-    if (!dts.empty()) F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.dt, dts.data(), dts.size() * 4, hipMemcpyHostToDevice, s));
-    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.cfgv, &a->cfg_strength, 4, hipMemcpyHostToDevice, s));
-    F5_HIP_CHECK(hipStreamSynchronize(s));  // host staging vectors die at scope exit
-    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.text, a->text, (size_t)c.B * c.nt * 4, hipMemcpyDeviceToDevice, s));
-    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.cond, a->cond, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
+    // host scalars -> workspace as kernel arguments (no host buffer outlives this call, no host synchronisation)
+    const size_t nfe1 = tnfe.empty() ? 1 : tnfe.size();
+    std::vector<uint32_t> words(w.scal_words, 0u);
+    F5_REQUIRE(w.scal_words == (size_t)3 * c.B + nfe1 + a->steps + 1 && dts.size() <= (size_t)a->steps, "internal: scalar staging layout");
+    memcpy(words.data(), a->lens, (size_t)c.B * 4);
+    for (int b = 0; b < c.B; ++b) words[c.B + b] = words[2 * c.B + b] = (uint32_t)a->durations[b];
+    if (!tnfe.empty()) memcpy(words.data() + 3 * c.B, tnfe.data(), tnfe.size() * 4);
+    if (!dts.empty()) memcpy(words.data() + 3 * c.B + nfe1, dts.data(), dts.size() * 4);
+    memcpy(words.data() + 3 * c.B + nfe1 + a->steps, &a->cfg_strength, 4);
+    RC(f5_launch_stage_words(words.data(), words.size(), c.p<uint32_t>(w.scal), s));
+    // caller-owned device inputs -> workspace (the captured graph only references the workspace and the arena)
+    RC(f5_launch_copy_words(a->text, c.ws + w.text, (size_t)c.B * c.nt, s));
+    RC(f5_launch_copy_words(a->cond, c.ws + w.cond, M1 * mel, s));
     const float* x0 = x_override ? x_override : a->y0;
     F5_REQUIRE(x0 != nullptr, "initial state (y0) is null");
-    F5_HIP_CHECK(hipMemcpyAsync(c.ws + w.traj, x0, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
+    RC(f5_launch_copy_words(x0, c.ws + w.traj, M1 * mel, s));
     return 0;
 }
 
@@ -964,8 +971,7 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     }
     const float* ylast = c.p<float>(c.w.traj) + (size_t)(a->steps - 1) * M1 * mel;
     RC(f5_launch_splice(c.p<float>(c.w.cond), ylast, c.p<int>(c.w.lens), a->out, c.B, c.N, mel, s));
-    if (a->trajectory)
-        F5_HIP_CHECK(hipMemcpyAsync(a->trajectory, c.ws + c.w.traj, (size_t)a->steps * M1 * mel * 4, hipMemcpyDeviceToDevice, s));
+    if (a->trajectory) RC(f5_launch_copy_words(c.ws + c.w.traj, a->trajectory, (size_t)a->steps * M1 * mel, s));
     return 0;
 }
 
@@ -987,9 +993,8 @@ extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float
     RC(run_prep(c, 1));
     RC(K.pack_x(c.p<float>(c.w.traj), c.pb(c.w.xin, 0), c.pb(c.w.xin, 1), (int)M1, mel, s));
     RC(run_dit(c, 0));
-    F5_HIP_CHECK(hipMemcpyAsync(pred, c.ws + c.w.vel, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
-    if (null_pred && c.nb == 2)
-        F5_HIP_CHECK(hipMemcpyAsync(null_pred, c.ws + c.w.vel + M1 * mel * 4, M1 * mel * 4, hipMemcpyDeviceToDevice, s));
+    RC(f5_launch_copy_words(c.ws + c.w.vel, pred, M1 * mel, s));
+    if (null_pred && c.nb == 2) RC(f5_launch_copy_words(c.ws + c.w.vel + M1 * mel * 4, null_pred, M1 * mel, s));
     return 0;
 }
 
@@ -1003,8 +1008,10 @@ F5_DECL_KNOB(f5_attn_version)
 F5_DECL_KNOB(f5_attn_ablation)
 F5_DECL_KNOB(f5_attn_wide)
 F5_DECL_KNOB(f5_attn_kvsplit)
+F5_DECL_KNOB(f5_attn_prio)
 F5_DECL_KNOB(f5_gemm_big_kernel)
 F5_DECL_KNOB(f5_gemm_v3_stagger)
+F5_DECL_KNOB(f5_gemm_v3_prio)
 F5_DECL_KNOB(f5_gemm_ring_default)
 F5_DECL_KNOB(f5_gemm_order)
 F5_DECL_KNOB(f5_gemm_debug_flags)
@@ -1032,6 +1039,11 @@ extern "C" int f5_debug_set_attn_wide(int v) {
     F5_SET_BOTH(f5_attn_wide, v);
     return 0;
 }
+extern "C" int f5_debug_set_attn_prio(int v) {
+    F5_REQUIRE(v >= 0 && v <= 2, "attention priority scheme must be 0 (MFMA clusters), 1 (none) or 2 (softmax section)");
+    F5_SET_BOTH(f5_attn_prio, v);
+    return 0;
+}
 extern "C" int f5_debug_set_attn_kvsplit(int v) {
     F5_REQUIRE(v == -1 || v == 1 || v == 2 || v == 4, "attention KV split must be -1 (auto), 1, 2 or 4");
     F5_SET_BOTH(f5_attn_kvsplit, v);
@@ -1051,6 +1063,11 @@ extern "C" int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles) {
     F5_REQUIRE(v == 2 || v == 3, "big GEMM kernel must be 2 (256x256) or 3 (128x256, two workgroups per CU)");
     F5_SET_BOTH(f5_gemm_big_kernel, v);
     F5_SET_BOTH(f5_gemm_v3_stagger, stagger_cycles);
+    return 0;
+}
+extern "C" int f5_debug_set_gemm_v3_prio(int v) {
+    F5_REQUIRE(v >= 0 && v <= 2, "128x256 GEMM priority scheme must be 0 (MFMA clusters), 1 (none) or 2 (epilogue)");
+    F5_SET_BOTH(f5_gemm_v3_prio, v);
     return 0;
 }
 extern "C" int f5_debug_set_gemm_ring(int v) {

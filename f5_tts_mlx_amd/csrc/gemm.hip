@@ -1197,7 +1197,10 @@ static int launch_ring_ablate(const F5GemmArgs& a, int sel, int abl, hipStream_t
 #define V3_BK 32
 __device__ __forceinline__ int swz32(int row, int chunk) { return row * V3_BK + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
-template <int EPI>
+// PRIO (issue priority between the two co-resident workgroups of a CU): 0 = s_setprio 1 around the MFMA clusters (round 1:
+// measured no overlap of one workgroup's epilogue with the other's main loop), 1 = no priority changes, 2 = the EPILOGUE runs at
+// priority 3 and the main loop at 0, so the epilogue's VALU / LDS / store instructions issue in the gaps of the partner's MFMAs
+template <int EPI, int PRIO>
 __global__ __launch_bounds__(256, 2) void f5_gemm_v3_kernel(F5GemmArgs p, int tiles_n, int ntiles, int stagger_cycles) {
     constexpr int BMt = 128, BNt = 256, NST = 3;
     constexpr int NA = 2, NW = 4, G = NA + NW;
@@ -1288,7 +1291,7 @@ __global__ __launch_bounds__(256, 2) void f5_gemm_v3_kernel(F5GemmArgs p, int ti
 
         const op16_t* sA = smem + (tt % NST) * STAGE;
         const op16_t* sB = sA + BMt * V3_BK;
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             op16x8 af[2], bfr[4];
@@ -1302,8 +1305,9 @@ __global__ __launch_bounds__(256, 2) void f5_gemm_v3_kernel(F5GemmArgs p, int ti
                 for (int nb = 0; nb < 4; ++nb)
                     acc[mb][nb] = F5_MFMA32(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 0) __builtin_amdgcn_s_setprio(0);
     }
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(3);
     if (p.debug_flags & 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1325,6 +1329,7 @@ __global__ __launch_bounds__(256, 2) void f5_gemm_v3_kernel(F5GemmArgs p, int ti
     }
 }
 
+int f5_gemm_v3_prio = 0;       // 128x256 kernel: 0 = priority to the MFMA clusters, 1 = none, 2 = priority to the epilogue
 int f5_gemm_v3_stagger = -1;   // cycles of initial delay for workgroups 256..511 (-1: auto = half a tile's main loop)
 template <int EPI>
 static int launch_v3(const F5GemmArgs& a, hipStream_t stream) {
@@ -1332,7 +1337,9 @@ static int launch_v3(const F5GemmArgs& a, hipStream_t stream) {
     const int ntiles = tiles_m * tiles_n;
     int stagger = f5_gemm_v3_stagger;
     if (stagger < 0) stagger = (a.K / V3_BK) * a.nseg * 16 * 32;   // ~ half of (K tiles x 16 MFMAs x 32 cycles x 2 workgroups)
-    hipLaunchKernelGGL((f5_gemm_v3_kernel<EPI>), dim3(ntiles), dim3(256), 0, stream, a, tiles_n, ntiles, stagger);
+    if (f5_gemm_v3_prio == 1) hipLaunchKernelGGL((f5_gemm_v3_kernel<EPI, 1>), dim3(ntiles), dim3(256), 0, stream, a, tiles_n, ntiles, stagger);
+    else if (f5_gemm_v3_prio == 2) hipLaunchKernelGGL((f5_gemm_v3_kernel<EPI, 2>), dim3(ntiles), dim3(256), 0, stream, a, tiles_n, ntiles, stagger);
+    else hipLaunchKernelGGL((f5_gemm_v3_kernel<EPI, 0>), dim3(ntiles), dim3(256), 0, stream, a, tiles_n, ntiles, stagger);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -35,6 +35,8 @@ using f5bf::f5_launch_quantize_mx;
 using f5bf::f5_launch_quantize_mx_bf16;
 using f5bf::f5_launch_rope_table;
 using f5bf::f5_launch_rowkeep;
+using f5bf::f5_launch_stage_words;
+using f5bf::f5_launch_copy_words;
 using f5bf::f5_launch_skinny_gemm;
 using f5bf::f5_launch_splice;
 using f5bf::f5_launch_text_embed;
@@ -88,6 +90,9 @@ struct Ops {
     int im2col7(const float* x, op16_t* hi, op16_t* lo, int nbatch, int seq_len, int channels, hipStream_t s) const {
         return h ? f5hf::f5_launch_im2col7(x, H(hi), H(lo), nbatch, seq_len, channels, s)
                  : f5bf::f5_launch_im2col7(x, hi, lo, nbatch, seq_len, channels, s);
+    }
+    int zero_vt_pad(op16_t* vt, size_t rows, int seq_len, int npad, hipStream_t s) const {
+        return h ? f5hf::f5_launch_zero_vt_pad(H(vt), rows, seq_len, npad, s) : f5bf::f5_launch_zero_vt_pad(vt, rows, seq_len, npad, s);
     }
     int pack_bf16(const float* src, const uint8_t* rowkeep, op16_t* hi, op16_t* lo, int rows, int cols, int ld, int col0,
                   hipStream_t s) const {

@@ -581,6 +581,71 @@ int f5_launch_splice(const float* cond, const float* y, const int* lens, float* 
     return 0;
 }
 
+// ---- per-call staging without memcpy / memset API calls --------------------------------------------------------------------
+// Everything f5_sample enqueues is a KERNEL on the caller's stream: host scalars travel as kernel arguments (copied at launch
+// time: no host buffer to keep alive, no host synchronisation), device inputs / outputs are moved by a copy kernel, the V^T pad
+// columns are zeroed by a kernel.  hipMemcpyAsync / hipMemsetAsync go through the copy engines (and, captured, become graph
+// memcpy / memset nodes): their ordering against neighbouring kernel nodes of back-to-back graph launches was observed to fail
+// on some boxes of the pool (a late memset of V^T zeroing freshly written keys' values).
+struct F5StageWords {
+    uint32_t w[960];
+};
+__global__ __launch_bounds__(256) void stage_words_kernel(F5StageWords s, uint32_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = s.w[i];
+}
+int f5_launch_stage_words(const uint32_t* host_words, size_t nwords, uint32_t* dst, hipStream_t s) {
+    for (size_t o = 0; o < nwords; o += 960) {
+        F5StageWords sw;
+        const int n = (int)(nwords - o < 960 ? nwords - o : 960);
+        memcpy(sw.w, host_words + o, (size_t)n * 4);
+        hipLaunchKernelGGL(stage_words_kernel, dim3(f5_cdiv(n, 256)), dim3(256), 0, s, sw, dst + o, n);
+    }
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+__global__ __launch_bounds__(256) void copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n4, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void copy_words_scalar_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+// device -> device copy of n 32-bit words (16-byte accesses when both pointers allow it)
+int f5_launch_copy_words(const void* src, void* dst, size_t nwords, hipStream_t s) {
+    if (nwords == 0) return 0;
+    const bool al = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    const size_t work = al ? (nwords + 3) / 4 : nwords;
+    long blocks = f5_cdiv((long)work, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (al)
+        hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, nwords / 4, nwords);
+    else
+        hipLaunchKernelGGL(copy_words_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, nwords);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+// V^T [rows][npad]: zero the pad columns [seq_len, npad) (the attention kernel multiplies them by P = 0: they must be finite;
+// columns < seq_len are rewritten by every QKV epilogue)
+__global__ __launch_bounds__(256) void zero_vt_pad_kernel(op16_t* __restrict__ vt, int seq_len, int npad, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int pw = npad - seq_len;
+    const size_t row = i / pw;
+    const int c = seq_len + (int)(i - row * pw);
+    vt[row * npad + c] = static_cast<op16_t>(0.0f);
+}
+int f5_launch_zero_vt_pad(op16_t* vt, size_t rows, int seq_len, int npad, hipStream_t s) {
+    if (npad <= seq_len || rows == 0) return 0;
+    const size_t total = rows * (size_t)(npad - seq_len);
+    hipLaunchKernelGGL(zero_vt_pad_kernel, dim3(f5_cdiv((long)total, 256)), dim3(256), 0, s, vt, seq_len, npad, total);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void rowkeep_kernel(const int* __restrict__ dur, uint8_t* __restrict__ keep, int seq_len, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;

@@ -81,6 +81,12 @@ int f5_launch_ode_stage(const F5OdeArgs& a, hipStream_t s);
 int f5_launch_splice(const float* cond, const float* y, const int* lens, float* out, int B, int seq_len, int mel_dim,
                      hipStream_t s);
 
+// per-call staging as kernels (no memcpy / memset API on the sampling path): host words -> device through kernel arguments,
+// device -> device word copy, zeroing of the V^T pad columns
+int f5_launch_stage_words(const uint32_t* host_words, size_t nwords, uint32_t* dst, hipStream_t s);
+int f5_launch_copy_words(const void* src, void* dst, size_t nwords, hipStream_t s);
+int f5_launch_zero_vt_pad(op16_t* vt, size_t rows, int seq_len, int npad, hipStream_t s);
+
 // rowkeep[b*seq+n] = n < dur[b]  for 2 branches ([nb][seq])
 int f5_launch_rowkeep(const int* dur, uint8_t* keep, int nbatch, int seq_len, hipStream_t s);
 

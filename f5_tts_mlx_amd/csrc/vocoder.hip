@@ -325,7 +325,7 @@ extern "C" int f5_vocode(f5_vocoder* v, const float* mel, int B, int N, float* w
     char* ws = (char*)workspace;
     const size_t rows = (size_t)B * N;
     // caller buffers are staged outside the graph: the captured nodes only reference the workspace and the arena
-    F5_HIP_CHECK(hipMemcpyAsync(ws + w.mel, mel, rows * v->cfg.n_mels * 4, hipMemcpyDeviceToDevice, s));
+    RC(f5_launch_copy_words(mel, ws + w.mel, rows * v->cfg.n_mels, s));      // copy KERNELS, not memcpy nodes (rowops.hip)
     if (use_graph) {
         hipGraphExec_t exec = nullptr;
         for (auto& g : v->graphs)
@@ -366,6 +366,6 @@ extern "C" int f5_vocode(f5_vocoder* v, const float* mel, int B, int N, float* w
     } else {
         RC(vocode_body(v, w, ws, B, N, s));
     }
-    F5_HIP_CHECK(hipMemcpyAsync(wave, ws + w.wave, (size_t)B * v->cfg.hop_length * (N - 1) * 4, hipMemcpyDeviceToDevice, s));
+    RC(f5_launch_copy_words(ws + w.wave, wave, (size_t)B * v->cfg.hop_length * (N - 1), s));
     return 0;
 }

@@ -207,6 +207,8 @@ int f5_debug_set_gemm_order(int v);
 int f5_debug_set_gemm_ring(int v);
 /* large-shape GEMM kernel in auto mode: 2 = 256x256 (one workgroup per CU), 3 = 128x256 (two per CU); stagger < 0 = auto */
 int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles);
+/* 128x256 two-per-CU kernel: issue priority 0 = MFMA clusters, 1 = none, 2 = epilogue */
+int f5_debug_set_gemm_v3_prio(int v);
 /* large-shape GEMM schedule: 0 = one tile per workgroup (default), 1 = stream-K (persistent workgroup per CU over contiguous
  * K-step ranges), 2 = hybrid (lockstep rounds + stream-K tail);
  * f5_debug_gemm_streamk_error() returns 1 if a partial-tile hand-off ever timed out (results invalid) */
@@ -218,6 +220,8 @@ int f5_debug_set_attn_version(int v);
 int f5_debug_set_attn_ablation(int v);
 /* 256-query workgroups with two query blocks per wave (bf16, large grids): -1 auto, 0 off, 1 force */
 int f5_debug_set_attn_wide(int v);
+/* large-grid attention kernel: which phase of a wave holds SIMD issue priority: 0 MFMA clusters, 1 none, 2 softmax VALU section */
+int f5_debug_set_attn_prio(int v);
 /* in-workgroup KV split of the attention kernel: -1 auto (by grid size), 1 none, 2 / 4 wave groups */
 int f5_debug_set_attn_kvsplit(int v);
 

@@ -226,11 +226,15 @@ def test_c_abi_weight_broadcast_over_rccl(tiny_weights):
     1-rank communicator created with ctypes on librccl, the way a non-Python host would own one); the receiving engine is
     marked loaded.  The N-rank protocol itself is covered on CPU by tests/test_dist.py (gloo)."""
     import ctypes as C
+    class UniqueId(C.Structure):                       # ncclUniqueId is passed BY VALUE
+        _fields_ = [("internal", C.c_char * 128)]
     rccl = C.CDLL("librccl.so.1")
-    uid = (C.c_char * 128)()
+    torch.cuda.set_device(torch.device(DEV))
+    torch.zeros(1, device=DEV)                          # make sure the HIP context of this device exists
+    uid = UniqueId()
     assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
     comm = C.c_void_p()
-    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char * 128, C.c_int]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
     try:
         m = _model(TINY, tiny_weights, "f16")
@@ -578,6 +582,43 @@ def test_full_size_full_length_parity_golden():
     assert max(res["f16"]) <= MEL_L1_TOL, res
     assert max(res["bf16x3"]) <= MEL_L1_TOL, res
     assert max(res["bf16"]) <= 3e-2, res                                             # reported; NOT a parity mode
+
+
+def test_back_to_back_calls_without_host_sync_full_size():
+    """The bench pattern: sample() called back to back with no host synchronisation in between (outputs of earlier calls being
+    freed and their blocks re-used by torch's allocator meanwhile), graph and eager.  Every call must return the bits of a
+    synchronised call.  (Round 2 found garbage here on some boxes while the sampling path still used hipMemsetAsync /
+    hipMemcpyAsync: a captured memset of V^T could land after the first QKV epilogues; the path is kernels only since.)"""
+    import os
+    from f5test import ROOT
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_fullsize_golden", os.path.join(ROOT, "tests", "golden", "make_fullsize_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    wave, text, y0 = mg.inputs(0)
+    from f5_tts_mlx_amd.audio import log_mel_spectrogram
+    cond = log_mel_spectrogram(torch.from_numpy(wave).to(DEV))
+    m = _model(F5TTS_335M, synthetic_weights(F5TTS_335M, seed=42), "f16")
+    f5 = F5TTS(transformer=m)
+    kw = dict(duration=mg.N_FRAMES, y0=torch.from_numpy(y0)[None].to(DEV), steps=12, method="euler", cfg_strength=2.0, sway_sampling_coef=-1.0)
+    textd = torch.from_numpy(text)[None].to(DEV)
+    ref, ref_traj = f5.sample(cond, textd, use_graph=False, **kw)
+    torch.cuda.synchronize()
+    ref, ref_traj = ref.clone(), ref_traj.clone()
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) < 50
+    for mode in (True, False, "auto"):
+        outs = []
+        out = None
+        for i in range(6):
+            out, traj = f5.sample(cond, textd, use_graph=mode, **kw)        # previous `out` / `traj` are released here
+            if i % 2:
+                outs.append((out.clone(), traj[-1].clone()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), mode
+        for o, t in outs:
+            assert torch.equal(o, ref) and torch.equal(t, ref_traj[-1]), mode
+    del m
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("drops", [(0.9, 0.9), (0.1, 0.9), (0.9, 0.1)])     # (keep, keep) / audio dropped / both dropped
