@@ -1154,7 +1154,331 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
     }
 }
 
-int f5_attn_version = 2;   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower)
+// =================================================================================================
+// v5 (one-pass modes, large grids): software pipeline INSIDE the wave.  On this chip a wave's VALU / LDS / DMA instructions
+// only overlap matrix work when they sit between the MFMAs of the SAME instruction stream (<= ~5 issue slots per 32-cycle MFMA
+// gap; two co-resident waves do not interleave MFMA with VALU for each other -- tools/probes/coissue.hip, and the round-2
+// issue-priority experiment tools/attn_prio_bench.py moved nothing).  v2 runs S = K Q^T -> softmax -> O += V^T P strictly one
+// after the other per tile, so its MFMAs and its ~9 VALU per MFMA add up.  Here iteration j issues, as ONE block of
+// independent work,
+//     MFMA:  O^T += V^T(j-1) P(j-1)      (P of the previous tile, packed last iteration)
+//            S(j+1) = K(j+1) Q^T          (scores of the next tile, consumed next iteration)
+//     VALU:  softmax of S(j) -> P(j)      (scores computed last iteration)
+// and only the running-max rescale of O (a per-lane multiply by alpha(j)) follows it.  The source interleaves one MFMA with a
+// slice of the softmax; SCHED pins those slices with sched_barrier so the order survives instruction scheduling.
+// Workgroup = 8 waves x 32 queries (256 queries), <= 256 VGPRs => 2 waves per SIMD; K / V^T tiles of 64 keys arrive by
+// global_load_lds into 3-stage rings two iterations ahead (K(j+3), V^T(j+1) issued in iteration j), counted vmcnt, one barrier
+// per iteration.  Layouts (permuted K rows, XOR-swizzled 128-byte rows, P fed from the S accumulators) are v2's.
+// =================================================================================================
+template <bool HAS_PV, bool HAS_QK, bool SCHED, bool PK>
+__device__ __forceinline__ void attn5_body(const op16_t* sKn, const op16_t* sVp, const op16x8 (&qf)[4], f32x16 (&s_cur)[2],
+                                           f32x16 (&s_nxt)[2], f32x16 (&o)[2], const uint32_t (&pk_prev)[16], uint32_t (&pk_cur)[16],
+                                           float& m_run, float& l_run, float c2, int lq, int hi, int nmask) {
+    // nmask: keys >= nmask of this tile are padding (64 = none).  Only the LAST tile of a sequence can be partial, i.e. only the
+    // instantiations without a next tile carry the masking code (in the middle iterations it would be if-converted into 64
+    // unconditional compare / select instructions per tile)
+    if (!HAS_QK && nmask < 64) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb * 32 + 16 * hi + r >= nmask) s_cur[kb][r] = -INFINITY;
+    }
+    // MFMA slots of this iteration, in order: PV k-steps 0..3 (2 MFMAs each: d blocks 0, 1), then QK k-steps 0..3 (2 each: key
+    // blocks 0, 1).  Slot i's LDS fragment is read TWO slots ahead (fr[i & 3] rotates), so a ds_read_b128 has ~2 x (MFMA + its
+    // fillers) to land before the s_waitcnt in front of its MFMA.
+    constexpr int NPV = HAS_PV ? 8 : 0, NQK = HAS_QK ? 8 : 0, NSLOT = NPV + NQK;
+    op16x8 fr[4];
+    auto frag = [&](int i) -> op16x8 {                       // fragment of slot i (compile-time i after unrolling)
+        if (i < NPV) {
+            const int ks4 = i >> 1, db = i & 1;
+            return *reinterpret_cast<const op16x8*>(&sVp[attn_swz(db * 32 + lq, 4 * (ks4 >> 1) + 2 * hi + (ks4 & 1))]);
+        }
+        const int q = i - NPV, ks = q >> 1, kb = q & 1;
+        return *reinterpret_cast<const op16x8*>(&sKn[attn_swz(kb * 32 + lq, ks * 2 + hi)]);
+    };
+    if (NSLOT > 0) fr[0] = frag(0);
+    if (NSLOT > 1) fr[1] = frag(1);
+    if (HAS_QK) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s_nxt[0][e] = 0.0f;
+            s_nxt[1][e] = 0.0f;
+        }
+    }
+#define A5_SLOT(i)                                                                                                      \
+    if ((i) < NSLOT) {                                                                                                  \
+        if ((i) + 2 < NSLOT) fr[((i) + 2) & 3] = frag((i) + 2);                                                         \
+        if ((i) < NPV) {                                                                                                \
+            const int ks4_ = (i) >> 1;                                                                                  \
+            const op16x8 pb_ = __builtin_bit_cast(op16x8, u32x4{pk_prev[4 * ks4_], pk_prev[4 * ks4_ + 1], pk_prev[4 * ks4_ + 2], \
+                                                                pk_prev[4 * ks4_ + 3]});                                \
+            o[(i) & 1] = F5_MFMA32(fr[(i) & 3], pb_, o[(i) & 1], 0, 0, 0);                                              \
+        } else {                                                                                                        \
+            const int q_ = (i) - NPV;                                                                                   \
+            s_nxt[q_ & 1] = F5_MFMA32(fr[(i) & 3], qf[q_ >> 1], s_nxt[q_ & 1], 0, 0, 0);                                \
+        }                                                                                                               \
+    }                                                                                                                   \
+    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+    // ---- VALU part 1 (slots 0..3): scale the scores by c2 = scale * log2(e) with packed multiplies -- their results are
+    // ordinary VALU outputs, so the maxima need no canonicalising v_max in front of every MFMA output -- and reduce them to the
+    // tile maximum; lanes l and l + 32 own the two halves of a query's keys: one v_permlane32_swap
+    // PK: packed f32 multiplies / subtracts / adds (half the instruction count, but a v_pk_*_f32 costs more than its issue
+    // slot beside MFMAs); !PK: the same arithmetic as single-issue v_mul / v_sub / v_add
+    attn_f32x2 t2[2][8];
+    const attn_f32x2 c2v = {c2, c2};
+#define A5_SCALE(kb)                                                                                                    \
+    _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                                     \
+        if (PK) {                                                                                                       \
+            t2[kb][r] = attn_f32x2{s_cur[kb][2 * r], s_cur[kb][2 * r + 1]} * c2v;                                       \
+        } else {                                                                                                        \
+            float a_ = s_cur[kb][2 * r] * c2, b_ = s_cur[kb][2 * r + 1] * c2;                                           \
+            asm volatile("" : "+v"(a_), "+v"(b_));                                                                      \
+            t2[kb][r] = attn_f32x2{a_, b_};                                                                             \
+        }                                                                                                               \
+    }
+    A5_SCALE(0)
+    A5_SLOT(0)
+    A5_SCALE(1)
+#undef A5_SCALE
+    A5_SLOT(1)
+    float tm[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r0 = q * 4;
+        tm[q] = fmaxf(fmaxf(fmaxf(t2[0][r0][0], t2[0][r0][1]), fmaxf(t2[0][r0 + 1][0], t2[0][r0 + 1][1])),
+                      fmaxf(fmaxf(t2[0][r0 + 2][0], t2[0][r0 + 2][1]), fmaxf(t2[0][r0 + 3][0], t2[0][r0 + 3][1])));
+    }
+    A5_SLOT(2)
+#pragma unroll
+    for (int q = 2; q < 4; ++q) {
+        const int r0 = (q & 1) * 4;
+        tm[q] = fmaxf(fmaxf(fmaxf(t2[1][r0][0], t2[1][r0][1]), fmaxf(t2[1][r0 + 1][0], t2[1][r0 + 1][1])),
+                      fmaxf(fmaxf(t2[1][r0 + 2][0], t2[1][r0 + 2][1]), fmaxf(t2[1][r0 + 3][0], t2[1][r0 + 3][1])));
+    }
+    const float tmax_own = fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3]));
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax_own), __float_as_uint(tmax_own), false, false);
+    // after the swap (sw[0], sw[1]) = (own, partner) in the lower half-wave and (partner, own) in the upper one
+    const float mc = fmaxf(m_run, fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));   // running maximum, in exp2 units
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mc);       // m_run = -inf on the first tile: alpha = 0 (o = l = 0 then)
+    m_run = mc;
+    A5_SLOT(3)
+    // ---- VALU part 2 (slots 4..15): p = exp2(t - m), row sum, pack to the operand type, 1-2 pairs per MFMA slot.  Every packed
+    // P dword passes through an empty asm so that the slice stays HERE (it is consumed next iteration and would be sunk there)
+    attn_f32x2 ps2 = {0.0f, 0.0f};
+    const attn_f32x2 mcv = {mc, mc};
+#define A5_EXP(kb, r)                                                                                                   \
+    {                                                                                                                   \
+        float e0_, e1_;                                                                                                 \
+        if (PK) {                                                                                                       \
+            const attn_f32x2 t = t2[kb][r] - mcv;                                                                       \
+            e0_ = __builtin_amdgcn_exp2f(t[0]);                                                                         \
+            e1_ = __builtin_amdgcn_exp2f(t[1]);                                                                         \
+            ps2 += attn_f32x2{e0_, e1_};                                                                                \
+        } else {                                                                                                        \
+            float a_ = t2[kb][r][0] - mc, b_ = t2[kb][r][1] - mc;                                                       \
+            asm volatile("" : "+v"(a_), "+v"(b_));                                                                      \
+            e0_ = __builtin_amdgcn_exp2f(a_);                                                                           \
+            e1_ = __builtin_amdgcn_exp2f(b_);                                                                           \
+            ps2[0] += e0_;                                                                                              \
+            asm volatile("" : "+v"(ps2[0]));                                                                            \
+            ps2[1] += e1_;                                                                                              \
+            asm volatile("" : "+v"(ps2[1]));                                                                            \
+        }                                                                                                               \
+        pk_cur[(kb) * 8 + (r)] = f5_pack2_bounded(e0_, e1_);                                                            \
+        asm volatile("" : "+v"(pk_cur[(kb) * 8 + (r)]));                                                                \
+    }
+    A5_EXP(0, 0) A5_SLOT(4)
+    A5_EXP(0, 1) A5_SLOT(5)
+    A5_EXP(0, 2) A5_SLOT(6)
+    A5_EXP(0, 3) A5_SLOT(7)
+    A5_EXP(0, 4) A5_EXP(0, 5) A5_SLOT(8)
+    A5_EXP(0, 6) A5_SLOT(9)
+    A5_EXP(0, 7) A5_EXP(1, 0) A5_SLOT(10)
+    A5_EXP(1, 1) A5_SLOT(11)
+    A5_EXP(1, 2) A5_EXP(1, 3) A5_SLOT(12)
+    A5_EXP(1, 4) A5_SLOT(13)
+    A5_EXP(1, 5) A5_EXP(1, 6) A5_SLOT(14)
+    A5_EXP(1, 7) A5_SLOT(15)
+#undef A5_EXP
+#undef A5_SLOT
+    l_run = l_run * alpha + (ps2[0] + ps2[1]);
+    // O (now including tile j-1) moves from the old to the new running maximum; exact skip when no lane's maximum moved
+    if (HAS_PV && __any(alpha != 1.0f)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            o[0][e] *= alpha;
+            o[1][e] *= alpha;
+        }
+    }
+}
+
+// NW waves x 32 queries per workgroup: NW = 8 (one workgroup per CU, 256 queries) or 4 (two per CU, independent barriers)
+template <bool PK, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void f5_attn5_kernel(F5AttnArgs p) {
+    constexpr bool SCHED = true;
+    constexpr int NST = 3;
+    constexpr int TILE = 64 * 64;
+    constexpr int NCH = 8 / NW;                                            // 16-byte chunks of K (and of V^T) per thread per tile
+    __shared__ __attribute__((aligned(16))) op16_t smem[NST * 2 * TILE];   // [stage][K | V^T][64 x 64]: 48 KB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lq = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
+    const int nt = (kvlen + 63) >> 6;
+    const size_t rowbase = (size_t)b * p.seq_len;
+
+    op16x8 qf[4];
+    {
+        int qr = q0 + lq;
+        if (qr > p.seq_len - 1) qr = p.seq_len - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = *reinterpret_cast<const op16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+    }
+    // staging: NCH 16-byte chunks of K and of V^T per thread per tile (64 * NW threads x NCH x 16 B = one 8 KB tile image)
+    int krow[NCH], ldsoff[NCH];
+    const op16_t* kbase[NCH];
+    const op16_t* vbase[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int q_ = i * (64 * NW) + tid;
+        const int srow = q_ >> 3;
+        const int schunk = (q_ & 7) ^ ((srow >> 1) & 7);
+        krow[i] = attn_kperm(srow);
+        kbase[i] = p.qk[0] + rowbase * p.ldqk + p.dmodel + h * 64 + schunk * 8;
+        vbase[i] = p.vt[0] + ((size_t)bh * 64 + srow) * p.npad + schunk * 8;
+        ldsoff[i] = (i * (64 * NW) + wave * 64) * 8;
+    }
+    auto issue_k = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int key = t * 64 + krow[i];
+            if (key > p.seq_len - 1) key = p.seq_len - 1;
+            attn_glds16(kbase[i] + (size_t)key * p.ldqk, smem + (t % NST) * (2 * TILE) + ldsoff[i]);
+        }
+    };
+    auto issue_v = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) attn_glds16(vbase[i] + t * 64, smem + (t % NST) * (2 * TILE) + TILE + ldsoff[i]);
+    };
+#define A5_BARRIER()                               \
+    {                                              \
+        asm volatile("" ::: "memory");             \
+        __builtin_amdgcn_s_barrier();              \
+        asm volatile("" ::: "memory");             \
+    }
+
+    f32x16 o[2], s_a[2], s_b[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        o[0][e] = 0.0f;
+        o[1][e] = 0.0f;
+        s_a[0][e] = 0.0f;
+        s_a[1][e] = 0.0f;
+    }
+    uint32_t pk_a[16], pk_b[16];
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    // ---- prologue: K(0..2), V^T(0); S(0) = K(0) Q^T
+    issue_k(0);
+    if (nt > 1) issue_k(1);
+    if (nt > 2) issue_k(2);
+    issue_v(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    A5_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const op16x8 k0 = *reinterpret_cast<const op16x8*>(&smem[attn_swz(lq, ks * 2 + hi)]);
+        const op16x8 k1 = *reinterpret_cast<const op16x8*>(&smem[attn_swz(32 + lq, ks * 2 + hi)]);
+        s_a[0] = F5_MFMA32(k0, qf[ks], s_a[0], 0, 0, 0);
+        s_a[1] = F5_MFMA32(k1, qf[ks], s_a[1], 0, 0, 0);
+    }
+    if (nt > 3) A5_BARRIER();        // iteration 0 refills K(0)'s slot with K(3): every wave must be done reading K(0)
+
+    // ---- main loop.  Iteration j: S(j) in s_cur, P(j-1) in pk_prev; reads K(j+1), V^T(j-1); issues K(j+3), V^T(j+1).
+    // (s_a, pk_a) hold the even tiles, (s_b, pk_b) the odd ones: the loop runs two iterations per trip so that the roles
+    // alternate without register copies; the first and the last iteration are peeled (no P yet / no next tile).
+#define A5_WAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define A5_ITER(j_, HAS_PV_, HAS_QK_, s_cur_, s_nxt_, pk_prev_, pk_cur_)                                                \
+    {                                                                                                                   \
+        const int jt = (j_);   /* not `j`: the argument may be a variable of that name */                               \
+        if (jt + 3 < nt) issue_k(jt + 3);                                                                               \
+        if (jt + 1 < nt) issue_v(jt + 1);                                                                               \
+        const op16_t* sKn = smem + ((jt + 1) % NST) * (2 * TILE);                                                       \
+        const op16_t* sVp = smem + ((jt + NST - 1) % NST) * (2 * TILE) + TILE;                                          \
+        const int nmask = kvlen - jt * 64 < 64 ? kvlen - jt * 64 : 64;                                                  \
+        attn5_body<HAS_PV_, HAS_QK_, SCHED, PK>(sKn, sVp, qf, s_cur_, s_nxt_, o, pk_prev_, pk_cur_, m_run, l_run, c2, lq, hi, nmask); \
+        /* next iteration reads K(j+2), V^T(j): everything but the group just issued must have landed */              \
+        const int pend = (jt + 3 < nt ? 1 : 0) + (jt + 1 < nt ? 1 : 0);                                                 \
+        if (pend == 2) {                                                                                                \
+            A5_WAIT(2 * NCH);                                                                                           \
+        } else if (pend == 1) {                                                                                         \
+            A5_WAIT(NCH);                                                                                               \
+        } else {                                                                                                        \
+            A5_WAIT(0);                                                                                                 \
+        }                                                                                                               \
+        A5_BARRIER();                                                                                                   \
+    }
+    // O += V^T(nt-1) P(nt-1) after the last iteration (its P sits in pk_a for an even last tile, pk_b for an odd one; the two
+    // arrays must never be selected between at run time, or they are demoted from registers to scratch memory)
+#define A5_FINAL_PV(pk_)                                                                                                \
+    {                                                                                                                   \
+        const op16_t* sVl = smem + ((nt - 1) % NST) * (2 * TILE) + TILE;                                                \
+        _Pragma("unroll") for (int ks4 = 0; ks4 < 4; ++ks4) {                                                           \
+            const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{pk_[4 * ks4], pk_[4 * ks4 + 1], pk_[4 * ks4 + 2], pk_[4 * ks4 + 3]}); \
+            const int ch = 4 * (ks4 >> 1) + 2 * hi + (ks4 & 1);                                                         \
+            o[0] = F5_MFMA32(*reinterpret_cast<const op16x8*>(&sVl[attn_swz(lq, ch)]), pb, o[0], 0, 0, 0);              \
+            o[1] = F5_MFMA32(*reinterpret_cast<const op16x8*>(&sVl[attn_swz(32 + lq, ch)]), pb, o[1], 0, 0, 0);         \
+        }                                                                                                               \
+    }
+    if (nt == 1) {
+        A5_ITER(0, false, false, s_a, s_b, pk_b, pk_a);
+        A5_FINAL_PV(pk_a);
+    } else {
+        A5_ITER(0, false, true, s_a, s_b, pk_b, pk_a);
+        int j = 1;
+        for (; j + 2 < nt; j += 2) {                     // middle iterations j (odd), j + 1 (even), both < nt - 1
+            A5_ITER(j, true, true, s_b, s_a, pk_a, pk_b);
+            A5_ITER(j + 1, true, true, s_a, s_b, pk_b, pk_a);
+        }
+        if (j + 1 < nt) {                                // one middle iteration left (odd), the last one is even
+            A5_ITER(j, true, true, s_b, s_a, pk_a, pk_b);
+            A5_ITER(j + 1, true, false, s_a, s_b, pk_b, pk_a);
+            A5_FINAL_PV(pk_a);
+        } else {                                         // the last iteration is odd
+            A5_ITER(j, true, false, s_b, s_a, pk_a, pk_b);
+            A5_FINAL_PV(pk_b);
+        }
+    }
+#undef A5_FINAL_PV
+#undef A5_ITER
+#undef A5_WAIT
+#undef A5_BARRIER
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qr = q0 + lq;
+    if (qr < p.seq_len) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = db * 32 + 8 * rg + 4 * hi;
+                const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
+                *reinterpret_cast<u32x2*>(p.out[0] + off) =
+                    u32x2{f5_pack2_bounded(o[db][rg * 4 + 0] * inv, o[db][rg * 4 + 1] * inv),
+                          f5_pack2_bounded(o[db][rg * 4 + 2] * inv, o[db][rg * 4 + 3] * inv)};
+            }
+    }
+}
+
+int f5_attn_version = 2;
+int f5_attn_variant = 0;   // experiment bits of the pipelined kernel (versions 5 / 6), see the launcher   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower)
 int f5_attn_ablation = 0;  // timing experiments only
 int f5_attn_wide = -1;     // -1 auto (>= 1024 workgroups), 0 off, 1 force: 256-query workgroups, two query blocks per wave (bf16)
 int f5_attn_prio = 0;      // wide kernel: which phase holds issue priority (0 MFMA clusters, 1 none, 2 softmax section)
@@ -1176,6 +1500,25 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
         // measured (tools/attn_split_bench.py, N = 937, 16 heads): 128 WGs 20.5 / 17.4 / 16.2 us for 1 / 2 / 4 groups,
         // 256 WGs 21.4 / 19.1 / 20.1, 512 WGs 31.8 / 37.3 / 38.9
         ks = (wgs <= 160 && ntile >= 8) ? 4 : ((wgs <= 320 && ntile >= 4) ? 2 : 1);
+    }
+    // one-pass modes: in-wave software-pipelined kernel (256 queries per workgroup, 8 waves)
+    if ((f5_attn_version == 5 || f5_attn_version == 6) && !a.hp && !a.out8 && f5_attn_ablation == 0) {
+        // experiment matrix.  waves per workgroup: 8 (256 queries) or 4 (128); packed or single-issue softmax arithmetic;
+        // f5_attn_variant bit 0: single-issue VALU, bit 1: 40 KB of unused dynamic LDS so that only ONE 4-wave workgroup fits
+        // a CU (one wave per SIMD)
+        const bool pk = !(f5_attn_variant & 1);
+        const size_t dyn = (f5_attn_variant & 2) ? 40 * 1024 : 0;
+        if (f5_attn_version == 5) {
+            const dim3 g(f5_cdiv(a.seq_len, 256), a.B * a.H);
+            if (pk) hipLaunchKernelGGL((f5_attn5_kernel<true, 8>), g, dim3(512), dyn, stream, a);
+            else hipLaunchKernelGGL((f5_attn5_kernel<false, 8>), g, dim3(512), dyn, stream, a);
+        } else {
+            const dim3 g(f5_cdiv(a.seq_len, 128), a.B * a.H);
+            if (pk) hipLaunchKernelGGL((f5_attn5_kernel<true, 4>), g, dim3(256), dyn, stream, a);
+            else hipLaunchKernelGGL((f5_attn5_kernel<false, 4>), g, dim3(256), dyn, stream, a);
+        }
+        F5_LAUNCH_CHECK();
+        return 0;
     }
     // large grids (bf16): two query blocks per wave (256 queries per workgroup)
     if (f5_attn_version == 2 && f5_attn_ablation == 0 && !a.hp && ks <= 1 &&

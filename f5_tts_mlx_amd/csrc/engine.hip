@@ -1006,6 +1006,7 @@ extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float
 #define F5_SET_BOTH(v, x) do { f5bf::v = (x); f5hf::v = (x); } while (0)
 F5_DECL_KNOB(f5_attn_version)
 F5_DECL_KNOB(f5_attn_ablation)
+F5_DECL_KNOB(f5_attn_variant)
 F5_DECL_KNOB(f5_attn_wide)
 F5_DECL_KNOB(f5_attn_kvsplit)
 F5_DECL_KNOB(f5_attn_prio)
@@ -1026,8 +1027,13 @@ extern "C" uint16_t f5_debug_f2h_bits(float f) { return f5_f2h_bits(f); }
 extern "C" float f5_debug_h_bits2f(uint16_t h) { return f5_h_bits2f(h); }
 extern "C" uint16_t f5_debug_f2bf_bits(float f) { return f5_f2bf_bits(f); }
 extern "C" int f5_debug_set_attn_version(int v) {
-    F5_REQUIRE(v >= 1 && v <= 4, "attention version must be 1..4");
+    F5_REQUIRE(v >= 1 && v <= 6, "attention version must be 1..6");
     F5_SET_BOTH(f5_attn_version, v);
+    return 0;
+}
+extern "C" int f5_debug_set_attn_variant(int v) {
+    F5_REQUIRE(v >= 0 && v <= 3, "attention variant bits: 1 = single-issue softmax VALU, 2 = one workgroup per CU");
+    F5_SET_BOTH(f5_attn_variant, v);
     return 0;
 }
 extern "C" int f5_debug_set_attn_ablation(int v) {

@@ -217,6 +217,7 @@ int f5_debug_gemm_streamk_error(void);
 /* 1 = register-staged attention kernel, 2 = global_load_lds ring (default) */
 int f5_debug_set_attn_version(int v);
 /* timing-only ablations of the attention kernel (results are wrong unless 0) */
+int f5_debug_set_attn_variant(int bits);   /* experiment bits of attention versions 5 / 6 (see attention.hip) */
 int f5_debug_set_attn_ablation(int v);
 /* 256-query workgroups with two query blocks per wave (bf16, large grids): -1 auto, 0 off, 1 force */
 int f5_debug_set_attn_wide(int v);

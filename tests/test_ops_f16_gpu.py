@@ -59,6 +59,16 @@ def test_attention_large_grid_f16(lib):
 
 def test_attention_softmax_spike_f16(lib):
     T.test_attention_softmax_spike(lib)
+    T.test_attention_softmax_spike(lib, hp=0)
+
+
+@pytest.mark.parametrize("N", [1, 64, 130, 937])
+def test_attention_pipelined_kernel_f16(lib, N):
+    T.test_attention_pipelined_kernel_shapes(lib, 5, N)
+
+
+def test_attention_pipelined_kernel_ragged_f16(lib):
+    T.test_attention_pipelined_kernel_ragged_and_batched(lib, 5)
 
 
 @pytest.mark.parametrize("B,N,C", [(2, 130, 256), (1, 937, 1024)])

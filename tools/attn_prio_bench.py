@@ -45,13 +45,18 @@ def main():
             ao = torch.empty(nb * N, D, dtype=dt, device=dev)
             fn = lambda st: E.check(lib.f5_op_attention(P(qk), P(None), P(vt), P(None), P(ao), P(None), P(None), nb, H, N, npad, D,
                                                         C.c_float(0.125), 0, st))
-            res = {0: [], 1: [], 2: []}
+            # (kernel version, variant bits): 2 = round-1 kernels; 5 / 6 = in-wave pipelined kernel with 8 / 4 waves per workgroup;
+            # variant 1 = single-issue softmax VALU, 2 = one workgroup per CU (4 waves: one wave per SIMD)
+            arms = [(2, 0), (5, 0), (5, 1), (6, 0), (6, 1), (6, 2), (6, 3)]
+            res = {f"{v}.{b}": [] for v, b in arms}
             with E.operand_type(prec):
-                for rnd in range(4):
-                    for prio in (0, 1, 2):
-                        E.check(lib.f5_debug_set_attn_prio(prio))
-                        res[prio].append(graph_time(fn))
-            E.check(lib.f5_debug_set_attn_prio(0))
+                for rnd in range(3):
+                    for ver, bits in arms:
+                        E.check(lib.f5_debug_set_attn_version(ver))
+                        E.check(lib.f5_debug_set_attn_variant(bits))
+                        res[f"{ver}.{bits}"].append(graph_time(fn))
+            E.check(lib.f5_debug_set_attn_version(2))
+            E.check(lib.f5_debug_set_attn_variant(0))
             fl = 4.0 * nb * H * N * N * 64
             print(json.dumps(dict(nb=nb, prec=prec, us={k: [round(x, 1) for x in v] for k, v in res.items()},
                                   tflops_best={k: round(fl / min(v) / 1e6) for k, v in res.items()})), flush=True)
