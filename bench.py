@@ -106,11 +106,13 @@ def _time_launches(run, dev, iters: int) -> float:
 
 
 def _pmc_traffic(key: str, shape: str, precision: str):
-    """HBM/fabric bytes per launch from the last committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), if it is this shape."""
+    """HBM/fabric bytes per launch from the last committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE, separate passes, collected by tools/gpu_pmc_ops.sh), if there is an entry for this kernel, shape and precision."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[key]
-        if pm.get("shape") == shape and pm.get("precision") == precision:
-            return pm["fetch_bytes_corrected_x2"] + pm["write_bytes"]
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        for e in pm.get("entries", []):
+            if e.get("key") == key and e.get("shape") == shape and e.get("precision") == precision:
+                return e["fetch_bytes_corrected_x2"] + e["write_bytes"]
     except Exception:
         pass
     return None
