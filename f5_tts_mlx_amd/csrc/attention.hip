@@ -22,6 +22,25 @@ namespace F5_NS {
 #define KLD 72   // K  tile row stride in elements (144 B)
 #define VLD 68   // V^T tile row stride in elements (136 B)
 
+// workgroup -> (query block, batch*head).  Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every query
+// block of a head streams that head's whole K / V^T: with a plain (x = query block, y = head) numbering the query blocks of
+// a head land on different XCDs and K / V^T is fetched into several private L2s (FETCH_SIZE 1.12 GB per launch at 64 x 16 x
+// 937 with 256-query blocks, against 0.37 GB of q + k + v; tools/gpu_pmc_ops.sh).  The launcher therefore uses a 1-D grid of
+// 8 * ceil(B*H / 8) * nqb workgroups: XCD = id & 7, and on one XCD consecutive workgroups walk the query blocks of one head
+// before moving to the next head (measured +3.5-6 % on the large-grid kernel, tools/attn_prio_bench.py).  A 2-D grid
+// (f5_attn_variant bit 2, A/B only) keeps the plain numbering.
+__device__ __forceinline__ bool attn_block_map(const F5AttnArgs& p, int qrows, int& bh, int& qblk) {
+    if (gridDim.y != 1) {
+        bh = blockIdx.y;
+        qblk = blockIdx.x;
+        return true;
+    }
+    const int nqb = (p.seq_len + qrows - 1) / qrows;
+    const int s = blockIdx.x >> 3;
+    qblk = s % nqb;
+    bh = (s / nqb) * 8 + (blockIdx.x & 7);
+    return bh < p.B * p.H;
+}
 template <bool HP>
 __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
     constexpr int NP = HP ? 2 : 1;
@@ -30,9 +49,10 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
-    const int bh = blockIdx.y;
+    int bh, qblk;
+    if (!attn_block_map(p, 128, bh, qblk)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qblk * 128 + wave * 32;
     const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
     const int ntile = (kvlen + 63) >> 6;
     const size_t rowbase = (size_t)b * p.seq_len;
@@ -281,9 +301,10 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lq = lane & 31;
-    const int bh = blockIdx.y;
+    int bh, qblk;
+    if (!attn_block_map(p, 128, bh, qblk)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qblk * 128 + wave * 32;
     const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
     const int ntile = (kvlen + 63) >> 6;
     const size_t rowbase = (size_t)b * p.seq_len;
@@ -528,9 +549,10 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lq = lane & 31;
-    const int bh = blockIdx.y;
+    int bh, qblk;
+    if (!attn_block_map(p, 256, bh, qblk)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * 256 + wave * 64;
+    const int q0 = qblk * 256 + wave * 64;
     const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
     const int ntile = (kvlen + 63) >> 6;
     const size_t rowbase = (size_t)b * p.seq_len;
@@ -733,9 +755,10 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
     const int tg = tid & 255;
     op16_t* smem = smem_all + grp * RING;
     const int hi = lane >> 5, lq = lane & 31;
-    const int bh = blockIdx.y;
+    int bh, qblk;
+    if (!attn_block_map(p, 128, bh, qblk)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qblk * 128 + wave * 32;
     const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
     const int ntile = (kvlen + 63) >> 6;
     const int nit = (ntile + KS - 1) / KS;              // iterations of group 0 (the most)
@@ -979,9 +1002,10 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lq = lane & 31;
-    const int bh = blockIdx.y;
+    int bh, qblk;
+    if (!attn_block_map(p, 128, bh, qblk)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qblk * 128 + wave * 32;
     const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
     const int ntile = (kvlen + 63) >> 6;
     const size_t rowbase = (size_t)b * p.seq_len;
@@ -1325,9 +1349,10 @@ __global__ __launch_bounds__(64 * NW, 2) void f5_attn5_kernel(F5AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lq = lane & 31;
-    const int bh = blockIdx.y;
+    int bh, qblk;
+    if (!attn_block_map(p, 32 * NW, bh, qblk)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+    const int q0 = qblk * (32 * NW) + wave * 32;
     const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
     const int nt = (kvlen + 63) >> 6;
     const size_t rowbase = (size_t)b * p.seq_len;
@@ -1477,12 +1502,19 @@ __global__ __launch_bounds__(64 * NW, 2) void f5_attn5_kernel(F5AttnArgs p) {
     }
 }
 
-int f5_attn_version = 2;
-int f5_attn_variant = 0;   // experiment bits of the pipelined kernel (versions 5 / 6), see the launcher   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower)
+int f5_attn_version = 2;   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower); 5 / 6 = pipelined experiment
+int f5_attn_variant = 0;   // experiment bits (see the launcher): 1, 2 = pipelined kernel variants, 4 = plain 2-D block numbering
 int f5_attn_ablation = 0;  // timing experiments only
 int f5_attn_wide = -1;     // -1 auto (>= 1024 workgroups), 0 off, 1 force: 256-query workgroups, two query blocks per wave (bf16)
 int f5_attn_prio = 0;      // wide kernel: which phase holds issue priority (0 MFMA clusters, 1 none, 2 softmax section)
 int f5_attn_kvsplit = -1;  // -1 auto, 1 / 2 / 4 = force the in-workgroup KV split (debug hook)
+
+// 1-D XCD-aware grid (attn_block_map) unless f5_attn_variant bit 2 asks for the plain 2-D numbering
+static dim3 attn_grid(const F5AttnArgs& a, int qrows) {
+    const int nqb = f5_cdiv(a.seq_len, qrows);
+    if (f5_attn_variant & 4) return dim3(nqb, a.B * a.H);
+    return dim3(nqb * 8 * f5_cdiv(a.B * a.H, 8), 1);
+}
 
 int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     F5_REQUIRE(a.B > 0 && a.H > 0 && a.seq_len > 0, "attention: bad shape");
@@ -1491,11 +1523,12 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     F5_REQUIRE(a.qk[0] && a.vt[0] && (a.out[0] || a.out8), "attention: null pointer");
     F5_REQUIRE(!a.out8 || (!a.hp && a.out8s && f5_attn_version == 2 && f5_attn_ablation == 0 && a.ldo8 % 4 == 0),
                "attention: fp8 output needs the bf16 ring kernels");
-    dim3 grid(f5_cdiv(a.seq_len, 128), a.B * a.H);
+    const dim3 grid = attn_grid(a, 128);
+    const long wgs128 = (long)f5_cdiv(a.seq_len, 128) * a.B * a.H;
     // small batches: fewer workgroups than ~2 per CU -> split the KV range over 2 or 4 wave groups inside the workgroup
     int ks = f5_attn_kvsplit;
     if (ks < 0) {
-        const long wgs = (long)grid.x * grid.y;
+        const long wgs = wgs128;
         const int ntile = f5_cdiv(a.seq_len, 64);
         // measured (tools/attn_split_bench.py, N = 937, 16 heads): 128 WGs 20.5 / 17.4 / 16.2 us for 1 / 2 / 4 groups,
         // 256 WGs 21.4 / 19.1 / 20.1, 512 WGs 31.8 / 37.3 / 38.9
@@ -1509,11 +1542,11 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
         const bool pk = !(f5_attn_variant & 1);
         const size_t dyn = (f5_attn_variant & 2) ? 40 * 1024 : 0;
         if (f5_attn_version == 5) {
-            const dim3 g(f5_cdiv(a.seq_len, 256), a.B * a.H);
+            const dim3 g = attn_grid(a, 256);
             if (pk) hipLaunchKernelGGL((f5_attn5_kernel<true, 8>), g, dim3(512), dyn, stream, a);
             else hipLaunchKernelGGL((f5_attn5_kernel<false, 8>), g, dim3(512), dyn, stream, a);
         } else {
-            const dim3 g(f5_cdiv(a.seq_len, 128), a.B * a.H);
+            const dim3 g = attn_grid(a, 128);
             if (pk) hipLaunchKernelGGL((f5_attn5_kernel<true, 4>), g, dim3(256), dyn, stream, a);
             else hipLaunchKernelGGL((f5_attn5_kernel<false, 4>), g, dim3(256), dyn, stream, a);
         }
@@ -1522,8 +1555,8 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     }
     // large grids (bf16): two query blocks per wave (256 queries per workgroup)
     if (f5_attn_version == 2 && f5_attn_ablation == 0 && !a.hp && ks <= 1 &&
-        (f5_attn_wide >= 1 || (f5_attn_wide < 0 && (long)f5_cdiv(a.seq_len, 256) * grid.y >= 512))) {
-        const dim3 gw(f5_cdiv(a.seq_len, 256), a.B * a.H);
+        (f5_attn_wide >= 1 || (f5_attn_wide < 0 && (long)f5_cdiv(a.seq_len, 256) * a.B * a.H >= 512))) {
+        const dim3 gw = attn_grid(a, 256);
         if (f5_attn_prio == 1) hipLaunchKernelGGL(f5_attn2w_kernel<1>, gw, dim3(256), 0, stream, a);
         else if (f5_attn_prio == 2) hipLaunchKernelGGL(f5_attn2w_kernel<2>, gw, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(f5_attn2w_kernel<0>, gw, dim3(256), 0, stream, a);
