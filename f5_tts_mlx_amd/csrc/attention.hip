@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 // phase): 0 = the MFMA clusters (s_setprio 1 around them), 1 = no priority changes, 2 = the softmax VALU section (the wave
 // sits at priority 1 and drops to 0 for its MFMA clusters, so a partner's transcendentals / VALU issue in the gaps of this
 // wave's MFMAs instead of queueing behind them)
-template <int PRIO>
+template <int PRIO, bool LAZY = true>
 __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
     constexpr int NST = 3;
     constexpr int TILE = 64 * 64;
@@ -610,6 +610,7 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
         }
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
     const float c2 = p.scale * 1.4426950408889634f;
+    const float lazy_margin = 8.0f / c2;                 // raw-score units: exponent of at most 8 in exp2 units
 
     A2W_ISSUE(0);
     if (ntile > 1) A2W_ISSUE(1);
@@ -667,7 +668,12 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[qb][kb][r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            {
+            // Lazy rescale: m_run is the reference point of the exponentials, not necessarily the running maximum.  It only
+            // moves (and O, l are only rescaled: 64 + 1 multiplies per query block) when some query's tile maximum exceeds it
+            // by more than 2^8 -- softmax is shift invariant, so any reference within range gives the same normalised result;
+            // P then lies in [0, 2^8], inside half's range, with the same RELATIVE rounding as P <= 1.  After the first
+            // tile the branch is rarely taken (wave-uniform: `s_cbranch` on an SGPR mask, no divergence).
+            if (!LAZY || __any(tmax > m_run[qb] + lazy_margin)) {
                 const float m_new = fmaxf(m_run[qb], tmax);
                 const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c2);
                 m_run[qb] = m_new;
@@ -1503,7 +1509,7 @@ __global__ __launch_bounds__(64 * NW, 2) void f5_attn5_kernel(F5AttnArgs p) {
 }
 
 int f5_attn_version = 2;   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower); 5 / 6 = pipelined experiment
-int f5_attn_variant = 0;   // experiment bits (see the launcher): 1, 2 = pipelined kernel variants, 4 = plain 2-D block numbering
+int f5_attn_variant = 0;   // experiment bits (see the launcher): 1, 2 = pipelined kernel variants, 4 = plain 2-D block numbering, 8 = eager O rescale in the large-grid kernel
 int f5_attn_ablation = 0;  // timing experiments only
 int f5_attn_wide = -1;     // -1 auto (>= 1024 workgroups), 0 off, 1 force: 256-query workgroups, two query blocks per wave (bf16)
 int f5_attn_prio = 0;      // wide kernel: which phase holds issue priority (0 MFMA clusters, 1 none, 2 softmax section)
@@ -1559,6 +1565,7 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
         const dim3 gw = attn_grid(a, 256);
         if (f5_attn_prio == 1) hipLaunchKernelGGL(f5_attn2w_kernel<1>, gw, dim3(256), 0, stream, a);
         else if (f5_attn_prio == 2) hipLaunchKernelGGL(f5_attn2w_kernel<2>, gw, dim3(256), 0, stream, a);
+        else if (f5_attn_variant & 8) hipLaunchKernelGGL((f5_attn2w_kernel<0, false>), gw, dim3(256), 0, stream, a);   // A/B: eager rescale
         else hipLaunchKernelGGL(f5_attn2w_kernel<0>, gw, dim3(256), 0, stream, a);
         F5_LAUNCH_CHECK();
         return 0;

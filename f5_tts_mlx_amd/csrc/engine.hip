@@ -1032,7 +1032,7 @@ extern "C" int f5_debug_set_attn_version(int v) {
     return 0;
 }
 extern "C" int f5_debug_set_attn_variant(int v) {
-    F5_REQUIRE(v >= 0 && v <= 7, "attention variant bits: 1 = single-issue softmax VALU, 2 = one workgroup per CU, 4 = 2-D block numbering");
+    F5_REQUIRE(v >= 0 && v <= 15, "attention variant bits: 1 = single-issue softmax VALU, 2 = one workgroup per CU, 4 = 2-D block numbering, 8 = eager rescale");
     F5_SET_BOTH(f5_attn_variant, v);
     return 0;
 }

@@ -47,7 +47,7 @@ def main():
                                                         C.c_float(0.125), 0, st))
             # (kernel version, variant bits): 2 = round-1 kernels; 5 / 6 = in-wave pipelined kernel with 8 / 4 waves per workgroup;
             # variant 1 = single-issue softmax VALU, 2 = one workgroup per CU (4 waves: one wave per SIMD)
-            arms = [(2, 0), (2, 4), (5, 0)]     # variant 4 = plain 2-D block numbering (A/B of the XCD-aware one)
+            arms = [(2, 0), (2, 8)]     # variant 8 = eager O rescale (A/B of the lazy one), 4 = plain 2-D block numbering
             res = {f"{v}.{b}": [] for v, b in arms}
             with E.operand_type(prec):
                 for rnd in range(4):

@@ -1,10 +1,5 @@
 #!/bin/bash
 OUT=gpurun_out/${1:-r2d}
 mkdir -p $OUT
-for rep in 1 2; do
-for v in 0 4; do
-  for b in 1 32; do
-  timeout 300 python tools/bench_flags.py attnvar=$v -- --batch $b --steps 4 --warmup 2 --no-sub --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('attnvar',$v,'batch',$b, d['value'], d['ms_per_step'])" | tee -a $OUT/attnvar_ab.txt
-  done
-done
-done
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_ops_f16_gpu.py -m gpu -q --tb=short -p no:cacheprovider -k "attention" > $OUT/pytest_attn.txt 2>&1; grep -E "passed|failed" $OUT/pytest_attn.txt | tail -2; grep -E "^(FAILED|ERROR)" $OUT/pytest_attn.txt | head -20
+timeout 600 python tools/attn_prio_bench.py 64 16 > $OUT/attn_lazy.txt 2>&1; cat $OUT/attn_lazy.txt
