@@ -47,7 +47,8 @@ struct TextBlockW {
 
 struct Workspace {
     size_t total = 0;
-    size_t scal, scal_words;   // per-call host scalars, contiguous: [lens B | dur2 2B | tgrid nfe | dt steps | cfg 1] (32-bit words)
+    size_t scal, scal_words;   // per-call host scalars, contiguous: [lens B | dur2 2B | tgrid nfe | dt steps | cfg 1 | lncnt] (32-bit words)
+    size_t lncnt, lncnt_words; // row-block arrival counters of the fused LN tail (zeroed with the scalars; 0 words = no fusion)
     size_t lens, dur2, text, ids, keep, rowkeep;
     size_t tgrid, dt, cfgv, sinus, th, temb, mod;
     size_t rope_cos, rope_sin;
@@ -388,13 +389,16 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
     Bump b;
     Workspace w;
     const size_t nfe1 = (size_t)(nfe > 0 ? nfe : 1);
-    w.scal_words = (size_t)3 * B + nfe1 + steps + 1;
+    // one counter per 64 rows of the residual stream; only small-M launches fuse (gemm.hpp ln_counter), large ones get none
+    w.lncnt_words = (M2 + 63) / 64 <= 512 ? (M2 + 63) / 64 : 0;
+    w.scal_words = (size_t)3 * B + nfe1 + steps + 1 + w.lncnt_words;
     w.scal = b.take(w.scal_words * 4);
     w.lens = w.scal;
     w.dur2 = w.lens + (size_t)B * 4;
     w.tgrid = w.dur2 + (size_t)2 * B * 4;
     w.dt = w.tgrid + nfe1 * 4;
     w.cfgv = w.dt + (size_t)steps * 4;
+    w.lncnt = w.cfgv + 4;
     w.text = b.take((size_t)B * (nt > 0 ? nt : 1) * 4);
     w.ids = b.take(M2 * 4);
     w.keep = b.take(M2);
@@ -556,6 +560,11 @@ static int run_prep(const Ctx& c, int nfe) {
 }
 
 // one batched (cond + null) DiT forward; input = xin (bf16 padded state), modulation row `j`
+// f5_debug_set_ln_fusion: LN-modulate fused behind the residual GEMMs of small-tile launches (gemm.hpp ln_counter).  OFF by
+// default: bit-identical, but measured SLOWER at batch 1 (88.5 / 90.3 ms per sample against 75.1 / 78.6 on the same boxes,
+// profiles/r02/ln_fusion_ab.txt): a cross-XCD hand-over inside a kernel is three dependent trips to the memory side (write-through
+// ack, counter atomic, agent-scope re-read: ~10 us per GEMM) where the separate LN launch costs 5.2 us.
+static int g_fuse_ln = 0;
 static int run_dit(const Ctx& c, int j) {
     const f5_engine* e = c.e;
     const f5_config& cf = e->cfg;
@@ -683,10 +692,24 @@ static int run_dit(const Ctx& c, int j) {
         g2.gate = m6 + 5 * D;
         RC(f5_launch_gemm_f8(g2, EPI_RESID_GATE, s));
     }
+    // LN-modulate fused behind the residual GEMMs where the launch is small-tile (gemm.hpp ln_counter): at batch 1 that removes
+    // 2 of the 7 launches of a block; h_ready = the h operand of the next QKV / final projection already exists
+    const float* mf = mod + (size_t)L * 6 * D;  // final adaLN: (scale, shift) order, dit.py:287
+    bool h_ready = false;
+    auto fuse_ln = [&](F5GemmArgs& g, const float* scale, const float* shift) -> bool {
+        if (!g_fuse_ln || w.lncnt_words == 0 || !K.gemm_resid_ln_fusable(g)) return false;
+        g.ln_counter = c.p<int>(w.lncnt);
+        g.ln_scale = scale;
+        g.ln_shift = shift;
+        g.ln_out[0] = c.pb(w.h, 0);
+        g.ln_out[1] = c.pb(w.h, 1);
+        g.ln_eps = 1e-6f;
+        return true;
+    };
     for (int i = 0; i < L && e->prec != F5_PREC_MXFP8; ++i) {
         const BlockW& bw = e->blocks[i];
         const float* m6 = mod + (size_t)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        RC(K.ln_modulate(c.p<float>(w.x), m6 + D, m6, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+        if (!h_ready) RC(K.ln_modulate(c.p<float>(w.x), m6 + D, m6, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
         F5GemmArgs gq = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.qkv, M, 3 * D, D, c.a<float>(bw.bqkv));
         gq.out_bf[0] = c.pb(w.qk, 0);
         gq.out_bf[1] = c.pb(w.qk, 1);
@@ -725,9 +748,10 @@ static int run_dit(const Ctx& c, int j) {
         go.ldo = D;
         go.gate = m6 + 2 * D;
         go.rowkeep = rowkeep;
+        const bool fused_mlp_ln = fuse_ln(go, m6 + 4 * D, m6 + 3 * D);     // h = LN(x) (1 + scale_mlp) + shift_mlp in the same launch
         RC(K.gemm(go, EPI_RESID_GATE, s));
 
-        RC(K.ln_modulate(c.p<float>(w.x), m6 + 4 * D, m6 + 3 * D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+        if (!fused_mlp_ln) RC(K.ln_modulate(c.p<float>(w.x), m6 + 4 * D, m6 + 3 * D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
         F5GemmArgs g1 = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.ff1, M, FF, D, c.a<float>(bw.bff1));
         g1.out_bf[0] = c.pb(w.ffh, 0);
         g1.out_bf[1] = c.pb(w.ffh, 1);
@@ -737,10 +761,12 @@ static int run_dit(const Ctx& c, int j) {
         g2.out_f32 = c.p<float>(w.x);
         g2.ldo = D;
         g2.gate = m6 + 5 * D;
+        // the LN that follows FF2: the next block's attention LN (scale_msa, shift_msa), or the final one (dit.py:287: scale, shift)
+        const float* m6n = m6 + 6 * D;
+        h_ready = (i + 1 < L) ? fuse_ln(g2, m6n + D, m6n) : fuse_ln(g2, mf, mf + D);
         RC(K.gemm(g2, EPI_RESID_GATE, s));
     }
-    const float* mf = mod + (size_t)L * 6 * D;  // (scale, shift) order, dit.py:287
-    RC(K.ln_modulate(c.p<float>(w.x), mf, mf + D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+    if (!h_ready) RC(K.ln_modulate(c.p<float>(w.x), mf, mf + D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
     F5GemmArgs gf = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, e->wout, M, cf.mel_dim, D, c.a<float>(e->bout));
     gf.out_f32 = c.p<float>(w.vel);
     gf.ldo = cf.mel_dim;
@@ -848,7 +874,8 @@ static int stage_inputs(Ctx& c, const f5_sample_args* a, const float* x_override
     // host scalars -> workspace as kernel arguments (no host buffer outlives this call, no host synchronisation)
     const size_t nfe1 = tnfe.empty() ? 1 : tnfe.size();
     std::vector<uint32_t> words(w.scal_words, 0u);
-    F5_REQUIRE(w.scal_words == (size_t)3 * c.B + nfe1 + a->steps + 1 && dts.size() <= (size_t)a->steps, "internal: scalar staging layout");
+    F5_REQUIRE(w.scal_words == (size_t)3 * c.B + nfe1 + a->steps + 1 + w.lncnt_words && dts.size() <= (size_t)a->steps,
+               "internal: scalar staging layout");
     memcpy(words.data(), a->lens, (size_t)c.B * 4);
     for (int b = 0; b < c.B; ++b) words[c.B + b] = words[2 * c.B + b] = (uint32_t)a->durations[b];
     if (!tnfe.empty()) memcpy(words.data() + 3 * c.B, tnfe.data(), tnfe.size() * 4);
@@ -912,8 +939,8 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb, (int)c.use_mask,
-             a->workspace);
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, g_fuse_ln, a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
         // a text-to-speech service sees a new (N, nt) on almost every call and capture + instantiate of ~5000 nodes costs more
@@ -1029,6 +1056,10 @@ extern "C" uint16_t f5_debug_f2bf_bits(float f) { return f5_f2bf_bits(f); }
 extern "C" int f5_debug_set_attn_version(int v) {
     F5_REQUIRE(v >= 1 && v <= 6, "attention version must be 1..6");
     F5_SET_BOTH(f5_attn_version, v);
+    return 0;
+}
+extern "C" int f5_debug_set_ln_fusion(int on) {
+    g_fuse_ln = on ? 1 : 0;       // part of the launch sequence, hence of the graph key
     return 0;
 }
 extern "C" int f5_debug_set_attn_variant(int v) {
@@ -1352,6 +1383,39 @@ extern "C" int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const v
     g.out_f32 = x;
     g.ldo = ldx;
     F5_REQUIRE(gate != nullptr && x != nullptr, "gemm_resid_gate: null gate / x");
+    return g_ops.gemm(g, EPI_RESID_GATE, (hipStream_t)stream);
+}
+// the same with the LN-modulate of the next sub-layer fused behind it (small-tile shapes only, see gemm.hpp ln_counter):
+// h = LN(x_new) * (1 + ln_scale) + ln_shift, bit-identical to f5_op_gemm_resid_gate followed by f5_op_ln_modulate.
+// counters: >= ceil(M / 64) ints, zero on entry (left zero on exit).  Returns an error for shapes that run the large-tile kernels.
+extern "C" int f5_op_gemm_resid_gate_ln(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                                        const float* gate, const uint8_t* rowkeep, float* x, const float* ln_scale,
+                                        const float* ln_shift, void* h_hi, void* h_lo, int* counters, int M, int N, int K, int lda,
+                                        int ldw, int nseg, void* stream) {
+    F5GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = (const op16_t*)a_hi;
+    g.A[1] = (const op16_t*)a_lo;
+    g.W[0] = (const op16_t*)w_hi;
+    g.W[1] = (const op16_t*)w_lo;
+    g.lda = lda;
+    g.ldw = ldw;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.nseg = nseg;
+    g.bias = bias;
+    g.gate = gate;
+    g.rowkeep = rowkeep;
+    g.out_f32 = x;
+    g.ldo = N;
+    g.ln_counter = counters;
+    g.ln_scale = ln_scale;
+    g.ln_shift = ln_shift;
+    g.ln_out[0] = (op16_t*)h_hi;
+    g.ln_out[1] = (op16_t*)h_lo;
+    g.ln_eps = 1e-6f;
+    F5_REQUIRE(gate && x && ln_scale && ln_shift && h_hi && counters, "gemm_resid_gate_ln: null pointer");
     return g_ops.gemm(g, EPI_RESID_GATE, (hipStream_t)stream);
 }
 // out_f32 = A[row % a_row_mod] W^T + addrows[row], out_bf = the same rounded to the operand type (dit.py:250: the per-step

@@ -11,6 +11,7 @@
 // (A_hi,W_lo): products are then exact to ~2^-17 relative, i.e. fp32-class results from bf16 MFMA
 // at 3x the matrix work.
 #include "gemm.hpp"
+#include "lnrow.hpp"
 
 namespace F5_NS {
 
@@ -134,7 +135,11 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                             p.out_f32[(size_t)row * p.ldo + c] = f5_gelu_erf(v);
                         } else if (EPI == EPI_RESID_GATE) {
                             if (keep[r] == 0) v = 0.0f;
-                            p.out_f32[(size_t)row * p.ldo + c] = pre[r][nb] + gcol[nb] * v;
+                            const float xn = pre[r][nb] + gcol[nb] * v;
+                            // fused LN tail: another XCD's workgroup reads these rows back inside this kernel -> agent-scope
+                            // (sc1, write-through) store; the XCDs' L2s are not coherent with each other
+                            if (p.ln_counter) __hip_atomic_store(&p.out_f32[(size_t)row * p.ldo + c], xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else p.out_f32[(size_t)row * p.ldo + c] = xn;
                         } else if (EPI == EPI_ADDROWS) {
                             v += pre[r][nb];
                             p.out_f32[(size_t)row * p.ldo + c] = v;
@@ -151,6 +156,71 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                 }
             }
         }
+    }
+}
+
+// ---- LN-modulate fused behind the residual update (EPI_RESID_GATE of the small-tile kernels, batch-1-sized problems) ------
+// At M = 2*937 every launch is one round of workgroups and costs ~2 us of launch / drain on top of its work, and the
+// stand-alone LN-modulate kernels are 2 of the 7 launches of a DiT block (5.2 us each).  Instead, every workgroup of the
+// residual GEMM publishes its part of x with agent-scope stores, drains them (vmcnt(0)), and bumps the counter of its row
+// block; the workgroup that arrives LAST (no one waits, so no deadlock and no ordering assumption) re-reads the rows with
+// agent-scope (sc1, L2-bypassing) loads -- the other column tiles were written from other XCDs -- and runs the same
+// per-row code as ln_modulate_kernel (lnrow.hpp: identical bits).  It re-arms the counter for the next launch.
+__device__ __forceinline__ f32x4 f5_ld_agent_f32x4(const float* ptr) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+template <int NV>
+__device__ __forceinline__ void resid_ln_rows(const F5GemmArgs& p, int row0, int row1, int wave, int nwaves, int lane) {
+    // RB rows per wave are in flight at a time: the agent-scope loads come from the Infinity Cache / HBM (~1-2 us), a row at a
+    // time the tail of a 64-row block took ~10 us (measured: 88 vs 75 ms per sample); RB = 4 keeps 16 * NV VGPRs live
+    constexpr int RB = 4;
+    for (int rbase = row0 + wave; rbase < row1; rbase += RB * nwaves) {
+        f32x4 v[RB][NV];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int row = rbase + j * nwaves < row1 ? rbase + j * nwaves : row1 - 1;     // clamped rows are loaded, not used
+            const float* xr = p.out_f32 + (size_t)row * p.ldo;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[j][i] = f5_ld_agent_f32x4(xr + i * 256 + lane * 4);
+        }
+        // the loads above are invisible to the compiler's own waitcnt bookkeeping: drain them by hand; every value passes
+        // through an (empty) asm statement behind the wait so that nothing reads it earlier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[j][i])::"memory");
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int row = rbase + j * nwaves;
+            if (row < row1)
+                f5_ln_modulate_row<NV>(v[j], p.ln_scale, p.ln_shift, p.ln_out[0], p.ln_out[1], (size_t)row, lane, p.ln_eps);
+        }
+    }
+}
+// called by EVERY wave of the workgroup (also the K-split groups that took no part in the epilogue) after the epilogue
+__device__ __forceinline__ void resid_ln_tail(const F5GemmArgs& p, int tile_m, int bm_rows, int ntiles_n) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's x stores have reached the coherence point
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(p.ln_counter + tile_m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == ntiles_n - 1;
+        if (last) __hip_atomic_store(p.ln_counter + tile_m, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int row0 = tile_m * bm_rows;
+    const int row1 = row0 + bm_rows < p.M ? row0 + bm_rows : p.M;
+    switch (p.N >> 8) {
+        case 1: resid_ln_rows<1>(p, row0, row1, wave, nwaves, lane); break;
+        case 2: resid_ln_rows<2>(p, row0, row1, wave, nwaves, lane); break;
+        case 3: resid_ln_rows<3>(p, row0, row1, wave, nwaves, lane); break;
+        default: resid_ln_rows<4>(p, row0, row1, wave, nwaves, lane); break;
     }
 }
 
@@ -296,6 +366,7 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
         return;
     }
     gemm_epilogue<EPI, MB, NB>(p, acc, m0, n0, wm, wn, lane);
+    if (EPI == EPI_RESID_GATE && p.ln_counter) resid_ln_tail(p, tm, BMt, (p.N + BNt - 1) / BNt);
 }
 
 // =================================================================================================
@@ -1084,7 +1155,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
                     for (int e = 0; e < 16; ++e) dst[((mb * NB + nb) * 16 + e) * 64] = acc[mb][nb][e];
         }
         __syncthreads();
-        if (grp > 0) return;
+        if (grp > 0) {
+            if (EPI == EPI_RESID_GATE && p.ln_counter) resid_ln_tail(p, tm, BMt, (p.N + BNt - 1) / BNt);
+            return;
+        }
 #pragma unroll
         for (int g = 1; g < KS; ++g) {
             const float* src = red + (size_t)((g - 1) * (WM * WN) + wave) * RED + lane;
@@ -1104,6 +1178,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
         return;
     }
     gemm_epilogue<EPI, MB, NB>(p, acc, m0, n0, wm, wn, lane);
+    if (EPI == EPI_RESID_GATE && p.ln_counter) resid_ln_tail(p, tm, BMt, (p.N + BNt - 1) / BNt);
 }
 
 template <int EPI, int MB, int NB>
@@ -1662,8 +1737,23 @@ int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4
 int f5_gemm_debug_flags = 0;
 int f5_gemm_big_kernel = 2;       // auto mode, large shapes: 2 = 256x256 (1 WG/CU), 3 = 128x256 (2 WG/CU, overlapped epilogue)
 int f5_gemm_ring_default = 1;   // auto mode: small tiles use the global_load_lds ring kernel
+// the large-shape kernels (256x256, 128x256) have no fused LN tail (at those sizes LN-modulate is HBM-bound, not launch-bound)
+static bool gemm_uses_big_kernel(const F5GemmArgs& a) {
+    const long t256 = (long)f5_cdiv(a.M, 256) * (a.N / 256);
+    const bool v2ok = (a.N % 256 == 0) && (a.M >= 256);
+    const int sel = f5_gemm_tile_override;
+    return sel == 7 || sel == 4 || (sel == 0 && v2ok && t256 >= 512);
+}
+bool f5_gemm_resid_ln_fusable(const F5GemmArgs& a) {
+    return !gemm_uses_big_kernel(a) && a.N % 256 == 0 && a.N >= 256 && a.N <= 1024 && a.ldo == a.N && a.M <= 64 * 65536;
+}
+
 template <int EPI>
 static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
+    if (a.ln_counter) {
+        F5_REQUIRE(EPI == EPI_RESID_GATE && f5_gemm_resid_ln_fusable(a) && a.ln_scale && a.ln_shift && a.ln_out[0],
+                   "gemm: the fused LN tail needs EPI_RESID_GATE on a small-tile shape (f5_gemm_resid_ln_fusable) and ln_* set");
+    }
     const long t128 = (long)f5_cdiv(a.M, 128) * f5_cdiv(a.N, 128);
     const long t64x128 = (long)f5_cdiv(a.M, 64) * f5_cdiv(a.N, 128);
     int sel = f5_gemm_tile_override;

@@ -41,6 +41,15 @@ struct F5GemmArgs {
     int seq_len, npad, heads, dmodel;
     op16_t* vt[2];            // [B*heads][64][npad]
     int debug_flags;          // bit 0: skip the epilogue (timing experiments only)
+    // ---- EPI_RESID_GATE only, small-tile kernels only (f5_gemm_resid_ln_fusable): LN-modulate of the NEXT sub-layer fused
+    // behind the residual update.  The workgroup that completes a row block (last of its tiles_n column tiles to finish, found
+    // with one agent-scope atomic counter per row block) re-reads the block's rows of x and writes
+    // ln_out = LN(x) * (1 + ln_scale) + ln_shift.  Needs N == ldo == the LN width (256 / 512 / 768 / 1024).
+    int* ln_counter;          // [>= ceil(M / 64)] ints, zero before the first launch (self re-arming), or null = not fused
+    const float* ln_scale;    // [N]
+    const float* ln_shift;    // [N]
+    op16_t* ln_out[2];        // hi, lo (lo may be null): [M][N]
+    float ln_eps;
     // ---- MX-fp8 path (f5_launch_gemm_f8): e4m3 operands with one E8M0 scale per 32 consecutive K elements
     const uint8_t* A8;        // [a_rows][lda8] bytes
     const uint8_t* W8;        // [>=ceil256(N)][ldw8] bytes
@@ -53,6 +62,8 @@ struct F5GemmArgs {
 };
 
 int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
+// true when f5_launch_gemm(a, EPI_RESID_GATE) would run a small-tile kernel that implements the fused LN tail (a.ln_* unset or set)
+bool f5_gemm_resid_ln_fusable(const F5GemmArgs& a);
 
 // stream-K schedule of the 256x256 kernel (large shapes): device scratch for partial tiles; must be initialised outside of a
 // stream capture (engine creation does it).  f5_gemm_streamk_error() != 0 means a consumer timed out (results invalid).

@@ -50,6 +50,9 @@ struct Ops {
     int gemm(const F5GemmArgs& a, int epi, hipStream_t s) const {
         return h ? f5hf::f5_launch_gemm(reinterpret_cast<const f5hf::F5GemmArgs&>(a), epi, s) : f5bf::f5_launch_gemm(a, epi, s);
     }
+    bool gemm_resid_ln_fusable(const F5GemmArgs& a) const {
+        return h ? f5hf::f5_gemm_resid_ln_fusable(reinterpret_cast<const f5hf::F5GemmArgs&>(a)) : f5bf::f5_gemm_resid_ln_fusable(a);
+    }
     int attention(const F5AttnArgs& a, hipStream_t s) const {
         return h ? f5hf::f5_launch_attention(reinterpret_cast<const f5hf::F5AttnArgs&>(a), s) : f5bf::f5_launch_attention(a, s);
     }

@@ -2,6 +2,7 @@
 // Everything here is fp32 arithmetic; bf16 only appears as the (hi, lo) operand encoding handed to
 // the MFMA kernels.  Loads/stores are 16 B per lane wherever the layout allows it.
 #include "rowops.hpp"
+#include "lnrow.hpp"
 
 namespace F5_NS {
 
@@ -18,36 +19,9 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     if (row >= rows) return;
     const float* xr = x + (size_t)row * DIM;
     f32x4 v[NV];
-    float sum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
-        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    }
-    const float mean = f5_wave_sum(sum) * (1.0f / DIM);
-    float sq = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = v[i][e] - mean;
-            sq += d * d;
-        }
-    const float var = f5_wave_sum(sq) * (1.0f / DIM);
-    const float rstd = rsqrtf(var + eps);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
-        *reinterpret_cast<u32x2*>(out_hi + (size_t)row * DIM + c) = u32x2{f5_pack2(y[0], y[1]), f5_pack2(y[2], y[3])};
-        if (out_lo)
-            *reinterpret_cast<u32x2*>(out_lo + (size_t)row * DIM + c) =
-                u32x2{f5_pack2_lo(y[0], y[1]), f5_pack2_lo(y[2], y[3])};
-    }
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+    f5_ln_modulate_row<NV>(v, scale, shift, out_hi, out_lo, (size_t)row, lane, eps);
 }
 
 int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, op16_t* out_hi, op16_t* out_lo,

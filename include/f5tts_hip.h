@@ -172,6 +172,13 @@ int f5_op_cfg_axpy(const float* pred, const float* null_pred, float cfg, const f
 int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                           const float* gate, const uint8_t* rowkeep, float* x, int M, int N, int K, int lda, int ldw, int ldx,
                           int nseg, void* stream);
+/* the same with the LN-modulate that follows it in a DiT block (dit.py:321 after :319; the next block's dit.py:270 after :323)
+ * fused into the launch: h = LN(x_new) * (1 + ln_scale) + ln_shift, bit-identical to f5_op_gemm_resid_gate followed by
+ * f5_op_ln_modulate.  Small-tile shapes only (batch-1-sized M; an error otherwise); N = 256 / 512 / 768 / 1024, x is [M][N];
+ * counters: >= ceil(M / 64) ints, zero on entry, zero again on exit. */
+int f5_op_gemm_resid_gate_ln(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                             const float* gate, const uint8_t* rowkeep, float* x, const float* ln_scale, const float* ln_shift,
+                             void* h_hi, void* h_lo, int* counters, int M, int N, int K, int lda, int ldw, int nseg, void* stream);
 /* out_f32 = A[row % a_row_mod] W^T + addrows[row]; (out_hi, out_lo) = the same as 16-bit operands: the split input projection of
  * InputEmbedding (dit.py:250), x part per step + hoisted cond / text part, x rows shared by the two CFG branches */
 int f5_op_gemm_addrows(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* addrows,
@@ -217,6 +224,7 @@ int f5_debug_gemm_streamk_error(void);
 /* 1 = register-staged attention kernel, 2 = global_load_lds ring (default) */
 int f5_debug_set_attn_version(int v);
 /* timing-only ablations of the attention kernel (results are wrong unless 0) */
+int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the residual GEMMs of small-M launches (default 0: measured slower) */
 int f5_debug_set_attn_variant(int bits);   /* experiment bits of attention versions 5 / 6 (see attention.hip) */
 int f5_debug_set_attn_ablation(int v);
 /* 256-query workgroups with two query blocks per wave (bf16, large grids): -1 auto, 0 off, 1 force */

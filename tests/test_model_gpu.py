@@ -195,6 +195,33 @@ def test_graph_replay_with_changed_cfg(tiny_bf16):
     assert torch.equal(got[0], eager[2.0]) and torch.equal(got[1], eager[3.0]) and torch.equal(got[2], eager[2.0])
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16x3"])
+def test_fused_ln_tail_equals_separate_ln_launches(tiny_weights, prec):
+    """LN-modulate fused behind the residual GEMMs (small-M launches) must not change a single bit of sample():
+    ragged masked batch and batch 1, eager and graph, tiny configuration; the 335M / N = 937 shapes are covered per op
+    (test_gemm_resid_gate_fused_ln_is_bit_identical).  The fusion is off by default (measured slower)."""
+    lib = E.load_library()
+    cfg = TINY
+    m = _model(cfg, tiny_weights, prec)
+    f5 = F5TTS(transformer=m)
+    for B, N, ragged in ((2, 72, True), (1, 130, False)):
+        cond, text, durations, y0 = synth_inputs(cfg, B, N, nt=16, n_ref=20, seed=B + N, ragged=ragged)
+        kw = dict(duration=torch.tensor(durations), steps=4, method="midpoint", y0=y0)
+        got = {}
+        for on in (1, 0):
+            E.check(lib.f5_debug_set_ln_fusion(on))
+            try:
+                got[on] = [f5.sample(cond, text, use_graph=g, **kw) for g in (False, True)]
+                torch.cuda.synchronize()
+                got[on] = [(o.clone(), t.clone()) for o, t in got[on]]
+            finally:
+                E.check(lib.f5_debug_set_ln_fusion(0))
+        for (o1, t1), (o0, t0) in zip(got[1], got[0]):
+            assert torch.isfinite(o1).all()
+            assert torch.equal(o1, o0) and torch.equal(t1, t0)
+        assert torch.equal(got[1][0][0], got[1][1][0])           # graph == eager
+
+
 def test_graph_cache_is_bounded_and_auto_mode(tiny_weights):
     """At most `set_graph_cache(n)` graph executables are kept (LRU); "auto" runs a new signature eagerly and captures it on
     its second sighting; every variant returns the eager bits."""

@@ -559,6 +559,65 @@ def test_gemm_addrows(lib, tile, nseg):
         E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+@pytest.mark.parametrize("nseg", [1, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 9, 10, 11])
+def test_gemm_resid_gate_fused_ln_is_bit_identical(lib, tile, nseg):
+    """LN-modulate fused behind the residual GEMM (the last-arriving workgroup of a row block runs it, dit.py:319-321 in one
+    launch): x and h must equal, bit for bit, f5_op_gemm_resid_gate followed by f5_op_ln_modulate -- for every small-tile kernel
+    configuration, with row masking, ragged M, all four LN widths, and on a second launch (the counters re-arm themselves)."""
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        for (M, N, K) in ((1874, 1024, 1024), (1874, 1024, 2048), (937, 1024, 1024), (333, 512, 192), (70, 256, 64), (129, 768, 128)):
+            if tile == 9 and N % 128:
+                continue
+            r = rng(M + N + K + tile + nseg)
+            a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+            gate, scale, shift = randn(r, N, scale=0.5), randn(r, N, scale=0.3), randn(r, N, scale=0.3)
+            x0 = randn(r, M, N, scale=2.0)
+            keep = (torch.from_numpy(r.random(M)) > 0.2).to(torch.uint8)
+            a_hi, a_lo = split_bf16(a.to(DEV))
+            w_hi, w_lo = split_bf16(w.to(DEV))
+            lo = (lambda t: t) if nseg == 3 else (lambda t: None)
+            dv = lambda t: t.to(DEV).contiguous()
+            bias_d, gate_d, scale_d, shift_d, keep_d = dv(bias), dv(gate), dv(scale), dv(shift), dv(keep)
+            # reference: two launches
+            x_ref = dv(x0)
+            h_ref = torch.zeros((M, N), dtype=op_dtype(), device=DEV)
+            h_ref_lo = torch.zeros_like(h_ref)
+            E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(lo(a_lo)), P(w_hi), P(lo(w_lo)), P(bias_d), P(gate_d), P(keep_d), P(x_ref), M, N, K,
+                                              K, K, N, nseg, stream()), "gemm_resid_gate")
+            E.check(lib.f5_op_ln_modulate(P(x_ref), P(scale_d), P(shift_d), P(h_ref), P(lo(h_ref_lo)), M, N, stream()), "ln_modulate")
+            sync()
+            counters = torch.zeros((M + 63) // 64 + 8, dtype=torch.int32, device=DEV)
+            for rep in range(2):
+                x = dv(x0)
+                h = torch.full((M, N), 7.0, dtype=op_dtype(), device=DEV)
+                h_lo = torch.full_like(h, 7.0)
+                E.check(lib.f5_op_gemm_resid_gate_ln(P(a_hi), P(lo(a_lo)), P(w_hi), P(lo(w_lo)), P(bias_d), P(gate_d), P(keep_d), P(x),
+                                                     P(scale_d), P(shift_d), P(h), P(lo(h_lo)), P(counters), M, N, K, K, K, nseg, stream()),
+                        "gemm_resid_gate_ln")
+                sync()
+                assert torch.equal(x, x_ref), f"x differs (tile {tile}, {M}x{N}x{K}, launch {rep})"
+                assert torch.equal(h.view(torch.int16), h_ref.view(torch.int16)), f"h differs (tile {tile}, {M}x{N}x{K}, launch {rep})"
+                if nseg == 3:
+                    assert torch.equal(h_lo.view(torch.int16), h_ref_lo.view(torch.int16))
+                assert int(counters.abs().sum()) == 0, "row-block counters must re-arm"
+        # a shape that runs the 256x256 kernel has no fused tail: the call must fail loudly, not skip the LN
+        if tile == 0:
+            M, N, K = 40000, 1024, 64
+            z16 = torch.zeros((M, K), dtype=op_dtype(), device=DEV)
+            w16 = torch.zeros((N, K), dtype=op_dtype(), device=DEV)
+            v = torch.zeros(N, device=DEV)
+            x = torch.zeros((M, N), device=DEV)
+            h = torch.zeros((M, N), dtype=op_dtype(), device=DEV)
+            cnt = torch.zeros(1024, dtype=torch.int32, device=DEV)
+            rc = lib.f5_op_gemm_resid_gate_ln(P(z16), P(None), P(w16), P(None), P(v), P(v), P(None), P(x), P(v), P(v), P(h), P(None), P(cnt),
+                                              M, N, K, K, K, 1, stream())
+            assert rc != 0 and b"fused LN" in lib.f5_last_error()
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 5, 6])
 def test_gemm_all_small_tile_kernels(lib, tile):
     """every block-tile variant (register-staged 128x128 / 64x128 / 64x64 and the global_load_lds ring 64x128 / 64x64)"""
