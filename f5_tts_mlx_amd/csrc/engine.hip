@@ -1033,6 +1033,8 @@ extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float
 #define F5_SET_BOTH(v, x) do { f5bf::v = (x); f5hf::v = (x); } while (0)
 F5_DECL_KNOB(f5_attn_version)
 F5_DECL_KNOB(f5_attn_ablation)
+F5_DECL_KNOB(f5_convpos_tps)
+F5_DECL_KNOB(f5_convpos_xcd_map)
 F5_DECL_KNOB(f5_attn_variant)
 F5_DECL_KNOB(f5_attn_wide)
 F5_DECL_KNOB(f5_attn_kvsplit)
@@ -1056,6 +1058,15 @@ extern "C" uint16_t f5_debug_f2bf_bits(float f) { return f5_f2bf_bits(f); }
 extern "C" int f5_debug_set_attn_version(int v) {
     F5_REQUIRE(v >= 1 && v <= 6, "attention version must be 1..6");
     F5_SET_BOTH(f5_attn_version, v);
+    return 0;
+}
+extern "C" int f5_debug_set_convpos_tps(int v) {
+    F5_REQUIRE(v == 0 || v == 1 || v == 2 || v == 4, "conv-pos taps per pipeline step must be 0 (auto), 1, 2 or 4");
+    F5_SET_BOTH(f5_convpos_tps, v);
+    return 0;
+}
+extern "C" int f5_debug_set_convpos_xcd_map(int on) {
+    F5_SET_BOTH(f5_convpos_xcd_map, on ? 1 : 0);
     return 0;
 }
 extern "C" int f5_debug_set_ln_fusion(int on) {

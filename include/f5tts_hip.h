@@ -224,6 +224,8 @@ int f5_debug_gemm_streamk_error(void);
 /* 1 = register-staged attention kernel, 2 = global_load_lds ring (default) */
 int f5_debug_set_attn_version(int v);
 /* timing-only ablations of the attention kernel (results are wrong unless 0) */
+int f5_debug_set_convpos_tps(int taps);     /* conv-pos kernel: weight slabs per pipeline step, 0 = auto (4 for small grids), 1 / 2 / 4 */
+int f5_debug_set_convpos_xcd_map(int on);   /* conv-pos kernel: 1 (default) = groups dealt to XCDs, 0 = plain 3-D block numbering */
 int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the residual GEMMs of small-M launches (default 0: measured slower) */
 int f5_debug_set_attn_variant(int bits);   /* experiment bits of attention versions 5 / 6 (see attention.hip) */
 int f5_debug_set_attn_ablation(int v);

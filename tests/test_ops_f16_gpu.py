@@ -71,9 +71,10 @@ def test_attention_pipelined_kernel_ragged_f16(lib):
     T.test_attention_pipelined_kernel_ragged_and_batched(lib, 5)
 
 
+@pytest.mark.parametrize("tps", [0, 1, 2])
 @pytest.mark.parametrize("B,N,C", [(2, 130, 256), (1, 937, 1024)])
-def test_convpos_f16(lib, B, N, C):
-    T.test_convpos(lib, B, N, C, 1)
+def test_convpos_f16(lib, B, N, C, tps):
+    T.test_convpos(lib, B, N, C, 31, 1, tps)
 
 
 @pytest.mark.parametrize("rows,dim", [(5, 512), (937, 1024)])
@@ -83,6 +84,11 @@ def test_ln_modulate_f16(lib, rows, dim):
 
 def test_dwconv_ln_f16(lib):
     T.test_dwconv_ln(lib, 2, 100, 512)
+
+
+@pytest.mark.parametrize("tile", [0, 2, 10])
+def test_gemm_resid_gate_fused_ln_f16(lib, tile):
+    T.test_gemm_resid_gate_fused_ln_is_bit_identical(lib, tile, 1)
 
 
 @pytest.mark.parametrize("tile", [0, 4, 8, 10])

@@ -224,11 +224,22 @@ def test_attention_softmax_spike(lib, hp=1):
 # ------------------------------------------------------------------------------------------------
 # conv position embedding
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,N,C", [(1, 50, 128), (2, 130, 256), (1, 937, 1024)])
+@pytest.mark.parametrize("B,N,C,taps", [(1, 50, 128, 31), (2, 130, 256, 31), (1, 937, 1024, 31), (2, 200, 128, 5)])
 @pytest.mark.parametrize("nseg", [1, 3])
-def test_convpos(lib, B, N, C, nseg):
+@pytest.mark.parametrize("tps", [0, 1, 2, 4])
+def test_convpos(lib, B, N, C, taps, nseg, tps):
+    """tps: weight slabs (taps) per pipeline step of the kernel -- 0 = the launcher's choice, 1 / 2 / 4 forced (31 and 5 taps are
+    not multiples of 2 or 4: the last step is partial)"""
+    E.check(lib.f5_debug_set_convpos_tps(tps))
+    try:
+        _convpos_case(lib, B, N, C, taps, nseg)
+    finally:
+        E.check(lib.f5_debug_set_convpos_tps(0))
+
+
+def _convpos_case(lib, B, N, C, taps, nseg):
     r = rng(N + C)
-    G, taps = C // 64, 31
+    G = C // 64
     x = randn(r, B, N, C)
     w = randn(r, C, taps, 64, scale=(taps * 64) ** -0.5)     # reference layout (out, k, in/groups)
     bias = randn(r, C, scale=0.1)

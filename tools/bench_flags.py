@@ -15,6 +15,8 @@ for kv in args[:split]:
     elif k == "ring": lib.f5_debug_set_gemm_ring(v)
     elif k == "wide": lib.f5_debug_set_attn_wide(v)
     elif k == "kvsplit": lib.f5_debug_set_attn_kvsplit(v)
+    elif k == "cptps": lib.f5_debug_set_convpos_tps(v)
+    elif k == "cpxcd": lib.f5_debug_set_convpos_xcd_map(v)
     elif k == "lnfuse": lib.f5_debug_set_ln_fusion(v)
     elif k == "attnvar": lib.f5_debug_set_attn_variant(v)
     elif k == "streamk": lib.f5_debug_set_gemm_streamk(v)
