@@ -1044,6 +1044,7 @@ F5_DECL_KNOB(f5_gemm_v3_stagger)
 F5_DECL_KNOB(f5_gemm_v3_prio)
 F5_DECL_KNOB(f5_gemm_ring_default)
 F5_DECL_KNOB(f5_gemm_order)
+F5_DECL_KNOB(f5_gemm_nband)
 F5_DECL_KNOB(f5_gemm_debug_flags)
 F5_DECL_KNOB(f5_gemm_tile_override)
 extern "C" int f5_op_set_operand_type(int fp16) {
@@ -1111,6 +1112,11 @@ extern "C" int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles) {
     F5_REQUIRE(v == 2 || v == 3, "big GEMM kernel must be 2 (256x256) or 3 (128x256, two workgroups per CU)");
     F5_SET_BOTH(f5_gemm_big_kernel, v);
     F5_SET_BOTH(f5_gemm_v3_stagger, stagger_cycles);
+    return 0;
+}
+extern "C" int f5_debug_set_gemm_nband(int v) {
+    F5_REQUIRE(v >= 0 && v <= 16, "column-tile band width of the 256x256 tile numbering must be 0 (n fastest) .. 16");
+    F5_SET_BOTH(f5_gemm_nband, v);
     return 0;
 }
 extern "C" int f5_debug_set_gemm_v3_prio(int v) {

@@ -696,7 +696,21 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     if (sp > 0) __syncthreads();                      // the previous span's epilogue staging is done with the LDS
     int ln = lane;                                    // opaque per span: keeps the epilogue / partial-tile address math from
     if (SK) asm volatile("" : "+v"(ln));              // being hoisted out of the span loop (hundreds of spilled VGPRs)
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    // tile -> (tm, tn).  n fastest, or BAND-major when the launcher set p.nband: the column tiles are cut into bands of nband,
+    // a band is walked row by row.  An XCD's contiguous chunk of tiles then stays inside one band: its W panels
+    // (nband x 512 KB at K = 1024) stay resident in the XCD's 4 MB L2 while the A panels stream through once, instead of all
+    // tiles_n W panels being re-fetched for every round of 32 tiles (QKV at M = 59 968: FETCH_SIZE 1.50 GB per launch, 3x the
+    // operand bytes, with n-fastest numbering).
+    int tm, tn;
+    if (p.nband > 0) {
+        const int per_band = (ntiles / tiles_n) * p.nband;          // tiles_m * nband
+        const int band = tile / per_band, r_ = tile - band * per_band;
+        tm = r_ / p.nband;
+        tn = band * p.nband + (r_ - tm * p.nband);
+    } else {
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+    }
     const int m0 = tm * 256, n0 = tn * 256;
 
     // ---- staging addresses: 2 chunks per thread per half tile -----------------------------------
@@ -949,17 +963,21 @@ int f5_gemm_streamk_error() {      // 1 if a consumer ever timed out waiting for
     if (hipMemcpy(&v, g_sk_flag + g_sk_P, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return v;
 }
+int f5_gemm_nband = 4;   // 256x256 kernel: column-tile band width of the tile numbering (0 = n fastest), f5_debug_set_gemm_nband.
+                         // 4 = 2 MB of W per band at K = 1024: sample() at batch 32 1 244 vs 1 260-1 275 ms (profiles/r02/gemm_nband_ab.txt)
 template <int EPI>
 static int launch_v2(const F5GemmArgs& a, hipStream_t stream) {
     F5_REQUIRE((size_t)(a.a_row_mod > 0 ? a.a_row_mod : a.M) * a.lda < (1ull << 31) && (size_t)(a.N + 256) * a.ldw < (1ull << 31),
                "gemm: operands of the 256x256 kernel must stay below 4 GiB (32-bit byte offsets)");
     const int tiles_m = f5_cdiv(a.M, 256), tiles_n = a.N / 256;
     const int ntiles = tiles_m * tiles_n;
+    F5GemmArgs ab = a;
+    ab.nband = (f5_gemm_nband > 0 && tiles_n > f5_gemm_nband && tiles_n % f5_gemm_nband == 0 && !f5_gemm_streamk) ? f5_gemm_nband : 0;
     if (f5_gemm_streamk && g_sk_part && ntiles >= g_sk_P) {
         hipLaunchKernelGGL((f5_gemm256_kernel<EPI, true>), dim3(g_sk_P), dim3(512), 0, stream, a, tiles_n, ntiles, g_sk_part,
                            g_sk_flag, g_sk_flag + g_sk_P, f5_gemm_streamk == 2 ? 1 : 0);
     } else {
-        hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false>), dim3(ntiles), dim3(512), 0, stream, a, tiles_n, ntiles,
+        hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles,
                            (float*)nullptr, (int*)nullptr, (int*)nullptr, 0);
     }
     F5_LAUNCH_CHECK();

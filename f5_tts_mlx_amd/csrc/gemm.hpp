@@ -41,6 +41,7 @@ struct F5GemmArgs {
     int seq_len, npad, heads, dmodel;
     op16_t* vt[2];            // [B*heads][64][npad]
     int debug_flags;          // bit 0: skip the epilogue (timing experiments only)
+    int nband;                // 256x256 kernel: > 0 = tiles numbered band-major, bands of nband column tiles (set by the launcher)
     // ---- EPI_RESID_GATE only, small-tile kernels only (f5_gemm_resid_ln_fusable): LN-modulate of the NEXT sub-layer fused
     // behind the residual update.  The workgroup that completes a row block (last of its tiles_n column tiles to finish, found
     // with one agent-scope atomic counter per row block) re-reads the block's rows of x and writes

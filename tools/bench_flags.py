@@ -17,6 +17,7 @@ for kv in args[:split]:
     elif k == "kvsplit": lib.f5_debug_set_attn_kvsplit(v)
     elif k == "cptps": lib.f5_debug_set_convpos_tps(v)
     elif k == "cpxcd": lib.f5_debug_set_convpos_xcd_map(v)
+    elif k == "nband": lib.f5_debug_set_gemm_nband(v)
     elif k == "lnfuse": lib.f5_debug_set_ln_fusion(v)
     elif k == "attnvar": lib.f5_debug_set_attn_variant(v)
     elif k == "streamk": lib.f5_debug_set_gemm_streamk(v)
