@@ -439,6 +439,26 @@ def force_v2(lib):
     E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+def test_gemm_v2_band_major_tile_numbering(lib, force_v2):
+    """the 256x256 kernel numbers its tiles in bands of 4 column tiles when N has more than 4 of them (QKV: 12, FF1: 8); the
+    numbering must not change a bit of the result (ragged M, 2 and 3 bands, also a band width that does not divide tiles_n)"""
+    for (M, N, K) in ((700, 2048, 128), (1100, 3072, 64), (300, 1536, 192)):
+        r = rng(M + N + K)
+        a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+        outs = []
+        for nband in (0, 4, 2, 5):
+            E.check(lib.f5_debug_set_gemm_nband(nband))
+            try:
+                outs.append(_gemm(lib, a, w, bias, 0, 1)[0])
+            finally:
+                E.check(lib.f5_debug_set_gemm_nband(4))
+        refbf = (bf16r(a).double() @ bf16r(w).double().T) + bias.double()
+        mx, _, _ = report(f"gemm256 band-major {M}x{N}x{K}", outs[1], refbf)
+        assert mx <= 2e-4 * max(1.0, float(refbf.abs().max()))
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 512, 128), (1000, 256, 192), (1874, 1024, 1024), (700, 768, 2048)])
 def test_gemm_v2_f32_out(lib, force_v2, M, N, K):
     r = rng(M + N + K + 1)
