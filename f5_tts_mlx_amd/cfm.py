@@ -19,7 +19,7 @@ import torch
 
 from .audio import MelSpec
 from .dit import DiT
-from .rng import mlx_like_normal
+from .engine import noise_normal
 from .utils import (default, exists, fetch_from_hub, lens_to_mask, list_str_to_idx, list_str_to_tensor,
                     mask_from_frac_lengths)
 from .weights import convert_upstream_weights, dequantize_mlx_checkpoint
@@ -196,14 +196,13 @@ class F5TTS:
         else:  # mx.pad with a negative width raises in the reference
             raise ValueError("duration shorter than the conditioning audio")
 
-        # noise input (cfm.py:369-375): channel-major draw per element, zero padded, "b d n -> b n d"
+        # noise input (cfm.py:369-375): channel-major draw per element, zero padded, "b d n -> b n d" -- drawn on the GPU
+        # (csrc/noise.hip; rng.mlx_like_normal is the host restatement the tests compare it with).  The reference re-seeds with
+        # the same `seed` for every element; without a seed every element gets fresh entropy.
         if y0 is None:
-            rows = []
-            for dur in duration.tolist():
-                s = seed if exists(seed) else int(np.random.SeedSequence().entropy % (1 << 63))
-                z = mlx_like_normal(s, (self.num_channels, int(dur)))
-                rows.append(np.pad(z, ((0, 0), (0, max_duration - int(dur)))))
-            y0 = torch.from_numpy(np.ascontiguousarray(np.stack(rows).transpose(0, 2, 1)))
+            durs = [int(d) for d in duration.tolist()]
+            seeds = [seed if exists(seed) else int(np.random.SeedSequence().entropy % (1 << 63)) for _ in durs]
+            y0 = noise_normal(seeds, durs, max_duration, self.num_channels, device)
         y0 = torch.as_tensor(y0).to(device, torch.float32).contiguous()
         assert y0.shape == (batch, max_duration, self.num_channels)
 

@@ -18,7 +18,7 @@ for f in gemm attention convpos rowops; do
     if stale $f.hip $o 0; then $HIPCC $FLAGS -DF5_F16=$v -c $f.hip -o $o & pids+=($!); fi
   done
 done
-for f in audio vocoder engine; do
+for f in audio vocoder noise engine; do
   o=build/$f.o
   objs+=($o)
   if stale $f.hip $o 1; then $HIPCC $FLAGS -c $f.hip -o $o & pids+=($!); fi

@@ -109,6 +109,24 @@ def stream_ptr(device: torch.device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def noise_normal(seeds: Sequence[int], durations: Sequence[int], N: int, mel: int, device: torch.device) -> torch.Tensor:
+    """Initial noise of F5TTS.sample (cfm.py:369-375) drawn on the GPU: element b is the channel-major draw
+    `mx.random.seed(seeds[b]); mx.random.normal((mel, durations[b]))`, zero padded to N frames -> (B, N, mel) fp32.
+    Same numbers as rng.mlx_like_normal (the host restatement of MLX's published generator; unverifiable against MLX here)."""
+    lib = load_library()
+    B = len(durations)
+    if len(seeds) != B:
+        raise ValueError("one seed per batch element")
+    device = torch.device(device)
+    y0 = torch.empty((B, int(N), int(mel)), dtype=torch.float32, device=device)
+    scratch = torch.empty(3 * B, dtype=torch.int32, device=device)
+    c_seeds = (C.c_uint64 * B)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds])
+    c_durs = (C.c_int32 * B)(*[int(d) for d in durations])
+    with torch.cuda.device(device):
+        check(lib.f5_noise_normal(c_seeds, B, c_durs, int(N), int(mel), ptr(y0), ptr(scratch), stream_ptr(device)), "f5_noise_normal")
+    return y0
+
+
 def to_c_config(cfg: DiTConfig) -> F5Config:
     return F5Config(cfg.dim, cfg.depth, cfg.heads, cfg.dim_head, cfg.ff_dim, cfg.mel_dim, cfg.text_num_embeds, cfg.text_dim,
                     cfg.text_ff_dim, cfg.conv_layers, cfg.conv_pos_kernel, cfg.conv_pos_groups, cfg.freq_embed_dim,

@@ -168,6 +168,14 @@ int f5_op_skinny_gemm(const float* a, const float* w, const float* b, float* out
 int f5_op_cfg_axpy(const float* pred, const float* null_pred, float cfg, const float* base, const float* dt_dev, float coef,
                    float divisor, float* out, void* xin_hi, void* xin_lo, int rows, int mel_dim, void* stream);
 
+/* Initial noise of F5TTS.sample (cfm.py:369-375) on the device: for each batch element the channel-major draw
+ * `mx.random.seed(seed); mx.random.normal((mel, dur))`, zero padded to N frames, laid out [B][N][mel].  The generator follows
+ * the published MLX algorithm as restated in f5_tts_mlx_amd/rng.py (threefry2x32 key split and counters: bit-exact integer path;
+ * float32 uniform mapping step by step; sqrt(2) * erfinv in float64, one final rounding) -- unverifiable against MLX itself here.
+ * seeds: one per element (the reference uses the same seed for all); durations: host; scratch_words: >= 3 * B device words. */
+int f5_noise_normal(const uint64_t* seeds, int B, const int32_t* durations, int N, int mel, float* y0, void* scratch_words,
+                    void* stream);
+
 /* x += gate[col] * ((A W^T + bias) * keep[row])  (dit.py:319,323; also Vocos' layer-scale + residual) */
 int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                           const float* gate, const uint8_t* rowkeep, float* x, int M, int N, int K, int lda, int ldw, int ldx,

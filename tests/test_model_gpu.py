@@ -463,6 +463,32 @@ def test_sample_with_vocoder_and_raw_wave(tiny_x3, tiny_weights):
     assert l1w <= 5e-3 * max(1e-3, refm) + 1e-5
 
 
+def test_device_noise_matches_the_host_generator():
+    """f5_noise_normal (threefry2x32 + float32 uniform mapping + float64 erfinv on the GPU, cfm.py:369-375) against
+    rng.mlx_like_normal: ragged batch, channel-major draw order, zero padding, odd element counts, 64-bit seeds; the same seed
+    for every element gives equal-duration elements identical noise (reference quirk)."""
+    from f5_tts_mlx_amd.engine import noise_normal
+    from f5_tts_mlx_amd.rng import mlx_like_normal
+    mel = 100
+    for seeds, durs, N in (([3, 3, 3], [50, 937, 50], 937), ([0], [1], 4), ([2 ** 40 + 7, 123456789], [333, 2], 400),
+                           ([2 ** 63 - 1], [937], 937)):
+        got = noise_normal(seeds, durs, N, mel, DEV)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        for b, (sd, d) in enumerate(zip(seeds, durs)):
+            ref = mlx_like_normal(sd, (mel, d)).T                             # (dur, mel)
+            g = got[b, :d]
+            assert np.all(got[b, d:] == 0.0)
+            diff = np.abs(g.astype(np.float64) - ref.astype(np.float64))
+            ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+            exact = float(np.mean(g == ref))
+            print(f"[noise] seed {sd} dur {d}: bit-equal fraction {exact:.6f}, max diff {diff.max():.3e}")
+            assert np.all(diff <= ulp) and exact >= 0.999                     # at most a last-place rounding tie apart
+            assert np.isfinite(g).all() and abs(float(g.mean())) < 0.05 + 3.0 / np.sqrt(g.size) and (d * mel < 1000 or abs(float(g.std()) - 1) < 0.05)
+        if len(durs) == 3:
+            assert np.array_equal(got[0, :50], got[2, :50])
+
+
 def test_generate_end_to_end(tiny_weights, tmp_path):
     """generate() control flow with the packaged reference voice: wav -> mel -> sample -> vocoder -> trimmed wave -> file."""
     from f5_tts_mlx_amd import generate as G
