@@ -252,7 +252,7 @@ extern "C" int f5_engine_create(const f5_config* cfg, int precision, f5_engine**
     F5_REQUIRE(c.ff_dim % 128 == 0 && c.text_ff_dim % 128 == 0, "ff dims must be multiples of 128");
     F5_REQUIRE(c.mel_dim >= 1 && c.mel_dim <= 128, "mel_dim must be in [1,128]");
     F5_REQUIRE(c.freq_embed_dim % 256 == 0 && c.freq_embed_dim <= 1024, "freq_embed_dim must be a multiple of 256");
-    F5_REQUIRE(c.depth >= 1 && c.conv_layers >= 1, "depth and conv_layers must be >= 1");
+    F5_REQUIRE(c.depth >= 1 && c.conv_layers >= 0, "depth must be >= 1 and conv_layers >= 0");
     f5_engine* e = new f5_engine();
     e->cfg = c;
     e->prec = precision;
@@ -527,8 +527,10 @@ static int run_prep(const Ctx& c, int nfe) {
     for (int p = 0; p < e->np; ++p) RC(K.zero_vt_pad(c.pb(w.vt, p), (size_t)2 * c.B * cf.heads * 64, c.N, c.npad, s));
 
     // --- text path for both branches (dit.py:196-229, convnext_v2.py:46-54)
-    RC(f5_launch_text_embed(c.p<int>(w.text), c.nt, c.a<float>(e->text_table), c.a<float>(e->text_pos), cf.text_max_pos,
-                            c.p<float>(w.te[0]), c.p<int>(w.ids), c.p<uint8_t>(w.keep), c.B, c.N, Dt, 1, s));
+    // conv_layers == 0 (dit.py:193-194): the plain embedding, no positional table and no masking; text_mask_padding == 0: no masking
+    RC(f5_launch_text_embed(c.p<int>(w.text), c.nt, c.a<float>(e->text_table), cf.conv_layers > 0 ? c.a<float>(e->text_pos) : nullptr,
+                            cf.text_max_pos, c.p<float>(w.te[0]), c.p<int>(w.ids), c.p<uint8_t>(w.keep), c.B, c.N, Dt,
+                            (cf.conv_layers > 0 && cf.text_mask_padding) ? 1 : 0, s));
     int cur = 0;
     for (int i = 0; i < cf.conv_layers; ++i) {
         const TextBlockW& t = e->tblocks[i];

@@ -298,9 +298,8 @@ __global__ __launch_bounds__(128) void text_embed_kernel(const int* __restrict__
     for (int c = threadIdx.x * 4; c < dim; c += 128 * 4) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (keep) {
-            const f32x4 e = *reinterpret_cast<const f32x4*>(table + (size_t)emb_id * dim + c);
-            const f32x4 pe = *reinterpret_cast<const f32x4*>(pos_table + (size_t)pos * dim + c);
-            v = e + pe;
+            v = *reinterpret_cast<const f32x4*>(table + (size_t)emb_id * dim + c);
+            if (pos_table) v = v + *reinterpret_cast<const f32x4*>(pos_table + (size_t)pos * dim + c);   // null: conv_layers == 0
         }
         *reinterpret_cast<f32x4*>(o + c) = v;
     }

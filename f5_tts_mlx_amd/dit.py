@@ -22,15 +22,13 @@ class DiT:
                  device: str | torch.device = "cuda:0"):
         if text_dim is None:
             text_dim = mel_dim
-        if not text_mask_padding:
-            raise NotImplementedError("text_mask_padding=False is not used by the sampling path (cfm.py:468)")
         if dropout != 0.0:
             raise NotImplementedError("dropout is training-only")
-        if conv_layers <= 0:
-            raise NotImplementedError("the engine implements the ConvNeXt text path (conv_layers > 0, cfm.py:466)")
+        if conv_layers < 0:
+            raise ValueError("conv_layers must be >= 0")
         self.cfg = DiTConfig(dim=dim, depth=depth, heads=heads, dim_head=dim_head, ff_mult=ff_mult, mel_dim=mel_dim,
                              text_num_embeds=text_num_embeds, text_dim=text_dim, conv_layers=conv_layers,
-                             conv_pos_groups=dim // 64)
+                             conv_pos_groups=dim // 64, text_mask_padding=bool(text_mask_padding))
         self.dim = dim
         self.depth = depth
         self.precision = precision
@@ -40,8 +38,8 @@ class DiT:
     @classmethod
     def from_config(cls, cfg: DiTConfig, precision="f16", device="cuda:0") -> "DiT":
         m = cls(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, dim_head=cfg.dim_head, ff_mult=cfg.ff_mult, mel_dim=cfg.mel_dim,
-                text_num_embeds=cfg.text_num_embeds, text_dim=cfg.text_dim, conv_layers=cfg.conv_layers, precision=precision,
-                device=device)
+                text_num_embeds=cfg.text_num_embeds, text_dim=cfg.text_dim, conv_layers=cfg.conv_layers,
+                text_mask_padding=getattr(cfg, "text_mask_padding", True), precision=precision, device=device)
         m.cfg = cfg
         return m
 

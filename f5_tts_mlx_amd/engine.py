@@ -50,7 +50,7 @@ class operand_type:
 class F5Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim", "depth", "heads", "dim_head", "ff_dim", "mel_dim", "text_num_embeds", "text_dim", "text_ff_dim",
-        "conv_layers", "conv_pos_kernel", "conv_pos_groups", "freq_embed_dim", "text_max_pos")]
+        "conv_layers", "conv_pos_kernel", "conv_pos_groups", "freq_embed_dim", "text_max_pos", "text_mask_padding")]
 
 
 class F5SampleArgs(C.Structure):
@@ -130,7 +130,7 @@ def noise_normal(seeds: Sequence[int], durations: Sequence[int], N: int, mel: in
 def to_c_config(cfg: DiTConfig) -> F5Config:
     return F5Config(cfg.dim, cfg.depth, cfg.heads, cfg.dim_head, cfg.ff_dim, cfg.mel_dim, cfg.text_num_embeds, cfg.text_dim,
                     cfg.text_ff_dim, cfg.conv_layers, cfg.conv_pos_kernel, cfg.conv_pos_groups, cfg.freq_embed_dim,
-                    cfg.text_max_pos)
+                    cfg.text_max_pos, int(bool(getattr(cfg, "text_mask_padding", True))))
 
 
 def _aligned_bytes(nbytes: int, device: torch.device) -> torch.Tensor:

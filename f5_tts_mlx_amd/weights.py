@@ -38,6 +38,7 @@ class DiTConfig:
     conv_pos_groups: int = 16
     freq_embed_dim: int = 256    # TimestepEmbedding (dit.py:74)
     text_max_pos: int = 4096     # TextEmbedding.precompute_max_pos (dit.py:190)
+    text_mask_padding: bool = True   # TextEmbedding mask_padding (dit.py:182,186): zero filler / padded text positions
 
     @property
     def ff_dim(self) -> int:

@@ -35,11 +35,12 @@ typedef struct f5_config {
     int32_t text_num_embeds; /* 2545 (embedding table has +1 rows, dit.py:184) */
     int32_t text_dim;        /* 512 */
     int32_t text_ff_dim;     /* text_dim * conv_mult = 1024 */
-    int32_t conv_layers;     /* 4 */
+    int32_t conv_layers;     /* 4; 0 = plain embedding: no positional table, no ConvNeXt blocks, no masking (dit.py:188-194) */
     int32_t conv_pos_kernel; /* 31 */
     int32_t conv_pos_groups; /* 16 (dim / groups must be 64) */
     int32_t freq_embed_dim;  /* 256 */
     int32_t text_max_pos;    /* 4096 */
+    int32_t text_mask_padding; /* 1 (dit.py:186): zero the text embedding at filler / padded positions around every text block */
 } f5_config;
 
 /* MFMA operand encoding.  The reference computes in fp32 throughout (dit.py, cfm.py); measured mel-L1 drift of a full 32-point

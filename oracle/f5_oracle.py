@@ -315,10 +315,13 @@ class DiTOracle:
         if self.cfg.conv_layers > 0:
             pos_idx = get_pos_embed_indices(torch.zeros(batch, dtype=torch.int32), seq_len, self.cfg.text_max_pos)
             x = x + self.freqs_cis[pos_idx.to(torch.int64)]                   # :215-218
-            x = torch.where(text_mask, torch.zeros_like(x), x)                # :222
+            mask_padding = bool(getattr(self.cfg, "text_mask_padding", True))      # :186; False -> plain Sequential (:227)
+            if mask_padding:
+                x = torch.where(text_mask, torch.zeros_like(x), x)            # :222
             for i in range(self.cfg.conv_layers):
                 x = self.convnext_block(x, i)
-                x = torch.where(text_mask, torch.zeros_like(x), x)            # :225
+                if mask_padding:
+                    x = torch.where(text_mask, torch.zeros_like(x), x)        # :225
         return x, ids
 
     def conv_pos_embed(self, x: Tensor) -> Tensor:

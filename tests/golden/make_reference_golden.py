@@ -81,7 +81,8 @@ class injected_random:
 
 def build_reference_model(cfg: DiTConfig, weights):
     dit = ref_dit.DiT(dim=cfg.dim, depth=cfg.depth, heads=cfg.heads, dim_head=cfg.dim_head, ff_mult=cfg.ff_mult, mel_dim=cfg.mel_dim,
-                      text_num_embeds=cfg.text_num_embeds, text_dim=cfg.text_dim, text_mask_padding=True, conv_layers=cfg.conv_layers)
+                      text_num_embeds=cfg.text_num_embeds, text_dim=cfg.text_dim,
+                      text_mask_padding=bool(getattr(cfg, "text_mask_padding", True)), conv_layers=cfg.conv_layers)
     model = ref_cfm.F5TTS(transformer=dit)
     model.load_weights(list(weights.items()))
     return model

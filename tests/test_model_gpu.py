@@ -179,6 +179,29 @@ def test_dit_forward_parity_f16(tiny_weights, tiny_f16, B, N, ragged):
             assert mean <= tol * max(1.0, refm)
 
 
+@pytest.mark.parametrize("variant", [dict(conv_layers=0), dict(text_mask_padding=False), dict(conv_layers=0, text_mask_padding=False)])
+def test_dit_text_embedding_variants(variant):
+    """TextEmbedding constructor variants of the reference DiT (dit.py:182-194,226-227): conv_layers=0 (plain embedding: no
+    positional table, no ConvNeXt blocks, no masking) and text_mask_padding=False (blocks without zeroing the filler positions);
+    cond and null branch, ragged masked batch, vs the oracle (itself fuzzed against the reference's code with these variants)."""
+    import dataclasses
+    cfg = dataclasses.replace(TINY, **variant)
+    w = synthetic_weights(cfg, seed=11)
+    B, N = 2, 90
+    cond, text, durations, y0 = synth_inputs(cfg, B, N, nt=20, n_ref=25, seed=4, ragged=True)
+    text[1, 12:] = -1                                            # filler tokens inside the text: where the masking differs
+    step_cond = _pad_cond(cond, N)
+    mask = O.lens_to_mask(torch.tensor(durations), N)
+    orc = O.DiTOracle(cfg, w)
+    m = _model(cfg, w, "bf16x3")
+    for drop in (False, True):
+        ref = orc.forward(y0, step_cond, text, torch.tensor(0.35), drop, drop, mask)
+        got = m(y0, step_cond, text, 0.35, drop, drop, mask)
+        torch.cuda.synchronize()
+        mx_, l1, refm = report(f"DiT forward {variant} drop={drop} [bf16x3]", got.cpu(), ref)
+        assert l1 <= 2e-4 * max(1.0, refm)
+
+
 def test_graph_replay_with_changed_cfg(tiny_bf16):
     """cfg_strength is read from workspace memory staged per call, not frozen into the captured graph: the same shapes with
     guidance 2.0 -> 3.0 -> 2.0 replay ONE cached graph and every result equals the eager run bit for bit."""

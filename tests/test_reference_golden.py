@@ -244,7 +244,7 @@ for case in range(6):
     heads = int(r.choice([2, 4, 8]))
     cfg = M.DiTConfig(dim=64 * heads, depth=int(r.integers(1, 4)), heads=heads, dim_head=64, ff_mult=int(r.choice([2, 4])),
                       mel_dim=100, text_num_embeds=int(r.integers(20, 90)), text_dim=int(r.choice([64, 128])),
-                      conv_layers=int(r.choice([0, 1, 3])), conv_pos_groups=16)
+                      conv_layers=int(r.choice([0, 1, 3])), conv_pos_groups=16, text_mask_padding=bool(case %% 2 == 0))
     w = M.synthetic_weights(cfg, seed=200 + case)
     model = M.build_reference_model(cfg, w)
     orc = O.DiTOracle(cfg, w, dtype=torch.float32)
