@@ -178,6 +178,9 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20):
          f"M={M} N={D} K={FF}", 2 * M * FF + 2 * D * FF + 8 * M * D),
     ]
     out = []
+    import ctypes as C
+    # sample() folds softmax_scale * log2(e) into q in the QKV epilogue (single-segment operand modes); time the same kernels
+    lib.f5_debug_set_op_q_premul(C.c_float(0.125 * 1.4426950408889634 if nseg == 1 else 0.0))
     with E.operand_type(precision):
         k_qkv()                                        # q / k / V^T hold real values before attention is timed
         for key, name, fn, flops, shape, alg_bytes in specs:
@@ -187,6 +190,7 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20):
                             unit="TFLOP/s", frac=ach / BF16_PEAK_TFLOPS, traffic=_pmc_traffic(key, shape, precision),
                             traffic_unit="bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", algorithmic_bytes=alg_bytes,
                             algorithmic_flops=flops))
+    lib.f5_debug_set_op_q_premul(C.c_float(0.0))
     total = sum(k["avg_launch_ms"] for k in out)
     for k in out:
         k["share_of_block"] = k["avg_launch_ms"] / total

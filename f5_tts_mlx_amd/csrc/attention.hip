@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
         o[1][e] = 0.0f;
     }
     float m_run = -INFINITY, l_run = 0.0f;
-    const float c2 = p.scale * 1.4426950408889634f;
+    const float c2 = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
     load_tile(0);
     store_tile(0);
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
         o[1][e] = 0.0f;
     }
     float m_run = -INFINITY, l_run = 0.0f;
-    const float c2 = p.scale * 1.4426950408889634f;
+    const float c2 = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
     A2_ISSUE(0);
     if (NST == 3 && ntile > 1) A2_ISSUE(1);
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
             o[qb][1][e] = 0.0f;
         }
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
-    const float c2 = p.scale * 1.4426950408889634f;
+    const float c2 = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
     const float lazy_margin = 8.0f / c2;                 // raw-score units: exponent of at most 8 in exp2 units
 
     A2W_ISSUE(0);
@@ -739,6 +739,247 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
 }
 
 // =================================================================================================
+// v2f (large grids, default): v2w with the softmax BOOKKEEPING taken off the per-tile path.  MFMA time and VALU time add on a
+// SIMD (tools/probes/coissue.hip), and at head dim 64 a key costs more VALU than MFMA issue time, so every instruction removed
+// from the softmax is kernel time.  Two things go:
+//  (1) the running maximum.  v2w needs max(S) of every tile (32 v_max3 + a cross-lane exchange through the LDS pipe per
+//      query block) only to find out that the reference point m_ref of the exponentials does not have to move.  Here the fast
+//      path never looks at the scores: p = exp2(s - m_ref) is computed unconditionally and the ROW SUMS, which are needed
+//      anyway, tell whether that was safe: if a lane's partial sum of a tile is <= 2^14, every p of it is <= 2^14, inside
+//      half's range with the usual relative rounding; the O / l accumulators are fp32.  Only when some sum is larger (or inf:
+//      a score more than 2^14 above the reference point), and on the first tile, the wave takes the slow path -- recompute
+//      the scores of the tile (K is still in LDS), take the true maximum, move m_ref there, rescale O and l -- which is v2w's
+//      arithmetic.  Softmax is shift invariant, so any reference point gives the same normalised result.
+//  (2) the scale / subtract.  With q pre-multiplied by scale * log2(e) in the QKV epilogue (p.q_prescaled; PRE) the MFMA
+//      result is already in exp2 units, and -m_ref enters as the C operand of the first QK^T MFMA of a block (16 registers per
+//      query block holding the same per-lane value, rewritten only on the slow path): the accumulator leaves the matrix core
+//      as s - m_ref and goes straight into v_exp_f32.  Without PRE the packed fma of v2w stays.
+// Per 64-key tile and wave: 32 MFMAs next to 64 v_exp + 32 v_pk_add + 32 v_cvt_pk (+ 32 v_pk_fma without PRE), against
+// v2w's additional 32 v_max3 + 10 v_max + 2 ds_bpermute round trips + the rescale test.
+// =================================================================================================
+__device__ __forceinline__ attn_f32x2 attn_exp_block_pre(f32x16& s, attn_f32x2 sum2) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        attn_f32x2 t;
+        t[0] = __builtin_amdgcn_exp2f(s[r]);
+        t[1] = __builtin_amdgcn_exp2f(s[r + 1]);
+        s[r] = t[0];
+        s[r + 1] = t[1];
+        sum2 += t;
+    }
+    return sum2;
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void f5_attn2f_kernel(F5AttnArgs p) {
+    constexpr int NST = 3;
+    constexpr int TILE = 64 * 64;
+    __shared__ __attribute__((aligned(16))) op16_t smem[NST * 2 * TILE];   // [stage][K | V^T][64*64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lq = lane & 31;
+    int bh, qblk;
+    if (!attn_block_map(p, 256, bh, qblk)) return;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qblk * 256 + wave * 64;
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
+    const int ntile = (kvlen + 63) >> 6;
+    const size_t rowbase = (size_t)b * p.seq_len;
+
+    op16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = q0 + qb * 32 + lq;
+        if (qr > p.seq_len - 1) qr = p.seq_len - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[qb][ks] = *reinterpret_cast<const op16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+    }
+
+    const op16_t* kptr[2];
+    const op16_t* vptr[2];
+    int krow[2], kcol[2], ldsoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q_ = i * 256 + tid;
+        const int srow = q_ >> 3;
+        const int schunk = (q_ & 7) ^ ((srow >> 1) & 7);
+        krow[i] = attn_kperm(srow);
+        kcol[i] = p.dmodel + h * 64 + schunk * 8;
+        ldsoff[i] = (i * 256 + wave * 64) * 8;
+        kptr[i] = p.qk[0] + (rowbase + krow[i]) * p.ldqk + kcol[i];
+        vptr[i] = p.vt[0] + ((size_t)bh * 64 + srow) * p.npad + schunk * 8;
+    }
+    const size_t kstep = (size_t)64 * p.ldqk;
+#define A2F_ISSUE(j_)                                                                                        \
+    {                                                                                                        \
+        op16_t* st_ = smem + ((j_) % NST) * (2 * TILE);                                                      \
+        const bool tail_ = ((j_) * 64 + 63) > p.seq_len - 1;                                                 \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            const op16_t* ks_ = kptr[i];                                                                     \
+            if (tail_) {                                                                                     \
+                int key_ = (j_) * 64 + krow[i];                                                              \
+                if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                              \
+                ks_ = p.qk[0] + (rowbase + key_) * p.ldqk + kcol[i];                                         \
+            }                                                                                                \
+            attn_glds16(ks_, st_ + ldsoff[i]);                                                               \
+            attn_glds16(vptr[i], st_ + TILE + ldsoff[i]);                                                    \
+            kptr[i] += kstep;                                                                                \
+            vptr[i] += 64;                                                                                   \
+        }                                                                                                    \
+    }
+    // S^T blocks of the current tile for both query blocks; USE_M: accumulate on top of -m_ref (PRE fast path)
+#define A2F_QK(USE_M)                                                                                        \
+    {                                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                   \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                               \
+                const op16x8 a = *reinterpret_cast<const op16x8*>(&sK[attn_swz(kb * 32 + lq, ks * 2 + hi)]); \
+                s[0][kb] = F5_MFMA32(a, qf[0][ks], ks == 0 ? ((USE_M) ? mneg[0] : zero16) : s[0][kb], 0, 0, 0); \
+                s[1][kb] = F5_MFMA32(a, qf[1][ks], ks == 0 ? ((USE_M) ? mneg[1] : zero16) : s[1][kb], 0, 0, 0); \
+            }                                                                                                \
+        }                                                                                                    \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        if (j * 64 + 64 > kvlen) {                                                                           \
+            _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                                 \
+                _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+                        const int key = j * 64 + kb * 32 + 16 * hi + r;                                      \
+                        if (key >= kvlen) s[qb][kb][r] = -INFINITY;                                          \
+                    }                                                                                        \
+        }                                                                                                    \
+    }
+
+    f32x16 o[2][2], mneg[2], zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        zero16[e] = 0.0f;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            o[qb][0][e] = 0.0f;
+            o[qb][1][e] = 0.0f;
+            mneg[qb][e] = 0.0f;
+        }
+    }
+    float m_ref[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};   // m_ref in exp2 units (scores * c2)
+    const float c2 = PRE ? 1.0f : p.scale * 1.4426950408889634f;
+    constexpr float SUM_LIMIT = 16384.0f;
+
+    A2F_ISSUE(0);
+    if (ntile > 1) A2F_ISSUE(1);
+
+    for (int j = 0; j < ntile; ++j) {
+        if (j + 1 < ntile) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + NST - 1 < ntile) A2F_ISSUE(j + NST - 1);
+
+        const op16_t* sK = smem + (j % NST) * (2 * TILE);
+        const op16_t* sV = sK + TILE;
+
+        f32x16 s[2][2];                                   // [query block][key block]
+        float psum[2];
+        bool slow = j == 0;
+        if (!slow) {
+            A2F_QK(PRE);
+            bool bad = false;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                attn_f32x2 ps2 = {0.0f, 0.0f};
+                if (PRE) {
+                    ps2 = attn_exp_block_pre(s[qb][0], ps2);
+                    ps2 = attn_exp_block_pre(s[qb][1], ps2);
+                } else {
+                    ps2 = attn_exp_block(s[qb][0], c2, m_ref[qb], ps2);
+                    ps2 = attn_exp_block(s[qb][1], c2, m_ref[qb], ps2);
+                }
+                psum[qb] = ps2[0] + ps2[1];
+                bad = bad || !(psum[qb] <= SUM_LIMIT);
+            }
+            slow = __any(bad);
+        }
+        if (slow) {                                       // wave-uniform: first tile, or a score far above the reference point
+            A2F_QK(false);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[qb][kb][r]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_ref[qb], tmax * c2);
+                const float alpha = __builtin_amdgcn_exp2f(m_ref[qb] - m_new);
+                m_ref[qb] = m_new;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    o[qb][0][e] *= alpha;
+                    o[qb][1][e] *= alpha;
+                    mneg[qb][e] = -m_new;
+                }
+                attn_f32x2 ps2 = {0.0f, 0.0f};
+                ps2 = attn_exp_block(s[qb][0], c2, m_new, ps2);
+                ps2 = attn_exp_block(s[qb][1], c2, m_new, ps2);
+                psum[qb] = ps2[0] + ps2[1];
+            }
+        }
+        l_run[0] += psum[0];
+        l_run[1] += psum[1];
+
+#pragma unroll
+        for (int ks4 = 0; ks4 < 4; ++ks4) {
+            const int kb = ks4 >> 1, sp = ks4 & 1;
+            op16x8 pb[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                uint32_t pw[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pw[e] = f5_pack2_bounded(s[qb][kb][8 * sp + 2 * e], s[qb][kb][8 * sp + 2 * e + 1]);
+                pb[qb] = __builtin_bit_cast(op16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const op16x8 a = *reinterpret_cast<const op16x8*>(&sV[attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp)]);
+                o[0][db] = F5_MFMA32(a, pb[0], o[0][db], 0, 0, 0);
+                o[1][db] = F5_MFMA32(a, pb[1], o[1][db], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+#undef A2F_ISSUE
+#undef A2F_QK
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qr = q0 + qb * 32 + lq;
+        if (p.out8) {
+            if (qr < p.seq_len) attn_store_f8(p, o[qb], inv, rowbase + qr, h, hi);
+        } else if (qr < p.seq_len) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d = db * 32 + 8 * rg + 4 * hi;
+                    const float v0 = o[qb][db][rg * 4 + 0] * inv, v1 = o[qb][db][rg * 4 + 1] * inv;
+                    const float v2 = o[qb][db][rg * 4 + 2] * inv, v3 = o[qb][db][rg * 4 + 3] * inv;
+                    const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
+                    *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2_bounded(v0, v1), f5_pack2_bounded(v2, v3)};
+                }
+        }
+    }
+}
+
+// =================================================================================================
 // v2s: v2 with the KV range split across KS wave groups INSIDE the workgroup (small batches: B*H*ceil(N/128)
 // workgroups of 4 waves leave the 256 CUs with one wave per SIMD and the whole kernel is one workgroup's latency
 // chain over all KV tiles).  Group g (4 waves, the same 128 queries as the other groups) walks tiles g, g+KS, ...
@@ -746,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
 // 1..KS-1 park (m, l, O^T) in LDS (the rings are dead by then) and group 0 merges them flash-decoding style:
 // m = max m_g, l = sum l_g 2^((m_g-m)c), O = sum O_g 2^((m_g-m)c) — the same numbers as one pass up to fp32 rounding.
 // =================================================================================================
-template <bool HP, int KS, int NST>
+template <bool HP, int KS, int NST, bool FAST = false>
 __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
     constexpr int NP = HP ? 2 : 1;
     constexpr int TILE = 64 * 64;
@@ -829,7 +1070,7 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
         o[1][e] = 0.0f;
     }
     float m_run = -INFINITY, l_run = 0.0f;
-    const float c2 = p.scale * 1.4426950408889634f;
+    const float c2 = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
     if (ntg > 0) A2S_ISSUE(0);
     if (NST == 3 && ntg > 1) A2S_ISSUE(1);
@@ -853,57 +1094,75 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
         const op16_t* sVl = st + (NP - 1) * 2 * TILE + TILE;
 
         f32x16 s[2];
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[kb][e] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = attn_swz(kb * 32 + lq, ks * 2 + hi);
-                const op16x8 a = *reinterpret_cast<const op16x8*>(&sK[off]);
-                s[kb] = F5_MFMA32(a, qf[0][ks], s[kb], 0, 0, 0);
-                if (HP) {
-                    const op16x8 al = *reinterpret_cast<const op16x8*>(&sKl[off]);
-                    s[kb] = F5_MFMA32(al, qf[0][ks], s[kb], 0, 0, 0);
-                    s[kb] = F5_MFMA32(a, qf[NP - 1][ks], s[kb], 0, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-
         const int key0 = (jj * KS + grp) * 64;
-        if (key0 + 64 > kvlen) {
+        // scores of the tile (raw units) with the key-padding tail masked
+#define A2S_QK()                                                                                             \
+        {                                                                                                    \
+            __builtin_amdgcn_s_setprio(1);                                                                   \
+            _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                               \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) s[kb][e] = 0.0f;                              \
+                _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                           \
+                    const int off = attn_swz(kb * 32 + lq, ks * 2 + hi);                                     \
+                    const op16x8 a = *reinterpret_cast<const op16x8*>(&sK[off]);                             \
+                    s[kb] = F5_MFMA32(a, qf[0][ks], s[kb], 0, 0, 0);                                         \
+                    if (HP) {                                                                                \
+                        const op16x8 al = *reinterpret_cast<const op16x8*>(&sKl[off]);                       \
+                        s[kb] = F5_MFMA32(al, qf[0][ks], s[kb], 0, 0, 0);                                    \
+                        s[kb] = F5_MFMA32(a, qf[NP - 1][ks], s[kb], 0, 0, 0);                                \
+                    }                                                                                        \
+                }                                                                                            \
+            }                                                                                                \
+            __builtin_amdgcn_s_setprio(0);                                                                   \
+            if (key0 + 64 > kvlen) {                                                                         \
+                _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+                        const int key = key0 + kb * 32 + 16 * hi + r;                                        \
+                        if (key >= kvlen) s[kb][r] = -INFINITY;                                              \
+                    }                                                                                        \
+            }                                                                                                \
+        }
+        A2S_QK();
+        // FAST (see f5_attn2f_kernel): after a group's first tile the exponentials are taken against the standing reference point
+        // m_run without looking for the tile maximum -- at this grid size the kernel is one workgroup's latency chain, and
+        // max -> cross-lane exchange (an LDS round trip) -> rescale test sits in front of every tile's exponentials.  The row
+        // sums tell whether that was safe (every p <= 2^14); if not, the tile is redone the slow way.
+        float psum = 0.0f;
+        bool slow = !FAST || HP || jj == 0;
+        if (!slow) {
+            const float mc = m_run * c2;
+            attn_f32x2 ps2 = {0.0f, 0.0f};
+            ps2 = attn_exp_block(s[0], c2, mc, ps2);
+            ps2 = attn_exp_block(s[1], c2, mc, ps2);
+            psum = ps2[0] + ps2[1];
+            slow = __any(!(psum <= 16384.0f));
+            if (slow) A2S_QK();
+        }
+        if (slow) {
+            float tmax = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + kb * 32 + 16 * hi + r;
-                    if (key >= kvlen) s[kb][r] = -INFINITY;
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m_run)) {
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    o[0][e] *= alpha;
+                    o[1][e] *= alpha;
                 }
-        }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        if (__any(tmax > m_run)) {
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                o[0][e] *= alpha;
-                o[1][e] *= alpha;
             }
+            const float mc = m_run * c2;
+            attn_f32x2 ps2 = {0.0f, 0.0f};
+            ps2 = attn_exp_block(s[0], c2, mc, ps2);
+            ps2 = attn_exp_block(s[1], c2, mc, ps2);
+            psum = ps2[0] + ps2[1];
         }
-        const float mc = m_run * c2;
-        attn_f32x2 ps2 = {0.0f, 0.0f};
-        ps2 = attn_exp_block(s[0], c2, mc, ps2);
-        ps2 = attn_exp_block(s[1], c2, mc, ps2);
-        l_run += ps2[0] + ps2[1];
+        l_run += psum;
+#undef A2S_QK
 
 #pragma unroll
         for (int ks4 = 0; ks4 < 4; ++ks4) {
@@ -1090,7 +1349,7 @@ __global__ __launch_bounds__(256, WPS) void f5_attn3_kernel(F5AttnArgs p) {
         o[1][e] = 0.0f;
     }
     float m_run = -INFINITY, l_run = 0.0f;
-    const float c2 = p.scale * 1.4426950408889634f;
+    const float c2 = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
     A3_ISSUE(0);
     if (ntile > 1) {
@@ -1414,7 +1673,7 @@ __global__ __launch_bounds__(64 * NW, 2) void f5_attn5_kernel(F5AttnArgs p) {
     }
     uint32_t pk_a[16], pk_b[16];
     float m_run = -INFINITY, l_run = 0.0f;
-    const float c2 = p.scale * 1.4426950408889634f;
+    const float c2 = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 
     // ---- prologue: K(0..2), V^T(0); S(0) = K(0) Q^T
     issue_k(0);
@@ -1563,7 +1822,10 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     if (f5_attn_version == 2 && f5_attn_ablation == 0 && !a.hp && ks <= 1 &&
         (f5_attn_wide >= 1 || (f5_attn_wide < 0 && (long)f5_cdiv(a.seq_len, 256) * a.B * a.H >= 512))) {
         const dim3 gw = attn_grid(a, 256);
-        if (f5_attn_prio == 1) hipLaunchKernelGGL(f5_attn2w_kernel<1>, gw, dim3(256), 0, stream, a);
+        if (f5_attn_prio == 0 && !(f5_attn_variant & (8 | 16))) {      // default: no per-tile maximum (variant bit 4 = 16: v2w)
+            if (a.q_prescaled) hipLaunchKernelGGL(f5_attn2f_kernel<true>, gw, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(f5_attn2f_kernel<false>, gw, dim3(256), 0, stream, a);
+        } else if (f5_attn_prio == 1) hipLaunchKernelGGL(f5_attn2w_kernel<1>, gw, dim3(256), 0, stream, a);
         else if (f5_attn_prio == 2) hipLaunchKernelGGL(f5_attn2w_kernel<2>, gw, dim3(256), 0, stream, a);
         else if (f5_attn_variant & 8) hipLaunchKernelGGL((f5_attn2w_kernel<0, false>), gw, dim3(256), 0, stream, a);   // A/B: eager rescale
         else hipLaunchKernelGGL(f5_attn2w_kernel<0>, gw, dim3(256), 0, stream, a);
@@ -1574,10 +1836,13 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
         if (a.hp) {
             F5_REQUIRE(a.qk[1] && a.vt[1] && a.out[1], "attention: bf16x3 needs lo buffers");
             hipLaunchKernelGGL((f5_attn2s_kernel<true, 2, 2>), grid, dim3(512), 0, stream, a);
+        } else if (f5_attn_variant & 16) {               // A/B: tile maximum on every tile
+            if (ks >= 4) hipLaunchKernelGGL((f5_attn2s_kernel<false, 4, 2>), grid, dim3(1024), 0, stream, a);
+            else hipLaunchKernelGGL((f5_attn2s_kernel<false, 2, 3>), grid, dim3(512), 0, stream, a);
         } else if (ks >= 4) {
-            hipLaunchKernelGGL((f5_attn2s_kernel<false, 4, 2>), grid, dim3(1024), 0, stream, a);
+            hipLaunchKernelGGL((f5_attn2s_kernel<false, 4, 2, true>), grid, dim3(1024), 0, stream, a);
         } else {
-            hipLaunchKernelGGL((f5_attn2s_kernel<false, 2, 3>), grid, dim3(512), 0, stream, a);
+            hipLaunchKernelGGL((f5_attn2s_kernel<false, 2, 3, true>), grid, dim3(512), 0, stream, a);
         }
         F5_LAUNCH_CHECK();
         return 0;

@@ -24,6 +24,7 @@ struct F5AttnArgs {
     int B, H, seq_len, npad, ldqk, ldo, dmodel;
     int hp;               // 0 bf16, 1 bf16x3
     float scale;
+    int q_prescaled;      // 1: q was multiplied by scale * log2(e) before rounding (QKV epilogue, F5GemmArgs::q_premul): scores are in exp2 units
     // MX-fp8 output (bf16 kernels only): e4m3 [B*seq_len][ldo8] + E8M0 [B*seq_len][dmodel/32] (one scale per head half)
     uint8_t* out8;
     uint8_t* out8s;

@@ -566,7 +566,9 @@ static int run_prep(const Ctx& c, int nfe) {
 // default: bit-identical, but measured SLOWER at batch 1 (88.5 / 90.3 ms per sample against 75.1 / 78.6 on the same boxes,
 // profiles/r02/ln_fusion_ab.txt): a cross-XCD hand-over inside a kernel is three dependent trips to the memory side (write-through
 // ack, counter atomic, agent-scope re-read: ~10 us per GEMM) where the separate LN launch costs 5.2 us.
+namespace f5hf { extern int f5_gemm_debug_flags; }   // by-value kernel argument (set for both builds together) => graph key
 static int g_fuse_ln = 0;
+static int g_q_premul = 1;       // q pre-multiplied by softmax_scale * log2(e) in the QKV epilogue (see run_dit); by-value kernel arguments => graph key
 static int run_dit(const Ctx& c, int j) {
     const f5_engine* e = c.e;
     const f5_config& cf = e->cfg;
@@ -621,6 +623,10 @@ static int run_dit(const Ctx& c, int j) {
     cp.out_f32 = c.p<float>(w.x);
     RC(K.convpos(cp, s));
 
+    // q leaves the QKV epilogue multiplied by softmax_scale * log2(e) (one rounding, like the unscaled q): the attention kernels
+    // then get their scores in exp2 units straight from the matrix cores (attention.hip v2f).  Single-segment operand modes only;
+    // bf16x3 keeps the unscaled q (hi / lo split of the reference-exact value).  f5_debug_set_q_premul(0) = A/B.
+    const float qpre = (g_q_premul && e->np == 1) ? (1.0f / sqrtf((float)cf.dim_head)) * 1.4426950408889634f : 0.0f;
     for (int i = 0; i < L && e->prec == F5_PREC_MXFP8; ++i) {
         // MX-fp8 block: the four GEMMs run on e4m3 operands with E8M0 block scales (v_mfma_scale_f32_32x32x64_f8f6f4); their A
         // operands are produced directly in that format by the LN kernel, the attention epilogue and the GELU epilogue.
@@ -654,6 +660,7 @@ static int run_dit(const Ctx& c, int j) {
         gq.heads = H;
         gq.dmodel = D;
         gq.vt[0] = c.pb(w.vt, 0);
+        gq.q_premul = qpre;
         RC(f5_launch_gemm_f8(gq, EPI_QKV_ROPE, s));
 
         F5AttnArgs at;
@@ -673,6 +680,7 @@ static int run_dit(const Ctx& c, int j) {
         at.dmodel = D;
         at.hp = 0;
         at.scale = 1.0f / sqrtf((float)cf.dim_head);
+        at.q_prescaled = qpre != 0.0f;
         RC(K.attention(at, s));
 
         F5GemmArgs go = f8args(c.p<uint8_t>(w.ao8), c.p<uint8_t>(w.ao8s), D, bw.o8, D, D, c.a<float>(bw.bo));
@@ -724,6 +732,7 @@ static int run_dit(const Ctx& c, int j) {
         gq.dmodel = D;
         gq.vt[0] = c.pb(w.vt, 0);
         gq.vt[1] = c.pb(w.vt, 1);
+        gq.q_premul = qpre;
         RC(K.gemm(gq, EPI_QKV_ROPE, s));
 
         F5AttnArgs at;
@@ -743,6 +752,7 @@ static int run_dit(const Ctx& c, int j) {
         at.dmodel = D;
         at.hp = e->np == 2;
         at.scale = 1.0f / sqrtf((float)cf.dim_head);
+        at.q_prescaled = qpre != 0.0f;
         RC(K.attention(at, s));
 
         F5GemmArgs go = gemm_base(c, c.pb(w.ao, 0), c.pb(w.ao, 1), D, bw.o, M, D, D, c.a<float>(bw.bo));
@@ -941,8 +951,8 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-             (int)c.use_mask, g_fuse_ln, a->workspace);
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d gf%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, g_fuse_ln, g_q_premul, f5hf::f5_gemm_debug_flags, a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
         // a text-to-speech service sees a new (N, nt) on almost every call and capture + instantiate of ~5000 nodes costs more
@@ -1076,8 +1086,12 @@ extern "C" int f5_debug_set_ln_fusion(int on) {
     g_fuse_ln = on ? 1 : 0;       // part of the launch sequence, hence of the graph key
     return 0;
 }
+extern "C" int f5_debug_set_q_premul(int on) {
+    g_q_premul = on ? 1 : 0;
+    return 0;
+}
 extern "C" int f5_debug_set_attn_variant(int v) {
-    F5_REQUIRE(v >= 0 && v <= 15, "attention variant bits: 1 = single-issue softmax VALU, 2 = one workgroup per CU, 4 = 2-D block numbering, 8 = eager rescale");
+    F5_REQUIRE(v >= 0 && v <= 31, "attention variant bits: 1 = single-issue softmax VALU, 2 = one workgroup per CU, 4 = 2-D block numbering, 8 = eager rescale, 16 = per-tile maximum (v2w) in the large-grid kernel");
     F5_SET_BOTH(f5_attn_variant, v);
     return 0;
 }
@@ -1206,6 +1220,13 @@ extern "C" int f5_op_quantize_mx(const float* x, int ldx, void* q, int ldq, void
     return f5_launch_quantize_mx(x, ldx, (uint8_t*)q, ldq, (uint8_t*)scales, rows, cols, (hipStream_t)stream);
 }
 
+// op-level twin of the engine's q pre-multiplication (run_dit): when set (single-segment operands only), f5_op_qkv_rope scales
+// the q columns by this factor and f5_op_attention treats q as already carrying scale * log2(e).  0 (default) = plain q.
+static float g_op_q_premul = 0.0f;
+extern "C" int f5_debug_set_op_q_premul(float v) {
+    g_op_q_premul = v;
+    return 0;
+}
 extern "C" int f5_op_attention(const void* qk_hi, const void* qk_lo, const void* vt_hi, const void* vt_lo, void* out_hi,
                                void* out_lo, const int32_t* kv_len, int B, int H, int seq_len, int npad, int dmodel, float scale,
                                int hp, void* stream) {
@@ -1227,6 +1248,7 @@ extern "C" int f5_op_attention(const void* qk_hi, const void* qk_lo, const void*
     at.dmodel = dmodel;
     at.hp = hp;
     at.scale = scale;
+    at.q_prescaled = g_op_q_premul != 0.0f && hp == 0;
     return g_ops.attention(at, (hipStream_t)stream);
 }
 
@@ -1255,6 +1277,7 @@ extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_
     g.npad = npad;
     g.heads = heads;
     g.dmodel = dmodel;
+    g.q_premul = nseg == 1 ? g_op_q_premul : 0.0f;
     g.vt[0] = (op16_t*)vt_hi;
     g.vt[1] = (op16_t*)vt_lo;
     return g_ops.gemm(g, EPI_QKV_ROPE, (hipStream_t)stream);

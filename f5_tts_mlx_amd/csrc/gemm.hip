@@ -80,8 +80,9 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                     for (int nb = 0; nb < NB; ++nb) {
                         const bool isqk = col[nb] < 2 * p.dmodel;
                         const int j = (col[nb] & 63) >> 1;
-                        rc[ri][nb] = (isqk && rowbase + ri < p.M) ? p.rope_cos[n * 32 + j] : 1.0f;
-                        rs[ri][nb] = (isqk && rowbase + ri < p.M) ? p.rope_sin[n * 32 + j] : 0.0f;
+                        const float qs = (p.q_premul != 0.0f && col[nb] < p.dmodel) ? p.q_premul : 1.0f;
+                        rc[ri][nb] = (isqk && rowbase + ri < p.M) ? p.rope_cos[n * 32 + j] * qs : 1.0f;
+                        rs[ri][nb] = (isqk && rowbase + ri < p.M) ? p.rope_sin[n * 32 + j] * qs : 0.0f;
                     }
                 }
             }
@@ -157,6 +158,75 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
             }
         }
     }
+}
+
+// x += gate * ((acc + bias) * keep) (EPI_RESID_GATE) with the ADD done by the L2's atomic units (global_atomic_add_f32 without
+// return value), straight from the accumulator registers.  MEASURED SLOWER, kept as an experiment behind gemm flag 8
+// (f5_debug_set_gemm_flags; tools/r2b_ab.py, profiles/r02/attention_nomax_and_resid_atomic_ab.txt).  Idea: the load / add / store forms
+// (gemm_epilogue, staged_epilogue_resid) make every wave wait for its 8 B / element round trip to HBM at the end of its tile
+// (490 MB per launch at batch 32, all 256 workgroups of a round enter the epilogue together, the matrix cores idle meanwhile);
+// a no-return atomic is fire-and-forget, so the workgroup would retire and the CU's next tile start its main loop while the
+// memory side applies the adds.  Every element receives exactly ONE add per launch (split-K partials are summed in LDS first),
+// so the result is deterministic and equals the load / add / store form up to the product gate * v being rounded before the
+// add.  Result on MI355X: out-proj 267 vs 193 us, FF2 360 vs 300 us at M = 59 968; 13.3 vs 12.6 and 18.5 vs 17.2 us at
+// M = 1 874; sample() 1 320 vs 1 254 ms at batch 32 -- the L2 atomic units retire the 61 M adds of a launch at ~1.5 TB/s
+// equivalent, slower than the 5.3 TB/s the plain read-modify-write reaches, and the queued atomics hold up the next tile's
+// operand loads instead of hiding under its MFMAs.
+// Lane layout of a 32x32 accumulator block: register r of lane (hi, lcol) is row 8*(r>>2) + 4*hi + (r&3), column lcol, so
+// one instruction updates two 128-byte row segments.
+template <int MBW, int NBW, bool GUARD>
+__device__ __forceinline__ void atomic_epilogue_resid_impl(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], int row0, int colbase,
+                                                           int lane) {
+    const int hi = lane >> 5, lcol = lane & 31;
+    float bcol[NBW], gcol[NBW];
+    bool colok[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int c = colbase + nb * 32 + lcol;
+        colok[nb] = !GUARD || c < p.N;
+        bcol[nb] = (p.bias != nullptr && colok[nb]) ? p.bias[c] : 0.0f;
+        gcol[nb] = colok[nb] ? p.gate[c] : 0.0f;
+    }
+    const bool keep_words = p.rowkeep != nullptr && (reinterpret_cast<uintptr_t>(p.rowkeep) & 3) == 0;
+    char* const xbase = reinterpret_cast<char*>(p.out_f32);
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int rowb = row0 + mb * 32 + rg * 8 + hi * 4;          // 4 consecutive rows, rowb % 4 == 0
+            uint32_t kw = 0x01010101u;                                   // keep bytes of the 4 rows
+            if (p.rowkeep != nullptr) {
+                if (keep_words && (!GUARD || rowb + 3 < p.M)) {
+                    kw = *reinterpret_cast<const uint32_t*>(p.rowkeep + rowb);
+                } else {
+                    kw = 0;
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri)
+                        if (!GUARD || rowb + ri < p.M) kw |= (uint32_t)p.rowkeep[rowb + ri] << (8 * ri);
+                }
+            }
+            // 32-bit BYTE offset from the uniform base (host-checked: M * ldo * 4 < 4 GiB)
+            uint32_t boff = ((uint32_t)rowb * (uint32_t)p.ldo + (uint32_t)(colbase + lcol)) * 4u;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const float kp = ((kw >> (8 * ri)) & 0xffu) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+                    if (!GUARD || (rowb + ri < p.M && colok[nb]))
+                        __hip_atomic_fetch_add(reinterpret_cast<float*>(xbase + boff + nb * 128),
+                                               gcol[nb] * ((acc[mb][nb][rg * 4 + ri] + bcol[nb]) * kp), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                boff += (uint32_t)p.ldo * 4u;
+            }
+        }
+}
+template <int MBW, int NBW>
+__device__ __forceinline__ void atomic_epilogue_resid(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], int row0, int colbase,
+                                                      int lane) {
+    // interior wave tiles (all but the last row / column of tiles): no per-element guards, the 16 * MBW * NBW atomics of a
+    // lane issue back to back
+    if (row0 + 32 * MBW <= p.M && colbase + 32 * NBW <= p.N) atomic_epilogue_resid_impl<MBW, NBW, false>(p, acc, row0, colbase, lane);
+    else atomic_epilogue_resid_impl<MBW, NBW, true>(p, acc, row0, colbase, lane);
 }
 
 // ---- LN-modulate fused behind the residual update (EPI_RESID_GATE of the small-tile kernels, batch-1-sized problems) ------
@@ -365,6 +435,10 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
                                           n0 + wn * (32 * NB), lane);
         return;
     }
+    if (EPI == EPI_RESID_GATE && p.ln_counter == nullptr && (p.debug_flags & 8) != 0) {
+        atomic_epilogue_resid<MB, NB>(p, acc, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane);
+        return;
+    }
     gemm_epilogue<EPI, MB, NB>(p, acc, m0, n0, wm, wn, lane);
     if (EPI == EPI_RESID_GATE && p.ln_counter) resid_ln_tail(p, tm, BMt, (p.N + BNt - 1) / BNt);
 }
@@ -423,6 +497,8 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
             constexpr int PAR = NBW >= 2 ? 2 : 1;
             float rc[4][4][PAR], rs[4][4][PAR];
             if (EPI == EPI_QKV_ROPE) {
+                // q columns carry the softmax scale * log2(e) (F5GemmArgs::q_premul) folded into their rotation factors
+                const float qs = (p.q_premul != 0.0f && colbase < p.dmodel) ? p.q_premul : 1.0f;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int nbase = (rowblk + rg * 8 + hi * 4) % p.seq_len;
@@ -433,8 +509,8 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
 #pragma unroll
                         for (int q = 0; q < PAR; ++q) {
                             const int j = ((q * 32 + lcol) & 63) >> 1;
-                            rc[rg][ri][q] = p.rope_cos[n * 32 + j];
-                            rs[rg][ri][q] = p.rope_sin[n * 32 + j];
+                            rc[rg][ri][q] = p.rope_cos[n * 32 + j] * qs;
+                            rs[rg][ri][q] = p.rope_sin[n * 32 + j] * qs;
                         }
                     }
                 }
@@ -927,7 +1003,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
         staged_epilogue_bf16<EPI, 4, 2>(p, acc, smem + wave * 8192, m0 + wm * 128, n0 + wn * 64, ln);
     } else if (EPI == EPI_RESID_GATE) {
-        staged_epilogue_resid<4, 2>(p, acc, reinterpret_cast<float*>(smem + wave * 8192), m0 + wm * 128, n0 + wn * 64, ln);
+        if (p.debug_flags & 8) atomic_epilogue_resid<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, ln);     // experiment, see atomic_epilogue_resid
+        else staged_epilogue_resid<4, 2>(p, acc, reinterpret_cast<float*>(smem + wave * 8192), m0 + wm * 128, n0 + wn * 64, ln);
     } else {
         gemm_epilogue<EPI, 4, 2>(p, acc, m0, n0, wm, wn, ln);
     }
@@ -1193,6 +1270,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
         if (KS == 1) __syncthreads();
         staged_epilogue_bf16<EPI, MB, NB>(p, acc, smem_all + wave * small_tile_stage_elems<NB>(), m0 + wm * (32 * MB),
                                           n0 + wn * (32 * NB), lane);
+        return;
+    }
+    if (EPI == EPI_RESID_GATE && p.ln_counter == nullptr && (p.debug_flags & 8) != 0) {
+        atomic_epilogue_resid<MB, NB>(p, acc, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane);
         return;
     }
     gemm_epilogue<EPI, MB, NB>(p, acc, m0, n0, wm, wn, lane);
@@ -1689,7 +1770,8 @@ __global__ __launch_bounds__(512) void f5_gemm256f8_kernel(F5GemmArgs p, int til
     } else if (EPI == EPI_GELU_TANH) {
         staged_epilogue_gelu_f8(p, acc, reinterpret_cast<float*>(stage), m0 + wm * 128, n0 + wn * 64, lane);
     } else if (EPI == EPI_RESID_GATE) {
-        staged_epilogue_resid<4, 2>(p, acc, reinterpret_cast<float*>(stage), m0 + wm * 128, n0 + wn * 64, lane);
+        if (p.debug_flags & 8) atomic_epilogue_resid<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+        else staged_epilogue_resid<4, 2>(p, acc, reinterpret_cast<float*>(stage), m0 + wm * 128, n0 + wn * 64, lane);
     } else {
         gemm_epilogue<EPI, 4, 2>(p, acc, m0, n0, wm, wn, lane);
     }
@@ -1703,7 +1785,11 @@ static int launch_f8(const F5GemmArgs& a, hipStream_t stream) {
     F5_LAUNCH_CHECK();
     return 0;
 }
-int f5_launch_gemm_f8(const F5GemmArgs& a, int epi, hipStream_t stream) {
+extern int f5_gemm_debug_flags;
+int f5_launch_gemm_f8(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
+    F5GemmArgs a = a_in;
+    a.debug_flags = f5_gemm_debug_flags;
+    F5_REQUIRE(epi != EPI_RESID_GATE || (size_t)a.M * a.ldo * 4 < (1ull << 32), "gemm_f8(resid): the residual stream must stay below 4 GiB");
     F5_REQUIRE(a.M > 0 && a.N > 0 && a.N % 256 == 0 && a.K > 0 && a.K % 128 == 0,
                "gemm_f8: bad shape M=%d N=%d K=%d (N %% 256 == 0, K %% 128 == 0)", a.M, a.N, a.K);
     F5_REQUIRE(a.A8 && a.W8 && a.As && a.Ws, "gemm_f8: null operand");
@@ -1837,6 +1923,7 @@ int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
     F5_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: leading dims must be multiples of 8");
     F5_REQUIRE((size_t)(a.a_row_mod > 0 ? a.a_row_mod : a.M) * a.lda < (1ull << 31) && (size_t)(a.N + 256) * a.ldw < (1ull << 31),
                "gemm: operands must stay below 4 GiB (the kernels use 32-bit byte offsets)");
+    F5_REQUIRE(epi != EPI_RESID_GATE || (size_t)a.M * a.ldo * 4 < (1ull << 32), "gemm(resid): the residual stream must stay below 4 GiB");
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(a, stream);
         case EPI_BF16: return launch_epi<EPI_BF16>(a, stream);

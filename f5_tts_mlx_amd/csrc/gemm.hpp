@@ -40,6 +40,7 @@ struct F5GemmArgs {
     const float* rope_sin;
     int seq_len, npad, heads, dmodel;
     op16_t* vt[2];            // [B*heads][64][npad]
+    float q_premul;           // EPI_QKV_ROPE: != 0 -> the q columns (col < dmodel) are multiplied by it before rounding (softmax scale * log2 e)
     int debug_flags;          // bit 0: skip the epilogue (timing experiments only)
     int nband;                // 256x256 kernel: > 0 = tiles numbered band-major, bands of nband column tiles (set by the launcher)
     // ---- EPI_RESID_GATE only, small-tile kernels only (f5_gemm_resid_ln_fusable): LN-modulate of the NEXT sub-layer fused

@@ -214,6 +214,8 @@ uint16_t f5_debug_f2bf_bits(float f);
 int f5_debug_set_gemm_tile(int sel);
 /* bit 0: skip GEMM epilogues of the 256x256 / 128x256 kernels (timing experiments only; results are garbage);
  * bit 1: small-tile kernels use the direct (2-byte store) epilogue instead of the LDS-staged one;
+ * bit 3 (8): experiment, measured slower -- the gated residual update x += gate * v (EPI_RESID_GATE) uses no-return L2 atomic adds
+ *            instead of load / add / store (one add per element per launch either way, so both forms are deterministic);
  * bits 4-7 (timing only, garbage results; tile overrides 10 / 13 with the bf16 epilogue): 16 = no operand loads after the prologue,
  * 32 = no MFMAs, 64 = no LDS fragment reads, 128 = no workgroup barrier (combinations 96, 112, 144, 240 are instantiated) */
 int f5_debug_set_gemm_flags(int v);
@@ -237,6 +239,8 @@ int f5_debug_set_convpos_tps(int taps);     /* conv-pos kernel: weight slabs per
 int f5_debug_set_convpos_xcd_map(int on);   /* conv-pos kernel: 1 (default) = groups dealt to XCDs, 0 = plain 3-D block numbering */
 int f5_debug_set_gemm_nband(int n);         /* 256x256 GEMM: tiles numbered in bands of n column tiles (0 = n fastest) */
 int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the residual GEMMs of small-M launches (default 0: measured slower) */
+int f5_debug_set_q_premul(int on);          /* 1 (default): sample() multiplies q by softmax_scale * log2(e) in the QKV epilogue (single-segment operand modes) */
+int f5_debug_set_op_q_premul(float factor); /* op-level twin: f5_op_qkv_rope scales q by factor, f5_op_attention expects q pre-scaled; 0 = off (default) */
 int f5_debug_set_attn_variant(int bits);   /* experiment bits of attention versions 5 / 6 (see attention.hip) */
 int f5_debug_set_attn_ablation(int v);
 /* 256-query workgroups with two query blocks per wave (bf16, large grids): -1 auto, 0 off, 1 force */

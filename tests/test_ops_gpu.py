@@ -93,7 +93,22 @@ def test_gemm_epilogues(lib, epi):
 # ------------------------------------------------------------------------------------------------
 # QKV + RoPE + attention
 # ------------------------------------------------------------------------------------------------
-def _attention_case(lib, B, H, N, kv_len, nseg, seed=0):
+QPRE = 0.125 * 1.4426950408889634     # softmax scale * log2(e): what the engine folds into q (F5GemmArgs::q_premul)
+
+
+def _attention_case(lib, B, H, N, kv_len, nseg, seed=0, premul=False):
+    """premul: the op-level twin of the engine's default -- q leaves the QKV epilogue multiplied by scale * log2(e) and the
+    attention kernels take their scores in exp2 units (single-segment operands only)."""
+    if premul:
+        assert nseg == 1
+        E.check(lib.f5_debug_set_op_q_premul(C.c_float(QPRE)))
+    try:
+        _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul)
+    finally:
+        E.check(lib.f5_debug_set_op_q_premul(C.c_float(0.0)))
+
+
+def _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul):
     D = H * 64
     r = rng(seed)
     x = randn(r, B * N, D)
@@ -127,6 +142,8 @@ def _attention_case(lib, B, H, N, kv_len, nseg, seed=0):
     assert float((cos_t.cpu().double() - freqs.cos()[:, 0::2]).abs().max()) < 1e-5 * max(1, N / 100)
     # q/k/v written by the epilogue
     got_q = join(qk[0], qk[1] if nseg == 3 else None).cpu()[:, :D].reshape(B, N, H, 64).transpose(1, 2)
+    if premul:
+        got_q = got_q / QPRE
     got_k = join(qk[0], qk[1] if nseg == 3 else None).cpu()[:, D:].reshape(B, N, H, 64).transpose(1, 2)
     got_v = join(vt[0], vt[1] if nseg == 3 else None).cpu().reshape(B, H, 64, npad)[..., :N].transpose(-1, -2)
     tol_in = 5e-5 if nseg == 3 else 2e-2
@@ -185,28 +202,36 @@ def test_attention_pipelined_kernel_ragged_and_batched(lib, version):
         E.check(lib.f5_debug_set_attn_version(2))
 
 
-def test_attention_softmax_spike(lib, hp=1):
+def test_attention_softmax_spike(lib, hp=1, premul=False, N=300, spikes=((70, 30.0), (200, 60.0))):
     """force large running-max jumps across KV tiles (online-softmax rescale path)."""
-    B, H, N, D = 1, 2, 300, 128
+    B, H, D = 1, 2, 128
     r = rng(3)
     q = randn(r, B * N, D)
     k = randn(r, B * N, D)
-    k[70] *= 30.0
-    k[200] *= 60.0
+    for pos, factor in spikes:
+        k[pos] *= factor
     v = randn(r, B * N, D)
-    npad = 320
-    qk = torch.cat([q, k], dim=1)
+    npad = (N + 63) // 64 * 64
+    if premul:
+        E.check(lib.f5_debug_set_op_q_premul(C.c_float(QPRE)))
+        q_dev = bf16r(q) * QPRE          # what the QKV epilogue would have written (exact here: the test rounds q first)
+        qk = torch.cat([q_dev, k], dim=1)
+    else:
+        qk = torch.cat([q, k], dim=1)
     qk_hi, qk_lo = split_bf16(qk.to(DEV))
     vt_full = torch.zeros((B * H, 64, npad))
     vt_full[..., :N] = v.reshape(N, H, 64).permute(1, 2, 0)
     vt_hi, vt_lo = split_bf16(vt_full.to(DEV))
     out = [torch.zeros((B * N, D), dtype=op_dtype(), device=DEV) for _ in range(2)]
     lo = (lambda t: t) if hp else (lambda t: None)
-    E.check(lib.f5_op_attention(P(qk_hi), P(lo(qk_lo)), P(vt_hi), P(lo(vt_lo)), P(out[0]), P(lo(out[1])), P(None), B, H, N, npad, D,
-                                C.c_float(0.125), hp, stream()))
-    sync()
+    try:
+        E.check(lib.f5_op_attention(P(qk_hi), P(lo(qk_lo)), P(vt_hi), P(lo(vt_lo)), P(out[0]), P(lo(out[1])), P(None), B, H, N, npad, D,
+                                    C.c_float(0.125), hp, stream()))
+        sync()
+    finally:
+        E.check(lib.f5_debug_set_op_q_premul(C.c_float(0.0)))
     rr = (lambda t: t) if hp else bf16r                      # one-pass kernels: the reference sees the rounded operands
-    qq = rr(q).double().reshape(N, H, 64).transpose(0, 1)
+    qq = (bf16r(bf16r(q) * QPRE) / QPRE if premul else rr(q)).double().reshape(N, H, 64).transpose(0, 1)
     kk = rr(k).double().reshape(N, H, 64).transpose(0, 1)
     vv = rr(v).double().reshape(N, H, 64).transpose(0, 1)
     ref = (torch.softmax(qq @ kk.transpose(-1, -2) * 0.125, dim=-1) @ vv).transpose(0, 1).reshape(N, D)
@@ -515,6 +540,47 @@ def test_attention_wide_workgroups(lib, mode=1):
         E.check(lib.f5_debug_set_attn_kvsplit(-1))
 
 
+@pytest.mark.parametrize("premul", [False, True])
+@pytest.mark.parametrize("path", ["wide", "split2", "split4", "auto"])
+def test_attention_without_tile_maximum(lib, path, premul):
+    """The default large-grid kernel (f5_attn2f_kernel) and the default split-KV kernels never compute a tile maximum after
+    a sequence's first tile: they exponentiate against the standing reference point and fall back to the exact path when a row
+    sum says a score was more than 2^14 above it.  Plain and ragged shapes must match the fp64 softmax like the old kernels,
+    with q plain or pre-multiplied by scale * log2(e); spikes placed in later tiles (x30 / x60 / x400 on one key: logits in the
+    hundreds, i.e. inf in the fast path) must come out finite and right, also when the spike is the last key of a partial tile
+    or sits in the first tile (the reference point then stays far above everything that follows)."""
+    if path == "wide":
+        E.check(lib.f5_debug_set_attn_wide(1))
+        E.check(lib.f5_debug_set_attn_kvsplit(1))
+    elif path != "auto":
+        E.check(lib.f5_debug_set_attn_kvsplit(int(path[-1])))
+    try:
+        _attention_case(lib, 1, 2, 50, None, 1, seed=1, premul=premul)
+        _attention_case(lib, 3, 2, 200, [200, 130, 1], 1, seed=7, premul=premul)
+        _attention_case(lib, 2, 4, 300, [300, 211], 1, seed=21, premul=premul)
+        _attention_case(lib, 1, 2, 937, None, 1, seed=8, premul=premul)
+        for N, spikes in ((300, ((70, 30.0), (200, 60.0))), (937, ((936, 400.0),)), (500, ((3, 100.0),)), (700, ((64, 50.0), (65, 90.0), (640, 20.0)))):
+            test_attention_softmax_spike(lib, hp=0, premul=premul, N=N, spikes=spikes)
+    finally:
+        E.check(lib.f5_debug_set_attn_wide(-1))
+        E.check(lib.f5_debug_set_attn_kvsplit(-1))
+
+
+def test_attention_tile_maximum_kernels_still_selectable(lib):
+    """attention variant bit 16 = the kernels of round 1 / early round 2 (tile maximum on every tile), kept for A/B runs"""
+    E.check(lib.f5_debug_set_attn_variant(16))
+    try:
+        for wide in (1, -1):
+            E.check(lib.f5_debug_set_attn_wide(wide))
+            E.check(lib.f5_debug_set_attn_kvsplit(1 if wide == 1 else -1))
+            _attention_case(lib, 2, 4, 300, [300, 211], 1, seed=21)
+            _attention_case(lib, 1, 2, 937, None, 1, seed=8, premul=True)
+    finally:
+        E.check(lib.f5_debug_set_attn_variant(0))
+        E.check(lib.f5_debug_set_attn_wide(-1))
+        E.check(lib.f5_debug_set_attn_kvsplit(-1))
+
+
 @pytest.mark.parametrize("ks", [1, 2, 4])
 def test_attention_kv_split(lib, ks):
     """in-workgroup KV split (small-batch kernel): every split factor gives the one-pass result, including groups that
@@ -647,6 +713,44 @@ def test_gemm_resid_gate_fused_ln_is_bit_identical(lib, tile, nseg):
             assert rc != 0 and b"fused LN" in lib.f5_last_error()
     finally:
         E.check(lib.f5_debug_set_gemm_tile(0))
+
+
+@pytest.mark.parametrize("nseg", [1, 3])
+@pytest.mark.parametrize("tile", [0, 2, 4, 5, 9, 10])
+def test_gemm_resid_gate_atomic_vs_load_add_store(lib, tile, nseg):
+    """Experiment kept behind gemm flag 8 (measured slower than the default load / add / store): the residual update
+    x += gate * v on the L2's atomic units (global_atomic_add_f32 without return, one add per element per launch).  It must be
+    deterministic (two launches from the same x: identical bits) and agree with the default form to the rounding of the product
+    (a few ulp of the operands), for the small-tile kernels and the 256x256 kernel, with row masking, ragged M (guarded tiles)
+    and interior tiles."""
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        for (M, N, K) in ((1874, 1024, 1024), (700, 512, 256), (2100, 1024, 128)):
+            r = rng(M + N + K + tile + nseg)
+            a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+            gate, x0 = randn(r, N), randn(r, M, N, scale=2.0)
+            keep = torch.from_numpy((r.random(M) > 0.3).astype(np.uint8))
+            a_hi, a_lo = split_bf16(a.to(DEV))
+            w_hi, w_lo = split_bf16(w.to(DEV))
+            bias_d, gate_d, keep_d = bias.to(DEV), gate.to(DEV), keep.to(DEV)
+            res = {}
+            for name, flags in (("atomic", 8), ("atomic2", 8), ("rmw", 0)):
+                E.check(lib.f5_debug_set_gemm_flags(flags))
+                x = x0.to(DEV).clone()
+                E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(a_lo), P(w_hi), P(w_lo), P(bias_d), P(gate_d), P(keep_d), P(x), M, N, K, K,
+                                                  K, N, nseg, stream()), "gemm_resid_gate")
+                sync()
+                res[name] = x.cpu()
+            assert torch.equal(res["atomic"], res["atomic2"]), "atomic residual update is not deterministic"
+            d = (res["atomic"].double() - res["rmw"].double()).abs()
+            scale = float(res["rmw"].abs().max())
+            print(f"[resid atomic vs rmw] tile={tile} nseg={nseg} {M}x{N}x{K}: max |d| = {float(d.max()):.3e} (max |x| = {scale:.2f})")
+            assert float(d.max()) <= 4e-7 * scale
+            # rows that are masked out must not change at all
+            assert torch.equal(res["atomic"][keep == 0], x0[keep == 0])
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))
+        E.check(lib.f5_debug_set_gemm_flags(0))
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3, 5, 6])

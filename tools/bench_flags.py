@@ -21,6 +21,8 @@ for kv in args[:split]:
     elif k == "lnfuse": lib.f5_debug_set_ln_fusion(v)
     elif k == "attnvar": lib.f5_debug_set_attn_variant(v)
     elif k == "streamk": lib.f5_debug_set_gemm_streamk(v)
+    elif k == "gflags": lib.f5_debug_set_gemm_flags(v)      # 8 = residual update by no-return L2 atomics (experiment)
+    elif k == "qpremul": lib.f5_debug_set_q_premul(v)       # 0 = plain q (attention multiplies by scale * log2 e itself)
     else: raise SystemExit(f"unknown flag {k}")
 sys.argv = ["bench.py"] + args[split + 1:]
 runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), run_name="__main__")
