@@ -229,6 +229,78 @@ __device__ __forceinline__ void atomic_epilogue_resid(const F5GemmArgs& p, f32x1
     else atomic_epilogue_resid_impl<MBW, NBW, true>(p, acc, row0, colbase, lane);
 }
 
+// ---- EPI_RESID_GATE of the small-tile ring kernel with everything the update needs ALREADY IN REGISTERS ---------------------
+// At M = 2*937 the launch is one round of workgroups and its run time is one workgroup's dependency chain; the plain epilogue
+// appends "load x, bias, gate, keep -> wait a memory round trip -> add -> store" to it.  The values do not depend on the
+// product, so the waves that will run the epilogue request them before the first operand tile (ResidPre) and the round trip
+// overlaps the whole K loop; the epilogue is then arithmetic + stores.  Same arithmetic as gemm_epilogue: x + gate * (v * keep).
+// Measured at M = 1874 (tools/r2c_ab.py, gemm flag 256 = loads in the epilogue): out-proj 11.6 vs 12.6 us, FF2 16.6 vs 17.5 us,
+// sample() at batch 1 77.5 vs 80.5 ms (profiles/r02/resid_preload_prefetch_ab.txt).
+template <int MB, int NB>
+struct ResidPre {
+    float x[MB][16][NB];
+    float bias[NB], gate[NB];
+    uint32_t keep[MB][4];       // keep bytes of rows (rg*8 + hi*4 + 0..3) of row block mb
+};
+template <int MB, int NB>
+__device__ __forceinline__ void resid_preload(const F5GemmArgs& p, ResidPre<MB, NB>& q, int row0, int colbase, int lane) {
+    const int hi = lane >> 5, lcol = lane & 31;
+    const bool keep_words = p.rowkeep != nullptr && (reinterpret_cast<uintptr_t>(p.rowkeep) & 3) == 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int c = colbase + nb * 32 + lcol;
+        const bool ok = c < p.N;
+        q.bias[nb] = (p.bias != nullptr && ok) ? p.bias[c] : 0.0f;
+        q.gate[nb] = ok ? p.gate[c] : 0.0f;
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int rowb = row0 + mb * 32 + rg * 8 + hi * 4;
+            uint32_t kw = 0x01010101u;
+            if (p.rowkeep != nullptr) {
+                if (keep_words && rowb + 3 < p.M) {
+                    kw = *reinterpret_cast<const uint32_t*>(p.rowkeep + rowb);
+                } else {
+                    kw = 0;
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri)
+                        if (rowb + ri < p.M) kw |= (uint32_t)p.rowkeep[rowb + ri] << (8 * ri);
+                }
+            }
+            q.keep[mb][rg] = kw;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int row = rowb + ri, c = colbase + nb * 32 + lcol;
+                    q.x[mb][rg * 4 + ri][nb] = (row < p.M && c < p.N) ? p.out_f32[(size_t)row * p.ldo + c] : 0.0f;
+                }
+        }
+}
+template <int MB, int NB>
+__device__ __forceinline__ void resid_epilogue_preloaded(const F5GemmArgs& p, f32x16 (&acc)[MB][NB], const ResidPre<MB, NB>& q, int row0,
+                                                         int colbase, int lane) {
+    const int hi = lane >> 5, lcol = lane & 31;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int row = row0 + mb * 32 + rg * 8 + hi * 4 + ri;
+                const bool kp = ((q.keep[mb][rg] >> (8 * ri)) & 0xffu) != 0;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int c = colbase + nb * 32 + lcol;
+                    float v = acc[mb][nb][rg * 4 + ri] + q.bias[nb];
+                    if (!kp) v = 0.0f;
+                    if (row < p.M && c < p.N) p.out_f32[(size_t)row * p.ldo + c] = q.x[mb][rg * 4 + ri][nb] + q.gate[nb] * v;
+                }
+            }
+}
+
 // ---- LN-modulate fused behind the residual update (EPI_RESID_GATE of the small-tile kernels, batch-1-sized problems) ------
 // At M = 2*937 every launch is one round of workgroups and costs ~2 us of launch / drain on top of its work, and the
 // stand-alone LN-modulate kernels are 2 of the 7 launches of a DiT block (5.2 us each).  Instead, every workgroup of the
@@ -849,6 +921,27 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // ---- experiment, MEASURED SLOWER, off by default (gemm flag 512/1024/2048 = prefetch 1/4, 1/2 or all of the tile):
+    // residual-update launches touch the 128-byte lines of their x tile BEFORE the main loop (one dword per line, value
+    // unused), hoping that the read half of the epilogue's read-modify-write is then served by the L2 / Infinity Cache and the
+    // HBM reads happen while the matrix cores work.  Out-proj at M = 59 968: 186 us without, 188 / 193 / 205 us with 1/4,
+    // 1/2, all lines; sample() at batch 32 1 296-1 301 vs 1 313 ms (profiles/r02/resid_preload_prefetch_ab.txt): a round's
+    // x tiles (8 MB per XCD) do not survive the operand stream in the 4 MB L2, and the early reads delay the first operand tiles.
+    // The loads are older than every operand load: the counted vmcnt waits of the main loop cover them.
+    float xpf[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (EPI == EPI_RESID_GATE && (p.debug_flags & (512 | 1024 | 2048)) && kind != 1) {
+        const int npf = (p.debug_flags & 2048) ? 4 : ((p.debug_flags & 1024) ? 2 : 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < npf) {
+                const int li = j * 512 + tid;                     // line of the 256 x 256 fp32 tile: 8 lines per row
+                int row = m0 + (li >> 3);
+                if (row > p.M - 1) row = p.M - 1;
+                const float* ptr = p.out_f32 + (size_t)row * p.ldo + n0 + (li & 7) * 32;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(xpf[j]) : "v"(ptr) : "memory");
+            }
+    }
+
     // ---- prologue: tile 0 (4 halves) + B halves of tile 1 -----------------------------------------
     int a_seg, a_k0, b_seg, b_k0;                     // running state: tile tt+1 (A halves) and tile tt+2 (B halves)
     {
@@ -993,6 +1086,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
                 __builtin_amdgcn_sched_barrier(0);
             }
     }
+    if (EPI == EPI_RESID_GATE) asm volatile("" ::"v"(xpf[0]), "v"(xpf[1]), "v"(xpf[2]), "v"(xpf[3]));   // prefetch registers live until here
     if (p.debug_flags & 1) {   // timing experiment: main loop only
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1170,6 +1264,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // residual-update launches: the epilogue waves request x / bias / gate / keep now (see ResidPre); these loads are older than
+    // every operand load, so the counted vmcnt waits below cover them (in-order return) and stay valid
+    constexpr bool PRE_RESID = EPI == EPI_RESID_GATE && MB * NB <= 3;   // 64 more live VGPRs would spill the 2x2 wave tile
+    ResidPre<PRE_RESID ? MB : 1, PRE_RESID ? NB : 1> rpre;
+    const bool use_pre = PRE_RESID && p.ln_counter == nullptr && (p.debug_flags & (8 | 256)) == 0;
+    if (PRE_RESID && use_pre && grp == 0) resid_preload<PRE_RESID ? MB : 1, PRE_RESID ? NB : 1>(p, rpre, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane);
+
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
         if (st < Tg) RING_ISSUE(st);
@@ -1275,6 +1376,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     if (EPI == EPI_RESID_GATE && p.ln_counter == nullptr && (p.debug_flags & 8) != 0) {
         atomic_epilogue_resid<MB, NB>(p, acc, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane);
         return;
+    }
+    if constexpr (PRE_RESID) {
+        if (use_pre) {
+            resid_epilogue_preloaded<MB, NB>(p, acc, rpre, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane);
+            return;
+        }
     }
     gemm_epilogue<EPI, MB, NB>(p, acc, m0, n0, wm, wn, lane);
     if (EPI == EPI_RESID_GATE && p.ln_counter) resid_ln_tail(p, tm, BMt, (p.N + BNt - 1) / BNt);

@@ -216,6 +216,10 @@ int f5_debug_set_gemm_tile(int sel);
  * bit 1: small-tile kernels use the direct (2-byte store) epilogue instead of the LDS-staged one;
  * bit 3 (8): experiment, measured slower -- the gated residual update x += gate * v (EPI_RESID_GATE) uses no-return L2 atomic adds
  *            instead of load / add / store (one add per element per launch either way, so both forms are deterministic);
+ * bit 8 (256): the small-tile ring kernels load x / bias / gate / keep of the residual update in the epilogue instead of
+ *            requesting them before the K loop (A/B of the default; identical bits);
+ * bits 9-11 (512 / 1024 / 2048): experiment -- the 256x256 residual GEMM touches 1/4, 1/2 or all 128-byte lines of its x tile
+ *            before the main loop (cache prefetch of the read half of the read-modify-write; identical bits);
  * bits 4-7 (timing only, garbage results; tile overrides 10 / 13 with the bf16 epilogue): 16 = no operand loads after the prologue,
  * 32 = no MFMAs, 64 = no LDS fragment reads, 128 = no workgroup barrier (combinations 96, 112, 144, 240 are instantiated) */
 int f5_debug_set_gemm_flags(int v);

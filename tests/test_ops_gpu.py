@@ -725,7 +725,7 @@ def test_gemm_resid_gate_atomic_vs_load_add_store(lib, tile, nseg):
     and interior tiles."""
     E.check(lib.f5_debug_set_gemm_tile(tile))
     try:
-        for (M, N, K) in ((1874, 1024, 1024), (700, 512, 256), (2100, 1024, 128)):
+        for (M, N, K) in ((1874, 1024, 1024), (700, 512, 256), (2100, 1024, 128), (333, 512, 192)):
             r = rng(M + N + K + tile + nseg)
             a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
             gate, x0 = randn(r, N), randn(r, M, N, scale=2.0)
@@ -734,7 +734,10 @@ def test_gemm_resid_gate_atomic_vs_load_add_store(lib, tile, nseg):
             w_hi, w_lo = split_bf16(w.to(DEV))
             bias_d, gate_d, keep_d = bias.to(DEV), gate.to(DEV), keep.to(DEV)
             res = {}
-            for name, flags in (("atomic", 8), ("atomic2", 8), ("rmw", 0)):
+            # 256 = the ring kernels load x / bias / gate / keep in the epilogue instead of before the K loop (same arithmetic:
+            # identical bits); 2048 = the 256x256 kernel touches its x tile before the main loop (prefetch experiment: no effect
+            # on the values)
+            for name, flags in (("atomic", 8), ("atomic2", 8), ("rmw", 0), ("late_loads", 256), ("prefetch", 2048)):
                 E.check(lib.f5_debug_set_gemm_flags(flags))
                 x = x0.to(DEV).clone()
                 E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(a_lo), P(w_hi), P(w_lo), P(bias_d), P(gate_d), P(keep_d), P(x), M, N, K, K,
@@ -742,6 +745,8 @@ def test_gemm_resid_gate_atomic_vs_load_add_store(lib, tile, nseg):
                 sync()
                 res[name] = x.cpu()
             assert torch.equal(res["atomic"], res["atomic2"]), "atomic residual update is not deterministic"
+            assert torch.equal(res["rmw"], res["late_loads"]), "early and late residual loads differ"
+            assert torch.equal(res["rmw"], res["prefetch"]), "x-tile prefetch changed the result"
             d = (res["atomic"].double() - res["rmw"].double()).abs()
             scale = float(res["rmw"].abs().max())
             print(f"[resid atomic vs rmw] tile={tile} nseg={nseg} {M}x{N}x{K}: max |d| = {float(d.max()):.3e} (max |x| = {scale:.2f})")
