@@ -52,6 +52,7 @@ struct Workspace {
     size_t lens, dur2, text, ids, keep, rowkeep;
     size_t tgrid, dt, cfgv, sinus, th, temb, mod;
     size_t rope_cos, rope_sin;
+    size_t rope_t;                 // pair-major q / k rotation tables: 4 x [32][N] floats (cos_q, sin_q, cos_k, sin_k)
     size_t cond, traj, ytmp, kst, vel;
     size_t xin[2];
     size_t te[2], tg, grn_partial, grn_nx;
@@ -409,6 +410,7 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
     w.mod = b.take((size_t)(nfe + 1) * (6 * L + 2) * D * 4);
     w.rope_cos = b.take((size_t)N * 32 * 4);
     w.rope_sin = b.take((size_t)N * 32 * 4);
+    w.rope_t = b.take((size_t)4 * 32 * N * 4);
     w.cond = b.take(M1 * mel * 4);
     w.traj = b.take((size_t)steps * M1 * mel * 4);
     w.ytmp = b.take(M1 * mel * 4);
@@ -484,6 +486,13 @@ struct Ctx {
     int nseg() const { return e->np == 2 ? 3 : 1; }
 };
 
+static int g_q_premul = 1;       // q pre-multiplied by softmax_scale * log2(e) in the QKV epilogue (see run_dit); by-value kernel arguments => graph key
+static int g_qkv_tr = 1;         // 256x256 QKV kernel: q / k tiles accumulated transposed (pair-major rotation tables); by-value arguments => graph key
+// factor folded into q by the QKV epilogue (0 = none): single-segment operand modes only, see run_dit
+static float q_premul_factor(const f5_engine* e) {
+    return (g_q_premul && e->np == 1) ? (1.0f / sqrtf((float)e->cfg.dim_head)) * 1.4426950408889634f : 0.0f;
+}
+
 static F5GemmArgs gemm_base(const Ctx& c, const op16_t* a_hi, const op16_t* a_lo, int lda, const MatBF& w, int M, int N, int K,
                             const float* bias) {
     F5GemmArgs g;
@@ -523,6 +532,12 @@ static int run_prep(const Ctx& c, int nfe) {
                                  (6 * L + 2) * D, D, 1, 0, s));
     }
     RC(f5_launch_rope_table(c.p<float>(w.rope_cos), c.p<float>(w.rope_sin), c.N, cf.dim_head, s));
+    {
+        float* t = c.p<float>(w.rope_t);
+        const size_t tn = (size_t)32 * c.N;
+        const float qf = q_premul_factor(e);
+        RC(f5_launch_rope_table_t(t, t + tn, t + 2 * tn, t + 3 * tn, c.N, c.N, cf.dim_head, qf != 0.0f ? qf : 1.0f, s));
+    }
     RC(f5_launch_rowkeep(c.p<int>(w.dur2), c.p<uint8_t>(w.rowkeep), 2 * c.B, c.N, s));
     for (int p = 0; p < e->np; ++p) RC(K.zero_vt_pad(c.pb(w.vt, p), (size_t)2 * c.B * cf.heads * 64, c.N, c.npad, s));
 
@@ -568,7 +583,6 @@ static int run_prep(const Ctx& c, int nfe) {
 // ack, counter atomic, agent-scope re-read: ~10 us per GEMM) where the separate LN launch costs 5.2 us.
 namespace f5hf { extern int f5_gemm_debug_flags; }   // by-value kernel argument (set for both builds together) => graph key
 static int g_fuse_ln = 0;
-static int g_q_premul = 1;       // q pre-multiplied by softmax_scale * log2(e) in the QKV epilogue (see run_dit); by-value kernel arguments => graph key
 static int run_dit(const Ctx& c, int j) {
     const f5_engine* e = c.e;
     const f5_config& cf = e->cfg;
@@ -626,7 +640,7 @@ static int run_dit(const Ctx& c, int j) {
     // q leaves the QKV epilogue multiplied by softmax_scale * log2(e) (one rounding, like the unscaled q): the attention kernels
     // then get their scores in exp2 units straight from the matrix cores (attention.hip v2f).  Single-segment operand modes only;
     // bf16x3 keeps the unscaled q (hi / lo split of the reference-exact value).  f5_debug_set_q_premul(0) = A/B.
-    const float qpre = (g_q_premul && e->np == 1) ? (1.0f / sqrtf((float)cf.dim_head)) * 1.4426950408889634f : 0.0f;
+    const float qpre = q_premul_factor(e);
     for (int i = 0; i < L && e->prec == F5_PREC_MXFP8; ++i) {
         // MX-fp8 block: the four GEMMs run on e4m3 operands with E8M0 block scales (v_mfma_scale_f32_32x32x64_f8f6f4); their A
         // operands are produced directly in that format by the LN kernel, the attention epilogue and the GELU epilogue.
@@ -733,6 +747,15 @@ static int run_dit(const Ctx& c, int j) {
         gq.vt[0] = c.pb(w.vt, 0);
         gq.vt[1] = c.pb(w.vt, 1);
         gq.q_premul = qpre;
+        if (g_qkv_tr) {                                  // pair-major tables (the q pair carries qpre, or 1): used by the 256x256 kernel
+            const float* t = c.p<float>(w.rope_t);
+            const size_t tn = (size_t)32 * c.N;
+            gq.rope_cos_tq = t;
+            gq.rope_sin_tq = t + tn;
+            gq.rope_cos_tk = t + 2 * tn;
+            gq.rope_sin_tk = t + 3 * tn;
+            gq.rope_ldt = c.N;
+        }
         RC(K.gemm(gq, EPI_QKV_ROPE, s));
 
         F5AttnArgs at;
@@ -951,8 +974,8 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d gf%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-             (int)c.use_mask, g_fuse_ln, g_q_premul, f5hf::f5_gemm_debug_flags, a->workspace);
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, g_fuse_ln, g_q_premul, g_qkv_tr, f5hf::f5_gemm_debug_flags, a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
         // a text-to-speech service sees a new (N, nt) on almost every call and capture + instantiate of ~5000 nodes costs more
@@ -1084,6 +1107,10 @@ extern "C" int f5_debug_set_convpos_xcd_map(int on) {
 }
 extern "C" int f5_debug_set_ln_fusion(int on) {
     g_fuse_ln = on ? 1 : 0;       // part of the launch sequence, hence of the graph key
+    return 0;
+}
+extern "C" int f5_debug_set_qkv_transposed(int on) {
+    g_qkv_tr = on ? 1 : 0;
     return 0;
 }
 extern "C" int f5_debug_set_q_premul(int on) {
@@ -1220,6 +1247,17 @@ extern "C" int f5_op_quantize_mx(const float* x, int ldx, void* q, int ldq, void
     return f5_launch_quantize_mx(x, ldx, (uint8_t*)q, ldq, (uint8_t*)scales, rows, cols, (hipStream_t)stream);
 }
 
+// pair-major twins of the rotation tables ([dim_head/2][seq_len], the q pair multiplied by qscale) and an op-level hook that hands
+// them to f5_op_qkv_rope: with all four set (and the q factor of f5_debug_set_op_q_premul folded into the q pair by the caller)
+// the 256x256 kernel accumulates the q / k tiles transposed, as sample() does.  Null = off.
+static const float* g_op_rope_t[4] = {nullptr, nullptr, nullptr, nullptr};
+extern "C" int f5_debug_set_op_rope_tables_t(const float* cos_tq, const float* sin_tq, const float* cos_tk, const float* sin_tk) {
+    g_op_rope_t[0] = cos_tq;
+    g_op_rope_t[1] = sin_tq;
+    g_op_rope_t[2] = cos_tk;
+    g_op_rope_t[3] = sin_tk;
+    return 0;
+}
 // op-level twin of the engine's q pre-multiplication (run_dit): when set (single-segment operands only), f5_op_qkv_rope scales
 // the q columns by this factor and f5_op_attention treats q as already carrying scale * log2(e).  0 (default) = plain q.
 static float g_op_q_premul = 0.0f;
@@ -1278,11 +1316,20 @@ extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_
     g.heads = heads;
     g.dmodel = dmodel;
     g.q_premul = nseg == 1 ? g_op_q_premul : 0.0f;
+    g.rope_cos_tq = g_op_rope_t[0];
+    g.rope_sin_tq = g_op_rope_t[1];
+    g.rope_cos_tk = g_op_rope_t[2];
+    g.rope_sin_tk = g_op_rope_t[3];
+    g.rope_ldt = seq_len;
     g.vt[0] = (op16_t*)vt_hi;
     g.vt[1] = (op16_t*)vt_lo;
     return g_ops.gemm(g, EPI_QKV_ROPE, (hipStream_t)stream);
 }
 
+extern "C" int f5_op_rope_table_t(float* cos_tq, float* sin_tq, float* cos_tk, float* sin_tk, int seq_len, int dim_head, float qscale,
+                                  void* stream) {
+    return f5_launch_rope_table_t(cos_tq, sin_tq, cos_tk, sin_tk, seq_len, seq_len, dim_head, qscale, (hipStream_t)stream);
+}
 extern "C" int f5_op_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, void* stream) {
     return f5_launch_rope_table(cos_t, sin_t, seq_len, dim_head, (hipStream_t)stream);
 }

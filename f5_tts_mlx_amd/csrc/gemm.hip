@@ -543,7 +543,7 @@ __device__ __forceinline__ void glds16(const op16_t* gptr, op16_t* lds_wave_base
 // V (QKV columns >= 2*dmodel) is written TRANSPOSED, Vt[(b*H+h)*64+d][n]: staged [d][64 tokens (+8)] and stored along
 // the token axis; those 16-byte stores may be only 2-byte aligned (legal on gfx950, tools/probes/unaligned.hip) and
 // are split element-wise where a chunk crosses a batch-element boundary.
-template <int EPI, int MBW, int NBW>
+template <int EPI, int MBW, int NBW, bool VONLY = false>
 __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
                                                      int colbase, int lane) {
     constexpr int W = 32 * NBW;
@@ -555,7 +555,7 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
     float bcol[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
-    const bool is_v = (EPI == EPI_QKV_ROPE) && (colbase >= 2 * p.dmodel);
+    const bool is_v = VONLY || ((EPI == EPI_QKV_ROPE) && (colbase >= 2 * p.dmodel));   // VONLY: the q / k tiles went elsewhere
 
     if (!is_v) {
         op16_t* rh = reg;
@@ -684,6 +684,129 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
     }
 }
 
+// 16-bit row-major outputs (FF1 + GELU, plain 16-bit) from a TRANSPOSED accumulator tile, D = W A^T: lane = token, registers =
+// 4 consecutive features per group (feature = 8*(r>>2) + 4*hi + (r&3)).  staged_epilogue_bf16 above turns the usual layout
+// (lane = feature) into row segments with one 2-byte LDS write per element; here a lane's 4 features are ONE 8-byte LDS write
+// into the same [32 tokens][W + 8] image, and the read-back / 16-byte global stores in full row segments are unchanged: 8x
+// fewer LDS write instructions per tile, bias lane-uniform.  The wave picks the layout by the operand order of its MFMAs
+// (f5_gemm256_kernel, V2_MM).
+template <int EPI, int MBW, int NBW>
+__device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0, int colbase,
+                                                   int lane) {
+    constexpr int W = 32 * NBW;
+    constexpr int LD = W + 8;
+    constexpr int CPR = W / 8;             // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;          // rows per store instruction
+    const int hi = lane >> 5, lcol = lane & 31;
+    const bool two = p.out_bf[1] != nullptr;
+    op16_t* rh = reg;
+    op16_t* rl = reg + 32 * LD;
+    f32x4 b4[NBW][4];                      // bias of the lane's feature groups (the same for every 32-token block)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            b4[nb][rg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colbase + nb * 32 + rg * 8 + hi * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) {
+        const int rowblk = row0 + mb * 32;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float v[4];
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) {
+                    v[ri] = acc[mb][nb][rg * 4 + ri] + b4[nb][rg][ri];
+                    if (EPI == EPI_GELU_TANH) v[ri] = f5_gelu_tanh(v[ri]);
+                    if (EPI == EPI_GELU_ERF_BF16) v[ri] = f5_gelu_erf(v[ri]);
+                }
+                const int so = lcol * LD + nb * 32 + rg * 8 + hi * 4;
+                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])};
+                if (two) *reinterpret_cast<u32x2*>(&rl[so]) = u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
+            const int grow = rowblk + lrow;
+            if (grow < p.M) {
+                const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
+                *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
+                if (two) *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The q / k column tiles of the QKV projection from a TRANSPOSED accumulator tile (256x256 kernel): as staged_epilogue_tr, with the
+// rotation applied in-lane -- the pair (2i, 2i+1) sits in neighbouring registers, so no cross-lane exchange -- from PAIR-major
+// tables ([dim_head/2][positions]: the 32 lanes of a half wave hold 32 consecutive tokens and read 128 contiguous bytes per
+// factor; the straight tile reads a token-major table with 2 lines per load but needs 64 loads and 32 lane swaps per 32 x 64
+// block).  q_premul is folded into the q tables by the host.  dit.py:136-158.
+template <int MBW, int NBW>
+__device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
+                                                        int colbase, int lane) {
+    constexpr int W = 32 * NBW;
+    constexpr int LD = W + 8;
+    constexpr int CPR = W / 8;
+    constexpr int RPI = 64 / CPR;
+    const int hi = lane >> 5, lcol = lane & 31;
+    const bool two = p.out_bf[1] != nullptr;
+    const bool isq = colbase < p.dmodel;
+    const float* ct = isq ? p.rope_cos_tq : p.rope_cos_tk;
+    const float* st = isq ? p.rope_sin_tq : p.rope_sin_tk;
+    op16_t* rh = reg;
+    op16_t* rl = reg + 32 * LD;
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) {
+        const int rowblk = row0 + mb * 32;
+        int row = rowblk + lcol;
+        if (row > p.M - 1) row = p.M - 1;                    // rows past the end compute a valid rotation and are never stored
+        const int n = row % p.seq_len;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            // one batch of loads per 32-feature block: 16 rotation factors + 4 bias quads (the accumulators leave ~90 free VGPRs)
+            float c0[4], c1[4], s0[4], s1[4];
+            f32x4 b4[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c = colbase + nb * 32 + rg * 8 + hi * 4;
+                const int j0 = (c & 63) >> 1;
+                c0[rg] = ct[(size_t)j0 * p.rope_ldt + n];
+                c1[rg] = ct[(size_t)(j0 + 1) * p.rope_ldt + n];
+                s0[rg] = st[(size_t)j0 * p.rope_ldt + n];
+                s1[rg] = st[(size_t)(j0 + 1) * p.rope_ldt + n];
+                b4[rg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float a0 = acc[mb][nb][rg * 4 + 0] + b4[rg][0], a1 = acc[mb][nb][rg * 4 + 1] + b4[rg][1];
+                const float a2 = acc[mb][nb][rg * 4 + 2] + b4[rg][2], a3 = acc[mb][nb][rg * 4 + 3] + b4[rg][3];
+                // same expressions as the straight tile: even column v*c - partner*s, odd column v*c + partner*s
+                const float o0 = a0 * c0[rg] - a1 * s0[rg], o1 = a1 * c0[rg] + a0 * s0[rg];
+                const float o2 = a2 * c1[rg] - a3 * s1[rg], o3 = a3 * c1[rg] + a2 * s1[rg];
+                const int so = lcol * LD + nb * 32 + rg * 8 + hi * 4;
+                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(o0, o1), f5_pack2(o2, o3)};
+                if (two) *reinterpret_cast<u32x2*>(&rl[so]) = u32x2{f5_pack2_lo(o0, o1), f5_pack2_lo(o2, o3)};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
+            const int grow = rowblk + lrow;
+            if (grow < p.M) {
+                const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
+                *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
+                if (two) *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // x += gate * ((acc + bias) * keep)  (dit.py:319,323): fp32 tile staged [32 rows][W+4] so that the read-modify-write of
 // the residual stream uses 16-byte accesses; the residual values are loaded before the LDS round trip.
 template <int MBW, int NBW>
@@ -750,7 +873,9 @@ __device__ __forceinline__ const char* v2_uniform_ptr(const void* ptr) {
 // in length from CU to CU, the epilogues (bursts of HBM writes: x += ... is 8 B per output) of different CUs no longer
 // coincide and run under other CUs' main loops; the last round is also perfectly balanced.  Results are deterministic
 // (fixed summation order); they differ from the data-parallel schedule only in fp32 summation order of split tiles.
-template <int EPI, bool SK>
+// QT (EPI_QKV_ROPE only): q / k column tiles accumulated transposed (staged_epilogue_tr_rope), V tiles straight; its own
+// instantiation so that the straight q / k epilogue does not sit in the same 256-register budget
+template <int EPI, bool SK, bool QT = false>
 __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles_n, int ntiles, float* sk_part, int* sk_flag,
                                                          int* sk_err, int sk_hybrid) {
     __shared__ __attribute__((aligned(16))) op16_t smem[2 * 4 * V2_HALF_ELEMS];   // [A0,A1,B0,B1][ring buffer][128*64]
@@ -980,7 +1105,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     op16x8 af[2][4], bfr[2][4];
 #define V2_FRAG_A(PAR, ks, rowoff) (*reinterpret_cast<const op16x8*>(pa[ks] + (PAR) * V2_HALF_ELEMS + (rowoff) * BK))
 #define V2_FRAG_B(PAR, ks, rowoff) (*reinterpret_cast<const op16x8*>(pb[ks] + (PAR) * V2_HALF_ELEMS + (rowoff) * BK))
-#define V2_KSTEP(PAR, tt)                                                                                               \
+#define V2_MM(TR_, A_, B_, C_) ((TR_) ? F5_MFMA32(B_, A_, C_, 0, 0, 0) : F5_MFMA32(A_, B_, C_, 0, 0, 0))
+#define V2_KSTEP(PAR, tt, TR_)                                                                                             \
     {                                                                                                                   \
         /* phase 1: A(mq=0), B(nq=0); quadrant (0,0); issue A0(t+1) */                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
@@ -990,13 +1116,13 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         if ((tt) + 1 < t1) V2_ISSUE_A(1 - PAR, 0, Apn, a_k0);                                            \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
-                acc[mb][0] = F5_MFMA32(af[mb][ks], bfr[0][ks], acc[mb][0], 0, 0, 0);      \
+                acc[mb][0] = V2_MM(TR_, af[mb][ks], bfr[0][ks], acc[mb][0]);                                            \
         /* phase 2: B(nq=1); quadrant (0,1); issue A1(t+1) */                                                           \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) bfr[1][ks] = V2_FRAG_B(PAR, ks, 32);                           \
         if ((tt) + 1 < t1) V2_ISSUE_A(1 - PAR, 1, Apn, a_k0);                                            \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
-                acc[mb][1] = F5_MFMA32(af[mb][ks], bfr[1][ks], acc[mb][1], 0, 0, 0);      \
+                acc[mb][1] = V2_MM(TR_, af[mb][ks], bfr[1][ks], acc[mb][1]);                                            \
         V2_BARRIER(); /* every wave has finished reading the B halves of this tile */                                   \
         /* phase 3: A(mq=1); quadrant (1,1); issue B0(t+2) */                                                           \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
@@ -1004,13 +1130,13 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         if ((tt) + 2 < t1) V2_ISSUE_B(PAR, 0, Wpn, b_k0);                                                \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
-                acc[2 + mb][1] = F5_MFMA32(af[mb][ks], bfr[1][ks], acc[2 + mb][1], 0, 0, 0); \
+                acc[2 + mb][1] = V2_MM(TR_, af[mb][ks], bfr[1][ks], acc[2 + mb][1]);                                    \
         V2_BARRIER(); /* every wave has finished reading the A halves of this tile */                                   \
         /* phase 4: quadrant (1,0) from registers; issue B1(t+2) */                                                     \
         if ((tt) + 2 < t1) V2_ISSUE_B(PAR, 1, Wpn, b_k0);                                                \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                \
             _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                            \
-                acc[2 + mb][0] = F5_MFMA32(af[mb][ks], bfr[0][ks], acc[2 + mb][0], 0, 0, 0); \
+                acc[2 + mb][0] = V2_MM(TR_, af[mb][ks], bfr[0][ks], acc[2 + mb][0]);                                    \
         /* next tile's operands: everything but the two B halves just issued for tile t+2 must have landed */           \
         if ((tt) + 2 < t1) {                                                                             \
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                            \
@@ -1033,11 +1159,27 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     }
     const op16_t* Apn = a_seg == 1 ? p.A[1] : p.A[0];   // operand (bf16x3 segment) pointers of the tiles being staged
     const op16_t* Wpn = b_seg == 2 ? p.W[1] : p.W[0];
+    // 16-bit row-major outputs: the tile is accumulated TRANSPOSED (operands swapped in every MFMA) for staged_epilogue_tr; the
+    // straight order stays selectable for A/B (gemm flag 16384).  Both loop copies end in their own epilogue: no join with 128
+    // live accumulator registers.
+    constexpr bool TR_EPI = !SK && (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
+    if ((TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel)) {       // workgroup-uniform
+        for (int tt = t0; tt < t1; tt += 2) {
+            V2_KSTEP(0, tt, true);
+            if (tt + 1 < t1) V2_KSTEP(1, tt + 1, true);
+        }
+        if ((p.debug_flags & 1) == 0) {
+            if (QT) staged_epilogue_tr_rope<4, 2>(p, acc, smem + wave * 8192, m0 + wm * 128, n0 + wn * 64, ln);
+            else staged_epilogue_tr<EPI, 4, 2>(p, acc, smem + wave * 8192, m0 + wm * 128, n0 + wn * 64, ln);
+        }
+        continue;
+    }
     for (int tt = t0; tt < t1; tt += 2) {
-        V2_KSTEP(0, tt);
-        if (tt + 1 < t1) V2_KSTEP(1, tt + 1);
+        V2_KSTEP(0, tt, false);
+        if (tt + 1 < t1) V2_KSTEP(1, tt + 1, false);
     }
 #undef V2_KSTEP
+#undef V2_MM
 #undef V2_FRAG_A
 #undef V2_FRAG_B
 
@@ -1094,7 +1236,9 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
         continue;
     }
-    if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
+    if (QT) {                                                               // (the q / k tiles finished above)
+        staged_epilogue_bf16<EPI, 4, 2, true>(p, acc, smem + wave * 8192, m0 + wm * 128, n0 + wn * 64, ln);
+    } else if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
         staged_epilogue_bf16<EPI, 4, 2>(p, acc, smem + wave * 8192, m0 + wm * 128, n0 + wn * 64, ln);
     } else if (EPI == EPI_RESID_GATE) {
         if (p.debug_flags & 8) atomic_epilogue_resid<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, ln);     // experiment, see atomic_epilogue_resid
@@ -1144,9 +1288,14 @@ static int launch_v2(const F5GemmArgs& a, hipStream_t stream) {
     const int ntiles = tiles_m * tiles_n;
     F5GemmArgs ab = a;
     ab.nband = (f5_gemm_nband > 0 && tiles_n > f5_gemm_nband && tiles_n % f5_gemm_nband == 0 && !f5_gemm_streamk) ? f5_gemm_nband : 0;
+    // staged_epilogue_tr reads the bias as 16-byte quads: an unaligned bias vector takes the straight-order path
+    if (a.bias != nullptr && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) ab.debug_flags |= 16384;
     if (f5_gemm_streamk && g_sk_part && ntiles >= g_sk_P) {
         hipLaunchKernelGGL((f5_gemm256_kernel<EPI, true>), dim3(g_sk_P), dim3(512), 0, stream, a, tiles_n, ntiles, g_sk_part,
                            g_sk_flag, g_sk_flag + g_sk_P, f5_gemm_streamk == 2 ? 1 : 0);
+    } else if (EPI == EPI_QKV_ROPE && ab.rope_cos_tk != nullptr) {
+        hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false, EPI == EPI_QKV_ROPE>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles,
+                           (float*)nullptr, (int*)nullptr, (int*)nullptr, 0);
     } else {
         hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles,
                            (float*)nullptr, (int*)nullptr, (int*)nullptr, 0);
@@ -2039,6 +2188,16 @@ int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
         case EPI_RESID_GATE: return launch_epi<EPI_RESID_GATE>(a, stream);
         case EPI_QKV_ROPE:
             F5_REQUIRE(a.dmodel % 128 == 0 && a.N == 3 * a.dmodel, "gemm(qkv): N must be 3*dmodel, dmodel %% 128 == 0");
+            F5_REQUIRE(a.rope_cos && a.rope_sin, "gemm(qkv): token-major rotation tables missing");
+            if (a.rope_cos_tk || a.rope_cos_tq) {
+                // pair-major tables = transposed q / k tiles on the 256x256 kernel: every 256-column tile must lie inside one of the
+                // q | k | v ranges, the bias is read as 16-byte quads; gemm flag 16384 = A/B against the straight tiles
+                F5_REQUIRE(a.rope_cos_tq && a.rope_sin_tq && a.rope_cos_tk && a.rope_sin_tk && a.rope_ldt >= a.seq_len,
+                           "gemm(qkv): pair-major rotation tables incomplete");
+                const bool ok = a.dmodel % 256 == 0 && (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+                                (f5_gemm_debug_flags & 16384) == 0;
+                if (!ok) a.rope_cos_tq = a.rope_sin_tq = a.rope_cos_tk = a.rope_sin_tk = nullptr;
+            }
             return launch_epi<EPI_QKV_ROPE>(a, stream);
         case EPI_ADDROWS: return launch_epi<EPI_ADDROWS>(a, stream);
         case EPI_RESID_KEEP: return launch_epi<EPI_RESID_KEEP>(a, stream);

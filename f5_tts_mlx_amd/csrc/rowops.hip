@@ -460,6 +460,30 @@ __global__ void rope_table_kernel(float* __restrict__ cos_t, float* __restrict__
         sin_t[(size_t)n * half + j] = sinf(a);
     }
 }
+// PAIR-major twins of the tables above for the transposed q / k tiles of the 256x256 QKV kernel (gemm.hip staged_epilogue_tr_rope):
+// [dim_head/2][ldt], position contiguous, so that 32 lanes holding 32 consecutive tokens read one 128-byte line.  Same fp32
+// expression for the angle; the q pair carries the factor the engine folds into q (softmax scale * log2 e, or 1).
+__global__ void rope_table_t_kernel(float* __restrict__ cos_tq, float* __restrict__ sin_tq, float* __restrict__ cos_tk,
+                                    float* __restrict__ sin_tk, int seq_len, int ldt, int dim_head, float qscale) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (n >= seq_len) return;
+    const float inv = 1.0f / powf(10000.0f, (float)(2 * j) / (float)dim_head);  // rope.py:23
+    const float a = (float)n * inv;                                              // fp32 product, rope.py:45
+    const float c = cosf(a), s = sinf(a);
+    const size_t o = (size_t)j * ldt + n;
+    cos_tk[o] = c;
+    sin_tk[o] = s;
+    cos_tq[o] = c * qscale;
+    sin_tq[o] = s * qscale;
+}
+int f5_launch_rope_table_t(float* cos_tq, float* sin_tq, float* cos_tk, float* sin_tk, int seq_len, int ldt, int dim_head, float qscale,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(rope_table_t_kernel, dim3(f5_cdiv(seq_len, 64), dim_head / 2), dim3(64), 0, s, cos_tq, sin_tq, cos_tk, sin_tk,
+                       seq_len, ldt, dim_head, qscale);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
 int f5_launch_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, hipStream_t s) {
     hipLaunchKernelGGL(rope_table_kernel, dim3(seq_len), dim3(64), 0, s, cos_t, sin_t, seq_len, dim_head);
     F5_LAUNCH_CHECK();

@@ -130,6 +130,10 @@ int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_hi, const v
                    const float* rope_cos, const float* rope_sin, void* qk_hi, void* qk_lo, void* vt_hi, void* vt_lo, int B,
                    int seq_len, int npad, int heads, int dmodel, int nseg, void* stream);
 int f5_op_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, void* stream);
+/* PAIR-major twins of the rotation tables, [dim_head/2][seq_len], the q pair multiplied by qscale (1 = plain q): with them the
+ * 256x256 QKV kernel accumulates the q / k column tiles transposed (rotation pairs in-lane); sample() builds its own */
+int f5_op_rope_table_t(float* cos_tq, float* sin_tq, float* cos_tk, float* sin_tk, int seq_len, int dim_head, float qscale,
+                       void* stream);
 /* dit.py:29-50 one grouped conv + Mish; mode 0 -> bf16 out, mode 1 -> out_f32 += */
 int f5_op_convpos(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias, void* out_hi,
                   void* out_lo, float* out_f32, int B, int seq_len, int C, int groups, int taps, int nseg, int mode,
@@ -220,6 +224,8 @@ int f5_debug_set_gemm_tile(int sel);
  *            requesting them before the K loop (A/B of the default; identical bits);
  * bits 9-11 (512 / 1024 / 2048): experiment -- the 256x256 residual GEMM touches 1/4, 1/2 or all 128-byte lines of its x tile
  *            before the main loop (cache prefetch of the read half of the read-modify-write; identical bits);
+ * bit 14 (16384): the 256x256 kernel accumulates 16-bit-output tiles (FF1, plain 16-bit, q / k of QKV) in the straight order with
+ *            2-byte staging writes instead of transposed with 8-byte ones (A/B; identical bits for FF1 / plain);
  * bits 4-7 (timing only, garbage results; tile overrides 10 / 13 with the bf16 epilogue): 16 = no operand loads after the prologue,
  * 32 = no MFMAs, 64 = no LDS fragment reads, 128 = no workgroup barrier (combinations 96, 112, 144, 240 are instantiated) */
 int f5_debug_set_gemm_flags(int v);
@@ -243,6 +249,8 @@ int f5_debug_set_convpos_tps(int taps);     /* conv-pos kernel: weight slabs per
 int f5_debug_set_convpos_xcd_map(int on);   /* conv-pos kernel: 1 (default) = groups dealt to XCDs, 0 = plain 3-D block numbering */
 int f5_debug_set_gemm_nband(int n);         /* 256x256 GEMM: tiles numbered in bands of n column tiles (0 = n fastest) */
 int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the residual GEMMs of small-M launches (default 0: measured slower) */
+int f5_debug_set_qkv_transposed(int on);    /* 1 (default): sample() hands the pair-major rotation tables to the QKV projection (256x256 kernel: transposed q / k tiles) */
+int f5_debug_set_op_rope_tables_t(const float* cos_tq, const float* sin_tq, const float* cos_tk, const float* sin_tk); /* op-level twin for f5_op_qkv_rope; NULLs = off */
 int f5_debug_set_q_premul(int on);          /* 1 (default): sample() multiplies q by softmax_scale * log2(e) in the QKV epilogue (single-segment operand modes) */
 int f5_debug_set_op_q_premul(float factor); /* op-level twin: f5_op_qkv_rope scales q by factor, f5_op_attention expects q pre-scaled; 0 = off (default) */
 int f5_debug_set_attn_variant(int bits);   /* experiment bits of attention versions 5 / 6 (see attention.hip) */

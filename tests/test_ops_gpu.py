@@ -96,19 +96,19 @@ def test_gemm_epilogues(lib, epi):
 QPRE = 0.125 * 1.4426950408889634     # softmax scale * log2(e): what the engine folds into q (F5GemmArgs::q_premul)
 
 
-def _attention_case(lib, B, H, N, kv_len, nseg, seed=0, premul=False):
+def _attention_case(lib, B, H, N, kv_len, nseg, seed=0, premul=False, tr_tables=False):
     """premul: the op-level twin of the engine's default -- q leaves the QKV epilogue multiplied by scale * log2(e) and the
     attention kernels take their scores in exp2 units (single-segment operands only)."""
     if premul:
         assert nseg == 1
         E.check(lib.f5_debug_set_op_q_premul(C.c_float(QPRE)))
     try:
-        _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul)
+        _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul, tr_tables)
     finally:
         E.check(lib.f5_debug_set_op_q_premul(C.c_float(0.0)))
 
 
-def _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul):
+def _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul, tr_tables=False):
     D = H * 64
     r = rng(seed)
     x = randn(r, B * N, D)
@@ -123,8 +123,31 @@ def _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul):
     qk = [torch.zeros((B * N, 2 * D), dtype=op_dtype(), device=DEV) for _ in range(2)]
     vt = [torch.zeros((B * H, 64, npad), dtype=op_dtype(), device=DEV) for _ in range(2)]
     bias_d = bias.to(DEV)
-    E.check(lib.f5_op_qkv_rope(P(x_hi), P(x_lo), P(w_hi), P(w_lo), P(bias_d), P(cos_t), P(sin_t), P(qk[0]), P(qk[1]),
-                               P(vt[0]), P(vt[1]), B, N, npad, H, D, nseg, stream()), "qkv_rope")
+    tt = None
+    if tr_tables:
+        # pair-major rotation tables (the q pair carrying the q factor): the 256x256 kernel then accumulates the q / k tiles
+        # transposed, as sample() does at large batch
+        tt = [torch.empty((32, N), device=DEV) for _ in range(4)]
+        E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), N, 64, C.c_float(QPRE if premul else 1.0), stream()))
+        assert torch.equal(tt[2].T.contiguous(), cos_t) and torch.equal(tt[3].T.contiguous(), sin_t)
+        E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
+    try:
+        E.check(lib.f5_op_qkv_rope(P(x_hi), P(x_lo), P(w_hi), P(w_lo), P(bias_d), P(cos_t), P(sin_t), P(qk[0]), P(qk[1]),
+                                   P(vt[0]), P(vt[1]), B, N, npad, H, D, nseg, stream()), "qkv_rope")
+        sync()
+        if tr_tables:       # the straight tiles must give the same 16-bit values (same expressions; report if contraction differs)
+            qk2 = [torch.zeros_like(qk[0]) for _ in range(2)]
+            vt2 = [torch.zeros_like(vt[0]) for _ in range(2)]
+            E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+            E.check(lib.f5_op_qkv_rope(P(x_hi), P(x_lo), P(w_hi), P(w_lo), P(bias_d), P(cos_t), P(sin_t), P(qk2[0]), P(qk2[1]),
+                                       P(vt2[0]), P(vt2[1]), B, N, npad, H, D, nseg, stream()), "qkv_rope")
+            sync()
+            dq = float((qk[0].float() - qk2[0].float()).abs().max())
+            print(f"[qkv transposed vs straight tiles] B{B} H{H} N{N} nseg={nseg} premul={premul}: max |dq| = {dq:.3e}, "
+                  f"identical = {torch.equal(qk[0], qk2[0])}")
+            assert dq <= 2.0 ** -8 * float(qk2[0].float().abs().max()) and torch.equal(vt[0], vt2[0])
+    finally:
+        E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
     out = [torch.zeros((B * N, D), dtype=op_dtype(), device=DEV) for _ in range(2)]
     kv = torch.tensor(kv_len, dtype=torch.int32, device=DEV) if kv_len is not None else None
     E.check(lib.f5_op_attention(P(qk[0]), P(qk[1]), P(vt[0]), P(vt[1]), P(out[0]), P(out[1]), P(kv), B, H, N, npad, D,
@@ -505,6 +528,46 @@ def test_gemm_v2_identity_and_repeat(lib, force_v2):
     for _ in range(3):   # repeated launches: the LDS ring / counted waits must not leave stale state
         out, _, _ = _gemm(lib, a, w, None, 0, 1)
         assert torch.equal(out, w.T.contiguous()[:256]), "v2 C tile layout / staging is wrong"
+
+
+@pytest.mark.parametrize("nseg", [1, 3])
+@pytest.mark.parametrize("epi", [1, 2, 8])
+def test_gemm_v2_16bit_epilogues_transposed_tile(lib, force_v2, epi, nseg):
+    """16-bit row-major outputs of the 256x256 kernel (plain, GELU-tanh = FF1, GELU-erf): the tile is accumulated transposed
+    (MFMA operands swapped) and staged with one 8-byte LDS write per 4 features.  Must match the fp64 reference on asymmetric
+    data (a transposed or permuted tile cannot pass) and equal, bit for bit, the straight-order path (gemm flag 16384), with
+    ragged M, bias, one- and three-segment operands."""
+    for (M, N, K) in ((700, 512, 256), (1000, 768, 128), (256, 256, 64)):
+        r = rng(M + N + K + epi)
+        a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.3)
+        pre = (a.double() if nseg == 3 else bf16r(a).double()) @ (w.double() if nseg == 3 else bf16r(w).double()).T + bias.double()
+        ref = pre if epi == 1 else (F.gelu(pre, approximate="tanh") if epi == 2 else F.gelu(pre))
+        outs = {}
+        for flags in (0, 16384):
+            E.check(lib.f5_debug_set_gemm_flags(flags))
+            try:
+                _, hi, lo = _gemm(lib, a, w, bias, epi, nseg)
+            finally:
+                E.check(lib.f5_debug_set_gemm_flags(0))
+            outs[flags] = (hi.clone(), lo.clone() if lo is not None else None)
+        got = join(outs[0][0], outs[0][1] if nseg == 3 else None)
+        mx, _, _ = report(f"gemm256 16-bit epilogue {epi} nseg={nseg} {M}x{N}x{K}", got, ref)
+        assert mx <= (1e-4 if nseg == 3 else 2 ** -8 * float(ref.abs().max()) + 1e-3)
+        assert torch.equal(outs[0][0].view(torch.int16), outs[16384][0].view(torch.int16)), "transposed and straight tiles differ"
+        if nseg == 3:
+            assert torch.equal(outs[0][1].view(torch.int16), outs[16384][1].view(torch.int16))
+
+
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_qkv_transposed_tiles_256_kernel(lib, force_v2, nseg):
+    """QKV projection on the 256x256 kernel with the q / k column tiles accumulated transposed (rotation pairs in-lane,
+    pair-major tables, 8-byte staging writes) and the V tiles straight: element-wise against the fp64 projection + rotation,
+    against the straight-tile kernel, and through the attention that consumes it; one- and three-segment operands, q plain or
+    carrying scale * log2(e), ragged batches whose rows straddle 32-token blocks, dmodel 256 and 1024."""
+    for premul in ((False, True) if nseg == 1 else (False,)):
+        _attention_case(lib, 2, 4, 300, [300, 211], nseg, seed=21, premul=premul, tr_tables=True)
+        _attention_case(lib, 3, 4, 203, [203, 130, 1], nseg, seed=22, premul=premul, tr_tables=True)
+    _attention_case(lib, 1, 16, 937, None, nseg, seed=24, premul=nseg == 1, tr_tables=True)
 
 
 @pytest.mark.parametrize("nseg", [1, 3])
