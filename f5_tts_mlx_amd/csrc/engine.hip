@@ -1080,6 +1080,7 @@ F5_DECL_KNOB(f5_gemm_v3_prio)
 F5_DECL_KNOB(f5_gemm_ring_default)
 F5_DECL_KNOB(f5_gemm_order)
 F5_DECL_KNOB(f5_gemm_nband)
+F5_DECL_KNOB(f5_gemm_qkv_small_tile)
 F5_DECL_KNOB(f5_gemm_debug_flags)
 F5_DECL_KNOB(f5_gemm_tile_override)
 extern "C" int f5_op_set_operand_type(int fp16) {
@@ -1155,6 +1156,11 @@ extern "C" int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles) {
     F5_REQUIRE(v == 2 || v == 3, "big GEMM kernel must be 2 (256x256) or 3 (128x256, two workgroups per CU)");
     F5_SET_BOTH(f5_gemm_big_kernel, v);
     F5_SET_BOTH(f5_gemm_v3_stagger, stagger_cycles);
+    return 0;
+}
+extern "C" int f5_debug_set_gemm_qkv_tile(int v) {
+    F5_REQUIRE(v == 0 || v == 12 || v == 13, "small-M QKV tile must be 0 (auto), 12 or 13 (8-wave 128x256 ring with transposed q / k wave tiles)");
+    F5_SET_BOTH(f5_gemm_qkv_small_tile, v);
     return 0;
 }
 extern "C" int f5_debug_set_gemm_nband(int v) {

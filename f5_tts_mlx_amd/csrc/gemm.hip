@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
 #pragma unroll
     for (int e = 0; e < 8; ++e) abl_frag[e] = (op16_t)0;
     if (ABL & 4) asm volatile("" : "+v"(abl_frag));
-#define RING_STEP(ST_, jj_)                                                                                         \
+#define RING_STEP(ST_, jj_, TR_)                                                                                       \
     {                                                                                                               \
         /* tile jj must have landed; up to NST-2 younger tiles may stay in flight (conservative vmcnt(0) at the tail) */ \
         if ((jj_) + NST - 2 < Tg) {                                                                                 \
@@ -1470,16 +1470,35 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
                 _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                   \
                     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                             \
                         if (ABL & 2) asm volatile("" ::"v"(af[mb]), "v"(bfr[nb]));                                  \
-                        else acc[mb][nb] = F5_MFMA32(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0); \
+                        else if (TR_) acc[mb][nb] = F5_MFMA32(bfr[nb], af[mb], acc[mb][nb], 0, 0, 0);               \
+                        else acc[mb][nb] = F5_MFMA32(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);                        \
                     }                                                                                               \
             }                                                                                                       \
         }                                                                                                           \
     }
+    // EPI_QKV_ROPE with pair-major rotation tables on the 8-wave instances: the q / k wave tiles are accumulated transposed and
+    // leave through staged_epilogue_tr_rope (wave-uniform choice; the block tile lies inside one of the q | k | v ranges, so
+    // every wave of the workgroup takes the same side and meets the same barriers).  The 4-wave instances keep the straight
+    // tiles: an earlier LDS-free variant of this path returned stale values on a few lanes there, nondeterministically
+    // (profiles/r02/qkv_direct_epilogue_rejected.txt), and the cause was not found.
+    constexpr bool QKV_TR_OK = EPI == EPI_QKV_ROPE && (32 * NB) % 64 == 0 && (NB & (NB - 1)) == 0 && KS == 1 && WM * WN == 8;
+    if (QKV_TR_OK && p.rope_cos_tk != nullptr && n0 + wn * (32 * NB) < 2 * p.dmodel) {
+        for (int jj = 0; jj < nit; jj += NST) {
+            RING_STEP(0, jj, true);
+            if (NST > 1 && jj + 1 < nit) RING_STEP(1 % NST, jj + 1, true);
+            if (NST > 2 && jj + 2 < nit) RING_STEP(2 % NST, jj + 2, true);
+            if (NST > 3 && jj + 3 < nit) RING_STEP(3 % NST, jj + 3, true);
+        }
+        __syncthreads();                                  // the ring is dead: its LDS becomes the staging area
+        staged_epilogue_tr_rope<MB, NB>(p, acc, smem_all + wave * small_tile_stage_elems<NB>(), m0 + wm * (32 * MB), n0 + wn * (32 * NB),
+                                        lane);
+        return;
+    }
     for (int jj = 0; jj < nit; jj += NST) {
-        RING_STEP(0, jj);
-        if (NST > 1 && jj + 1 < nit) RING_STEP(1 % NST, jj + 1);
-        if (NST > 2 && jj + 2 < nit) RING_STEP(2 % NST, jj + 2);
-        if (NST > 3 && jj + 3 < nit) RING_STEP(3 % NST, jj + 3);
+        RING_STEP(0, jj, false);
+        if (NST > 1 && jj + 1 < nit) RING_STEP(1 % NST, jj + 1, false);
+        if (NST > 2 && jj + 2 < nit) RING_STEP(2 % NST, jj + 2, false);
+        if (NST > 3 && jj + 3 < nit) RING_STEP(3 % NST, jj + 3, false);
     }
 #undef RING_STEP
 #undef RING_ISSUE
@@ -2096,6 +2115,7 @@ int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4
                                 // 7 = 128x256 v3, 8 = 128x192 8-wave ring, 9 = 128x128 8-wave ring, 10 / 11 = 64x128 / 128x128 split-K ring
 int f5_gemm_debug_flags = 0;
 int f5_gemm_big_kernel = 2;       // auto mode, large shapes: 2 = 256x256 (1 WG/CU), 3 = 128x256 (2 WG/CU, overlapped epilogue)
+int f5_gemm_qkv_small_tile = 0;   // small-M QKV projection with pair-major tables: 0 = auto tiles, 12 / 13 = 8-wave 128x256 ring, transposed q / k
 int f5_gemm_ring_default = 1;   // auto mode: small tiles use the global_load_lds ring kernel
 // the large-shape kernels (256x256, 128x256) have no fused LN tail (at those sizes LN-modulate is HBM-bound, not launch-bound)
 static bool gemm_uses_big_kernel(const F5GemmArgs& a) {
@@ -2130,6 +2150,14 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     if constexpr (EPI == EPI_BF16) {
         const int abl = (a.debug_flags >> 4) & 15;
         if (abl && (sel == 13 || sel == 10) && a.N % 256 == 0) return launch_ring_ablate(a, sel, abl, stream);
+    }
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        // batch-1-sized QKV projection with pair-major tables: one round of 8-wave 128 x 256 tiles with transposed q / k wave tiles
+        // (f5_gemm_qkv_small_tile = 13 / 12) instead of 64 x 128 register-staged tiles (0)
+        if (sel == 0 && (f5_gemm_qkv_small_tile == 12 || f5_gemm_qkv_small_tile == 13) && a.rope_cos_tk != nullptr && a.N % 256 == 0) {
+            const long t128x256 = (long)f5_cdiv(a.M, 128) * (a.N / 256);
+            if (t128x256 <= 256) sel = f5_gemm_qkv_small_tile;
+        }
     }
     if (sel == 12 || sel == 13) {
         if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_BF16 || EPI == EPI_GELU_TANH) {

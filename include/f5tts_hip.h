@@ -247,6 +247,7 @@ int f5_debug_set_attn_version(int v);
 /* timing-only ablations of the attention kernel (results are wrong unless 0) */
 int f5_debug_set_convpos_tps(int taps);     /* conv-pos kernel: weight slabs per pipeline step, 0 = auto (4 for small grids), 1 / 2 / 4 */
 int f5_debug_set_convpos_xcd_map(int on);   /* conv-pos kernel: 1 (default) = groups dealt to XCDs, 0 = plain 3-D block numbering */
+int f5_debug_set_gemm_qkv_tile(int sel);    /* small-M QKV projection with pair-major tables: 0 = auto tiles, 12 / 13 = 8-wave 128x256 ring, q / k wave tiles transposed */
 int f5_debug_set_gemm_nband(int n);         /* 256x256 GEMM: tiles numbered in bands of n column tiles (0 = n fastest) */
 int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the residual GEMMs of small-M launches (default 0: measured slower) */
 int f5_debug_set_qkv_transposed(int on);    /* 1 (default): sample() hands the pair-major rotation tables to the QKV projection (256x256 kernel: transposed q / k tiles) */

@@ -571,6 +571,26 @@ def test_qkv_transposed_tiles_256_kernel(lib, force_v2, nseg):
 
 
 @pytest.mark.parametrize("nseg", [1, 3])
+@pytest.mark.parametrize("tile", [9, 12, 13, "knob12", "knob13"])
+def test_qkv_transposed_wave_tiles_ring8(lib, tile, nseg):
+    """the same on the 8-wave ring kernels (128x128 and 128x256 block tiles, 32x64 / 64x64 / 32x128 wave tiles): forced by the
+    tile override, and chosen by the QKV-only knob at the batch-1 shape (M = 1874: one round of 128x256 tiles)"""
+    knob = isinstance(tile, str)
+    if knob:
+        E.check(lib.f5_debug_set_gemm_qkv_tile(int(tile[-2:])))
+    else:
+        E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        for premul in ((False, True) if nseg == 1 else (False,)):
+            _attention_case(lib, 2, 4, 300, [300, 211], nseg, seed=31, premul=premul, tr_tables=True)
+            _attention_case(lib, 3, 4, 203, [203, 130, 1], nseg, seed=32, premul=premul, tr_tables=True)
+        _attention_case(lib, 2, 16, 937, [937, 800], nseg, seed=34, premul=nseg == 1, tr_tables=True)
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))
+        E.check(lib.f5_debug_set_gemm_qkv_tile(0))
+
+
+@pytest.mark.parametrize("nseg", [1, 3])
 def test_attention_path_with_v2_qkv(lib, force_v2, nseg):
     _attention_case(lib, 2, 4, 300, [300, 211], nseg, seed=21)     # D = 256: QKV GEMM runs on the 256x256 kernel
 

@@ -22,6 +22,7 @@ for kv in args[:split]:
     elif k == "attnvar": lib.f5_debug_set_attn_variant(v)
     elif k == "streamk": lib.f5_debug_set_gemm_streamk(v)
     elif k == "gflags": lib.f5_debug_set_gemm_flags(v)      # 8 = residual update by no-return L2 atomics (experiment)
+    elif k == "qkvtile": lib.f5_debug_set_gemm_qkv_tile(v)  # small-M QKV: 0 auto, 12 / 13 = 8-wave 128x256 ring with transposed q / k wave tiles
     elif k == "qkvtr": lib.f5_debug_set_qkv_transposed(v)   # 0 = straight q / k tiles in the 256x256 QKV kernel
     elif k == "qpremul": lib.f5_debug_set_q_premul(v)       # 0 = plain q (attention multiplies by scale * log2 e itself)
     else: raise SystemExit(f"unknown flag {k}")
