@@ -338,7 +338,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU (BASELINE configs[1] = 1, configs[2] = 32)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="utterances per GPU.  Default: 1 on one GPU (BASELINE configs[1]); 32 per GPU when --gpus > 1 "
+                         "(BASELINE configs[3]: batch 256 sharded over 8 GPUs, weak scaling at 32 / GPU)")
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "bf16x3", "mxfp8"])
     ap.add_argument("--vocoder", action="store_true", help="put the Vocos vocoder (random-init) into the HEADLINE timed region")
     ap.add_argument("--config", default=None, choices=["c5"],
@@ -350,10 +352,14 @@ def main():
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (batch 32, bf16, wave-to-wave RTF)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launch, barrier, reduce and report only (no engine)")
     args = ap.parse_args()
+    batch_explicit = args.batch is not None
     if args.config == "c5":
         args.precision, args.vocoder, args.method, args.ode_points = "mxfp8", True, "midpoint", 16
-        if args.batch == 1:
+        if not batch_explicit:
             args.batch = 32
+    if args.batch is None:
+        # the multi-GPU line is BASELINE configs[3] (32 utterances per GPU, weak scaling); the single-GPU line configs[1] (batch 1)
+        args.batch = 32 if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 else 1
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)                 # does not return
@@ -370,6 +376,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    ranks_in_group = dist.get_world_size() if dist_on else 1       # asked of the communicator, not read from the environment
     B = args.batch
 
     def barrier():
@@ -470,7 +477,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_TEXT[args.precision],
             "data": "synthetic (seeded random-init 335M weights, white-noise reference audio, random token ids)",
-            "config": {"workload": f"F5-TTS 335M, {args.ode_points}-point {args.method} (={n_fwd} DiT forwards, CFG), "
+            "config": {"workload": f"{'BASELINE configs[3] (32 utterances / GPU, weak scaling)' if (world > 1 and B == 32) else ('BASELINE configs[1]' if (world == 1 and B == 1) else ('BASELINE configs[2]' if (world == 1 and B == 32) else 'custom batch'))}: "
+                                   f"F5-TTS 335M, {args.ode_points}-point {args.method} (={n_fwd} DiT forwards, CFG), "
                                    f"batch {B}/GPU x 10 s (N=937) utterances, hipGraph={not args.no_graph}"
                                    + (", + Vocos vocoder (mel -> waveform) in the timed region" if args.vocoder else ""),
                        "global_batch": world * B, "seq_len": N_FRAMES, "parallelism": f"dp{world} (utterance sharding)"},
@@ -478,7 +486,7 @@ def main():
             "executed_tflop_per_step": world * B * n_fwd * fwd_exec / 1e12, "reference_tflop_per_step": world * B * n_fwd * fwd_ref / 1e12,
             "whole_path_tflops": head["whole_path_tflops"], "whole_path_frac_of_bf16_peak": head["whole_path_frac_of_bf16_peak"],
             "rtf_mel_only": head["rtf_mel_only"],
-            "weights_load_s": load_s, "weights_broadcast_ms": bcast_ms, "ranks_seen_by_rccl": world if dist_on else 1,
+            "weights_load_s": load_s, "weights_broadcast_ms": bcast_ms, "ranks_seen_by_rccl": ranks_in_group,
             "roofline": dominant, "roofline_kernels": kernels, "roofline_symbol_shares": sym,
         }
         par = parity_against_golden(out[0], args) if not args.vocoder else None
@@ -511,13 +519,22 @@ def main():
             if B != 32:
                 c32, t32, y32, _ = synth_batch(32, first=0, device=device)
                 kw32 = dict(kw, y0=y32)
-                el, o32 = timed_samples(f5, c32, t32, kw32, 2, 1, barrier)
-                s32 = summarize(el / 2 * 1e3, 32)
+                n32 = 5
+                el, o32 = timed_samples(f5, c32, t32, kw32, n32, 1, barrier)
+                s32 = summarize(el / n32 * 1e3, 32)
+                s32["timed_iterations"] = n32
                 p32 = parity_against_golden(o32[0], args)
                 if p32:
                     s32.update(p32)
-                sub[f"b32_{args.precision}"] = s32
                 del c32, t32, y32, o32
+                torch.cuda.empty_cache()
+                if args.precision != "mxfp8":
+                    # the five block kernels at M = 59 968 (the shapes the MFMA-roofline target is quoted on), same live timing
+                    k32, sym32 = kernel_rooflines(args.precision, device, 32, iters=10)
+                    s32["roofline_kernels"] = k32
+                    s32["roofline_symbol_shares"] = sym32
+                    torch.cuda.empty_cache()
+                sub[f"b32_{args.precision}"] = s32
             # (3) the north-star's nominal dtype next to the parity-valid one
             if args.precision != "bf16" and B == 1:
                 mb = make_model("bf16")
@@ -529,6 +546,13 @@ def main():
                     sb.update(pb)
                 sub["b1_bf16"] = sb
                 del mb
+            # (4) what a first-seen shape costs under use_graph="auto" (the Python default: almost every generate() call): the same
+            # kernels launched eagerly, ~5 000 launches per sample, host-bound
+            if B == 1 and not args.no_graph:
+                el, oe = timed_samples(f5, cond, text, dict(kw, use_graph=False), 3, 1, barrier)
+                se = summarize(el / 3 * 1e3, B)
+                se["note"] = "eager launches (no hipGraph): the cost of a shape signature the first time it is seen"
+                sub["b1_eager"] = se
             rec["sub"] = sub
         else:
             rec["rtf"] = None if not args.vocoder else head["rtf_mel_only"]

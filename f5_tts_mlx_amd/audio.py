@@ -80,10 +80,12 @@ def log_mel_spectrogram(audio: torch.Tensor, sample_rate: int = 24_000, n_mels: 
     b, L = audio.shape
     frames = L // hop_length
     out = torch.empty((b, frames, n_mels), dtype=torch.float32, device=audio.device)
-    stream = _eng.stream_ptr(audio.device)
-    # one launch for the whole batch (the reference loops over it in Python, audio.py:195)
-    _eng.check(lib.f5_mel_spectrogram_batch(_eng.ptr(audio), b, C.c_int64(L), _eng.ptr(window), _eng.ptr(fb), n_fft, hop_length,
-                                            n_mels, _eng.ptr(out), stream), "f5_mel_spectrogram_batch")
+    # one launch for the whole batch (the reference loops over it in Python, audio.py:195), on the current stream of the device
+    # that holds the audio, with that device current (a launch on another device's stream would be a device mismatch)
+    with torch.cuda.device(audio.device):
+        stream = _eng.stream_ptr(audio.device)
+        _eng.check(lib.f5_mel_spectrogram_batch(_eng.ptr(audio), b, C.c_int64(L), _eng.ptr(window), _eng.ptr(fb), n_fft, hop_length,
+                                                n_mels, _eng.ptr(out), stream), "f5_mel_spectrogram_batch")
     return out
 
 

@@ -25,7 +25,44 @@ from .utils import (default, exists, fetch_from_hub, lens_to_mask, list_str_to_i
 from .weights import convert_upstream_weights, dequantize_mlx_checkpoint
 
 # The three fixed-grid solvers (cfm.py:38-122) live in the engine, fused with the CFG combine (csrc/rowops.hip: ode_stage_kernel,
-# sequenced by csrc/engine.hip: run_sample_body); there is no host-side ODE loop.
+# sequenced by csrc/engine.hip: run_sample_body); `sample()` has no host-side ODE loop.  The module-level names the reference
+# exports stay importable for user code that integrates its own vector field: one explicit Runge-Kutta driver parameterised by a
+# tableau (stage offsets c, stage weights a of the previous stage only -- all three schemes are "chain" schemes -- and output
+# weights b), over torch tensors instead of mx.arrays.
+
+
+def _explicit_rk(func: Callable, y0: torch.Tensor, t, c, a, b) -> torch.Tensor:
+    """Fixed-grid explicit RK: returns the states at every grid point, y0 first, shape (len(t), *y0.shape)."""
+    states = [y0]
+    y = y0
+    for i in range(len(t) - 1):
+        h = t[i + 1] - t[i]
+        ks = []
+        for cj, aj in zip(c, a):
+            yj = y if not ks else y + (aj * h) * ks[-1]
+            ks.append(func(t[i] + cj * h, yj))
+        incr = None
+        for bj, kj in zip(b, ks):
+            if bj != 0.0:
+                incr = bj * kj if incr is None else incr + bj * kj
+        y = y + h * incr
+        states.append(y)
+    return torch.stack(states)
+
+
+def odeint_euler(func, y0, t):
+    """cfm.py:38-61: forward Euler on the grid t."""
+    return _explicit_rk(func, y0, t, c=(0.0,), a=(0.0,), b=(1.0,))
+
+
+def odeint_midpoint(func, y0, t):
+    """cfm.py:64-91: explicit midpoint rule."""
+    return _explicit_rk(func, y0, t, c=(0.0, 0.5), a=(0.0, 0.5), b=(0.0, 1.0))
+
+
+def odeint_rk4(func, y0, t):
+    """cfm.py:94-122: classic fourth-order Runge-Kutta."""
+    return _explicit_rk(func, y0, t, c=(0.0, 0.5, 0.5, 1.0), a=(0.0, 0.5, 0.5, 1.0), b=(1 / 6, 2 / 6, 2 / 6, 1 / 6))
 
 
 def time_grid(steps: int, sway_sampling_coef: Optional[float]) -> np.ndarray:
@@ -78,7 +115,8 @@ class F5TTS:
         duration_predictor=None,
     ):
         self.frac_lengths_mask = frac_lengths_mask
-        self._mel_spec = default(mel_spec_module, MelSpec(**mel_spec_kwargs))
+        # host audio goes to the MODEL's GPU, not to whichever device happens to be current
+        self._mel_spec = default(mel_spec_module, MelSpec(**dict(dict(device=getattr(transformer, "device", None)), **mel_spec_kwargs)))
         num_channels = default(num_channels, self._mel_spec.n_mels)
         self.num_channels = num_channels
         self.audio_drop_prob = audio_drop_prob
@@ -166,6 +204,7 @@ class F5TTS:
         max_duration=4096,
         y0: Optional[torch.Tensor] = None,       # extension: inject the initial noise (b, n, d)
         use_graph="auto",                        # extension: True / False / "auto" (graph from the 2nd call of a shape on)
+        pad_to: Optional[int] = None,            # extension: padded length of a SHARD of a larger batch = that batch's max duration
     ) -> tuple[torch.Tensor, torch.Tensor]:
         self.eval()
         device = self.transformer.device
@@ -187,6 +226,12 @@ class F5TTS:
         if duration is None and self._duration_predictor is not None:
             duration = self.predict_duration(cond, text, speed)
         text, lens, duration, max_duration = prepare_lengths(text, cond_seq_len, batch, duration, lens, max_duration, method)
+        if pad_to is not None:
+            # GRN (convnext_v2.py:16) and the unmasked conv-pos-embed (dit.py:251) see the padding, so a shard of a batch only
+            # reproduces its rows of the unsharded call when it is padded to the WHOLE batch's maximum (dist.shard_batch)
+            if int(pad_to) < max_duration:
+                raise ValueError(f"pad_to={pad_to} is shorter than this shard's longest duration {max_duration}")
+            max_duration = int(pad_to)
         cond = cond.to(device, torch.float32)
 
         # pad the conditioning mel to max_duration (cfm.py:321); masks are built on the GPU from lens/durations

@@ -11,7 +11,7 @@ stale() {  # $1 = source, $2 = object, $3 = 1 when the source includes the publi
   [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer "$2")" ] || { [ "$3" = 1 ] && [ ../../include/f5tts_hip.h -nt "$2" ]; }
 }
 objs=()
-for f in gemm attention convpos rowops; do
+for f in gemm gemm256 gemm128 attention convpos rowops; do
   for v in 0 1; do
     o=build/${f}_h$v.o
     objs+=($o)

@@ -1075,6 +1075,7 @@ F5_DECL_KNOB(f5_attn_wide)
 F5_DECL_KNOB(f5_attn_kvsplit)
 F5_DECL_KNOB(f5_attn_prio)
 F5_DECL_KNOB(f5_gemm_big_kernel)
+F5_DECL_KNOB(f5_gemm128_pad_lds)
 F5_DECL_KNOB(f5_gemm_v3_stagger)
 F5_DECL_KNOB(f5_gemm_v3_prio)
 F5_DECL_KNOB(f5_gemm_ring_default)
@@ -1088,6 +1089,7 @@ extern "C" int f5_op_set_operand_type(int fp16) {
     g_ops.h = fp16 != 0;
     return 0;
 }
+extern "C" int f5_op_get_operand_type(void) { return g_ops.h ? 1 : 0; }
 // host-side conversions used by f5_load_tensor, exported for the CPU tests (no GPU needed)
 extern "C" uint16_t f5_debug_f2h_bits(float f) { return f5_f2h_bits(f); }
 extern "C" float f5_debug_h_bits2f(uint16_t h) { return f5_h_bits2f(h); }
@@ -1153,9 +1155,13 @@ extern "C" int f5_debug_set_gemm_streamk(int v) {
 }
 extern "C" int f5_debug_gemm_streamk_error() { return f5bf::f5_gemm_streamk_error() | f5hf::f5_gemm_streamk_error(); }
 extern "C" int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles) {
-    F5_REQUIRE(v == 2 || v == 3, "big GEMM kernel must be 2 (256x256) or 3 (128x256, two workgroups per CU)");
+    F5_REQUIRE(v >= 2 && v <= 5, "big GEMM kernel must be 2 (256x256 role-split), 3 (128x256 v3), 4 (256x256 lock-step) or 5 (128x256 prefetching, two per CU)");
     F5_SET_BOTH(f5_gemm_big_kernel, v);
     F5_SET_BOTH(f5_gemm_v3_stagger, stagger_cycles);
+    return 0;
+}
+extern "C" int f5_debug_set_gemm128_pad(int bytes) {
+    F5_SET_BOTH(f5_gemm128_pad_lds, bytes);
     return 0;
 }
 extern "C" int f5_debug_set_gemm_qkv_tile(int v) {

@@ -11,154 +11,12 @@
 // (A_hi,W_lo): products are then exact to ~2^-17 relative, i.e. fp32-class results from bf16 MFMA
 // at 3x the matrix work.
 #include "gemm.hpp"
+#include "gemm_dev.hpp"
 #include "lnrow.hpp"
 
 namespace F5_NS {
 
-#define BK 64
 
-__device__ __forceinline__ int swz_off(int row, int chunk) {
-    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
-}
-
-// Epilogue.  All global LOADS an epilogue needs (bias, gate, residual / addrows values, rope cos/sin, row
-// masks) are issued in batches BEFORE the dependent stores: a load placed between stores to a possibly
-// aliasing pointer is serialised by the compiler (one HBM round trip per element, ~40 us per tile).
-template <int EPI, int MB, int NB>
-__device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn,
-                                               int lane) {
-    const int hi = lane >> 5;
-    const int lcol = lane & 31;
-    int col[NB];
-    bool colok[NB];
-    float bcol[NB], gcol[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        col[nb] = n0 + wn * (32 * NB) + nb * 32 + lcol;
-        colok[nb] = col[nb] < p.N;
-        bcol[nb] = (EPI != EPI_ADDROWS && p.bias != nullptr && colok[nb]) ? p.bias[col[nb]] : 0.0f;
-        gcol[nb] = (EPI == EPI_RESID_GATE && colok[nb]) ? p.gate[col[nb]] : 0.0f;
-    }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int rowblk = m0 + wm * (32 * MB) + mb * 32 + hi * 4;   // row of (rg, ri) = rowblk + rg*8 + ri
-        // ---- batched loads for this 32-row block --------------------------------------------------
-        float pre[16][NB];
-        uint8_t keep[16];
-        if (EPI == EPI_RESID_GATE || EPI == EPI_ADDROWS || EPI == EPI_RESID_KEEP) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rowblk + (r >> 2) * 8 + (r & 3);
-                const bool rowok = row < p.M;
-                keep[r] = 1;
-                if (EPI != EPI_ADDROWS && p.rowkeep != nullptr && rowok) keep[r] = p.rowkeep[row];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    float v = 0.0f;
-                    if (rowok && colok[nb]) {
-                        if (EPI == EPI_RESID_GATE) v = p.out_f32[(size_t)row * p.ldo + col[nb]];
-                        if (EPI == EPI_ADDROWS) v = p.addrows[(size_t)row * p.ldadd + col[nb]];
-                        if (EPI == EPI_RESID_KEEP) v = p.resid[(size_t)row * p.ldres + col[nb]];
-                    }
-                    pre[r][nb] = v;
-                }
-            }
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int rowbase = rowblk + rg * 8;
-            int nbase = 0, bbase = 0;
-            float rc[4][NB], rs[4][NB];
-            if (EPI == EPI_QKV_ROPE) {
-                bbase = rowbase / p.seq_len;
-                nbase = rowbase - bbase * p.seq_len;
-#pragma unroll
-                for (int ri = 0; ri < 4; ++ri) {
-                    int n = nbase + ri;
-                    if (n >= p.seq_len) n -= p.seq_len;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const bool isqk = col[nb] < 2 * p.dmodel;
-                        const int j = (col[nb] & 63) >> 1;
-                        const float qs = (p.q_premul != 0.0f && col[nb] < p.dmodel) ? p.q_premul : 1.0f;
-                        rc[ri][nb] = (isqk && rowbase + ri < p.M) ? p.rope_cos[n * 32 + j] * qs : 1.0f;
-                        rs[ri][nb] = (isqk && rowbase + ri < p.M) ? p.rope_sin[n * 32 + j] * qs : 0.0f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int row = rowbase + ri;
-                const bool rowok = row < p.M;
-                const int r = rg * 4 + ri;
-                int n = nbase + ri, b = bbase;
-                if (EPI == EPI_QKV_ROPE) {
-                    if (n >= p.seq_len) {
-                        n -= p.seq_len;
-                        b += 1;
-                    }
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int c = col[nb];
-                    float v = acc[mb][nb][r] + bcol[nb];
-                    if (EPI == EPI_QKV_ROPE) {
-                        const float partner = __shfl_xor(v, 1, 64);
-                        if (rowok && colok[nb]) {
-                            if (c < 2 * p.dmodel) {
-                                const float o = (c & 1) ? (v * rc[ri][nb] + partner * rs[ri][nb])
-                                                        : (v * rc[ri][nb] - partner * rs[ri][nb]);
-                                op16_t h, l;
-                                f5_split(o, h, l);
-                                p.out_bf[0][(size_t)row * p.ldob + c] = h;
-                                if (p.out_bf[1]) p.out_bf[1][(size_t)row * p.ldob + c] = l;
-                            } else {
-                                const int c2 = c - 2 * p.dmodel;
-                                const int head = c2 >> 6, d = c2 & 63;
-                                const size_t off = ((size_t)(b * p.heads + head) * 64 + d) * p.npad + n;
-                                op16_t h, l;
-                                f5_split(v, h, l);
-                                p.vt[0][off] = h;
-                                if (p.vt[1]) p.vt[1][off] = l;
-                            }
-                        }
-                    } else if (rowok && colok[nb]) {
-                        if (EPI == EPI_F32) {
-                            p.out_f32[(size_t)row * p.ldo + c] = v;
-                        } else if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16) {
-                            if (EPI == EPI_GELU_TANH) v = f5_gelu_tanh(v);
-                            if (EPI == EPI_GELU_ERF_BF16) v = f5_gelu_erf(v);
-                            op16_t h, l;
-                            f5_split(v, h, l);
-                            p.out_bf[0][(size_t)row * p.ldob + c] = h;
-                            if (p.out_bf[1]) p.out_bf[1][(size_t)row * p.ldob + c] = l;
-                        } else if (EPI == EPI_GELU_ERF) {
-                            p.out_f32[(size_t)row * p.ldo + c] = f5_gelu_erf(v);
-                        } else if (EPI == EPI_RESID_GATE) {
-                            if (keep[r] == 0) v = 0.0f;
-                            const float xn = pre[r][nb] + gcol[nb] * v;
-                            // fused LN tail: another XCD's workgroup reads these rows back inside this kernel -> agent-scope
-                            // (sc1, write-through) store; the XCDs' L2s are not coherent with each other
-                            if (p.ln_counter) __hip_atomic_store(&p.out_f32[(size_t)row * p.ldo + c], xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            else p.out_f32[(size_t)row * p.ldo + c] = xn;
-                        } else if (EPI == EPI_ADDROWS) {
-                            v += pre[r][nb];
-                            p.out_f32[(size_t)row * p.ldo + c] = v;
-                            op16_t h, l;
-                            f5_split(v, h, l);
-                            p.out_bf[0][(size_t)row * p.ldob + c] = h;
-                            if (p.out_bf[1]) p.out_bf[1][(size_t)row * p.ldob + c] = l;
-                        } else if (EPI == EPI_RESID_KEEP) {
-                            v += pre[r][nb];
-                            if (keep[r] == 0) v = 0.0f;
-                            p.out_f32[(size_t)row * p.ldo + c] = v;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
 
 // x += gate * ((acc + bias) * keep) (EPI_RESID_GATE) with the ADD done by the L2's atomic units (global_atomic_add_f32 without
 // return value), straight from the accumulator registers.  MEASURED SLOWER, kept as an experiment behind gemm flag 8
@@ -530,342 +388,7 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
 // stay in flight across the barrier.  Barriers: end of phases 2, 3 (WAR on the slots about to be
 // overwritten) and 4 (RAW for the next tile).
 // =================================================================================================
-#define V2_HALF_ELEMS (128 * BK)
 
-__device__ __forceinline__ void glds16(const op16_t* gptr, op16_t* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),
-                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
-}
-
-// ---- LDS-staged epilogues (used by the 256x256 and the 128x256 kernels).  A wave owns a (32*MBW) x (32*NBW) tile
-// and a private LDS region; the MFMA C layout (lane = column, registers = rows) is turned into 16-byte global accesses
-// in full row segments.  bf16 row-major outputs (FF1 / q / k / plain bf16): 32-row passes, [32][W+8] hi (+ lo).
-// V (QKV columns >= 2*dmodel) is written TRANSPOSED, Vt[(b*H+h)*64+d][n]: staged [d][64 tokens (+8)] and stored along
-// the token axis; those 16-byte stores may be only 2-byte aligned (legal on gfx950, tools/probes/unaligned.hip) and
-// are split element-wise where a chunk crosses a batch-element boundary.
-template <int EPI, int MBW, int NBW, bool VONLY = false>
-__device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
-                                                     int colbase, int lane) {
-    constexpr int W = 32 * NBW;
-    constexpr int LD = W + 8;
-    constexpr int CPR = W / 8;             // 16-byte chunks per row
-    constexpr int RPI = 64 / CPR;          // rows per store instruction
-    const int hi = lane >> 5, lcol = lane & 31;
-    const bool two = p.out_bf[1] != nullptr;
-    float bcol[NBW];
-#pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
-    const bool is_v = VONLY || ((EPI == EPI_QKV_ROPE) && (colbase >= 2 * p.dmodel));   // VONLY: the q / k tiles went elsewhere
-
-    if (!is_v) {
-        op16_t* rh = reg;
-        op16_t* rl = reg + 32 * LD;
-#pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) {
-            const int rowblk = row0 + mb * 32;
-            // RoPE factors of the whole 32-row block, issued as ONE batch of loads (in a one-round launch the epilogue is a
-            // latency chain: four dependent batches cost four round trips).  The table index depends on the column only through
-            // its position inside the head, i.e. on the parity of nb; rows >= M read a valid entry and are never stored.
-            constexpr int PAR = NBW >= 2 ? 2 : 1;
-            float rc[4][4][PAR], rs[4][4][PAR];
-            if (EPI == EPI_QKV_ROPE) {
-                // q columns carry the softmax scale * log2(e) (F5GemmArgs::q_premul) folded into their rotation factors
-                const float qs = (p.q_premul != 0.0f && colbase < p.dmodel) ? p.q_premul : 1.0f;
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int nbase = (rowblk + rg * 8 + hi * 4) % p.seq_len;
-#pragma unroll
-                    for (int ri = 0; ri < 4; ++ri) {
-                        int n = nbase + ri;
-                        if (n >= p.seq_len) n -= p.seq_len;
-#pragma unroll
-                        for (int q = 0; q < PAR; ++q) {
-                            const int j = ((q * 32 + lcol) & 63) >> 1;
-                            rc[rg][ri][q] = p.rope_cos[n * 32 + j] * qs;
-                            rs[rg][ri][q] = p.rope_sin[n * 32 + j] * qs;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-#pragma unroll
-                for (int ri = 0; ri < 4; ++ri) {
-                    const int r = rg * 4 + ri;
-                    const int lrow = ri + 8 * rg + 4 * hi;
-#pragma unroll
-                    for (int nb = 0; nb < NBW; ++nb) {
-                        float v = acc[mb][nb][r] + bcol[nb];
-                        if (EPI == EPI_GELU_TANH) v = f5_gelu_tanh(v);
-                        if (EPI == EPI_GELU_ERF_BF16) v = f5_gelu_erf(v);
-                        if (EPI == EPI_QKV_ROPE) {
-                            const float partner = __shfl_xor(v, 1, 64);
-                            const float c = rc[rg][ri][nb & (PAR - 1)], sn = rs[rg][ri][nb & (PAR - 1)];
-                            v = (lcol & 1) ? (v * c + partner * sn) : (v * c - partner * sn);
-                        }
-                        op16_t h, l;
-                        f5_split(v, h, l);
-                        rh[lrow * LD + nb * 32 + lcol] = h;
-                        if (two) rl[lrow * LD + nb * 32 + lcol] = l;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < 32 / RPI; ++i) {
-                const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
-                const int grow = rowblk + lrow;
-                if (grow < p.M) {
-                    const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
-                    *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
-                    if (two)
-                        *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    } else {
-        // ---- V: transposed staging, [W d-rows][32*MP tokens (+8 pad)] per pass of MP 32-row blocks, hi then lo
-        constexpr int MP = MBW >= 2 ? 2 : 1;
-        static_assert(MBW % MP == 0, "row blocks per pass");
-        constexpr int TLD = 32 * MP + 8;
-        constexpr int CPD = 4 * MP;           // 16-byte chunks per d-row
-        const int head0 = (colbase - 2 * p.dmodel) >> 6;
-        const bool two_v = p.vt[1] != nullptr;
-#pragma unroll
-        for (int mq = 0; mq < MBW / MP; ++mq) {
-#pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                if (part == 1 && !two_v) break;
-#pragma unroll
-                for (int mb = 0; mb < MP; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            float v[4];
-#pragma unroll
-                            for (int ri = 0; ri < 4; ++ri) v[ri] = acc[mq * MP + mb][nb][rg * 4 + ri] + bcol[nb];
-                            const u32x2 pk = part == 0 ? u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])}
-                                                       : u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
-                            const int tok = mb * 32 + rg * 8 + 4 * hi;
-                            *reinterpret_cast<u32x2*>(&reg[(nb * 32 + lcol) * TLD + tok]) = pk;
-                        }
-                __builtin_amdgcn_wave_barrier();
-                u16* dstbase = reinterpret_cast<u16*>(p.vt[part]);
-#pragma unroll
-                for (int i = 0; i < W * CPD / 64; ++i) {
-                    const int c = i * 64 + lane;
-                    const int d = c / CPD, t0 = (c % CPD) * 8;
-                    const int grow = row0 + mq * (32 * MP) + t0;
-                    if (grow < p.M) {
-                        const int b = grow / p.seq_len;
-                        const int n = grow - b * p.seq_len;
-                        const u32x4 val = *reinterpret_cast<const u32x4*>(&reg[d * TLD + t0]);
-                        const int head = head0 + (d >> 6), dd = d & 63;
-                        u16* dst = dstbase + ((size_t)(b * p.heads + head) * 64 + dd) * p.npad + n;
-                        if (n + 8 <= p.seq_len && grow + 8 <= p.M) {
-                            *reinterpret_cast<u32x4*>(dst) = val;       // may be only 2-byte aligned: legal on gfx950
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const int g2 = grow + e;
-                                if (g2 < p.M) {
-                                    const int b2 = g2 / p.seq_len, n2 = g2 - b2 * p.seq_len;
-                                    dstbase[((size_t)(b2 * p.heads + head) * 64 + dd) * p.npad + n2] = (u16)(val[e >> 1] >> (16 * (e & 1)));
-                                }
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-}
-
-// 16-bit row-major outputs (FF1 + GELU, plain 16-bit) from a TRANSPOSED accumulator tile, D = W A^T: lane = token, registers =
-// 4 consecutive features per group (feature = 8*(r>>2) + 4*hi + (r&3)).  staged_epilogue_bf16 above turns the usual layout
-// (lane = feature) into row segments with one 2-byte LDS write per element; here a lane's 4 features are ONE 8-byte LDS write
-// into the same [32 tokens][W + 8] image, and the read-back / 16-byte global stores in full row segments are unchanged: 8x
-// fewer LDS write instructions per tile, bias lane-uniform.  The wave picks the layout by the operand order of its MFMAs
-// (f5_gemm256_kernel, V2_MM).
-template <int EPI, int MBW, int NBW>
-__device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0, int colbase,
-                                                   int lane) {
-    constexpr int W = 32 * NBW;
-    constexpr int LD = W + 8;
-    constexpr int CPR = W / 8;             // 16-byte chunks per row
-    constexpr int RPI = 64 / CPR;          // rows per store instruction
-    const int hi = lane >> 5, lcol = lane & 31;
-    const bool two = p.out_bf[1] != nullptr;
-    op16_t* rh = reg;
-    op16_t* rl = reg + 32 * LD;
-    f32x4 b4[NBW][4];                      // bias of the lane's feature groups (the same for every 32-token block)
-#pragma unroll
-    for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-            b4[nb][rg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colbase + nb * 32 + rg * 8 + hi * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) {
-        const int rowblk = row0 + mb * 32;
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                float v[4];
-#pragma unroll
-                for (int ri = 0; ri < 4; ++ri) {
-                    v[ri] = acc[mb][nb][rg * 4 + ri] + b4[nb][rg][ri];
-                    if (EPI == EPI_GELU_TANH) v[ri] = f5_gelu_tanh(v[ri]);
-                    if (EPI == EPI_GELU_ERF_BF16) v[ri] = f5_gelu_erf(v[ri]);
-                }
-                const int so = lcol * LD + nb * 32 + rg * 8 + hi * 4;
-                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])};
-                if (two) *reinterpret_cast<u32x2*>(&rl[so]) = u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
-            }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 32 / RPI; ++i) {
-            const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
-            const int grow = rowblk + lrow;
-            if (grow < p.M) {
-                const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
-                *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
-                if (two) *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// The q / k column tiles of the QKV projection from a TRANSPOSED accumulator tile (256x256 kernel): as staged_epilogue_tr, with the
-// rotation applied in-lane -- the pair (2i, 2i+1) sits in neighbouring registers, so no cross-lane exchange -- from PAIR-major
-// tables ([dim_head/2][positions]: the 32 lanes of a half wave hold 32 consecutive tokens and read 128 contiguous bytes per
-// factor; the straight tile reads a token-major table with 2 lines per load but needs 64 loads and 32 lane swaps per 32 x 64
-// block).  q_premul is folded into the q tables by the host.  dit.py:136-158.
-template <int MBW, int NBW>
-__device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
-                                                        int colbase, int lane) {
-    constexpr int W = 32 * NBW;
-    constexpr int LD = W + 8;
-    constexpr int CPR = W / 8;
-    constexpr int RPI = 64 / CPR;
-    const int hi = lane >> 5, lcol = lane & 31;
-    const bool two = p.out_bf[1] != nullptr;
-    const bool isq = colbase < p.dmodel;
-    const float* ct = isq ? p.rope_cos_tq : p.rope_cos_tk;
-    const float* st = isq ? p.rope_sin_tq : p.rope_sin_tk;
-    op16_t* rh = reg;
-    op16_t* rl = reg + 32 * LD;
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) {
-        const int rowblk = row0 + mb * 32;
-        int row = rowblk + lcol;
-        if (row > p.M - 1) row = p.M - 1;                    // rows past the end compute a valid rotation and are never stored
-        const int n = row % p.seq_len;
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            // one batch of loads per 32-feature block: 16 rotation factors + 4 bias quads (the accumulators leave ~90 free VGPRs)
-            float c0[4], c1[4], s0[4], s1[4];
-            f32x4 b4[4];
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int c = colbase + nb * 32 + rg * 8 + hi * 4;
-                const int j0 = (c & 63) >> 1;
-                c0[rg] = ct[(size_t)j0 * p.rope_ldt + n];
-                c1[rg] = ct[(size_t)(j0 + 1) * p.rope_ldt + n];
-                s0[rg] = st[(size_t)j0 * p.rope_ldt + n];
-                s1[rg] = st[(size_t)(j0 + 1) * p.rope_ldt + n];
-                b4[rg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const float a0 = acc[mb][nb][rg * 4 + 0] + b4[rg][0], a1 = acc[mb][nb][rg * 4 + 1] + b4[rg][1];
-                const float a2 = acc[mb][nb][rg * 4 + 2] + b4[rg][2], a3 = acc[mb][nb][rg * 4 + 3] + b4[rg][3];
-                // same expressions as the straight tile: even column v*c - partner*s, odd column v*c + partner*s
-                const float o0 = a0 * c0[rg] - a1 * s0[rg], o1 = a1 * c0[rg] + a0 * s0[rg];
-                const float o2 = a2 * c1[rg] - a3 * s1[rg], o3 = a3 * c1[rg] + a2 * s1[rg];
-                const int so = lcol * LD + nb * 32 + rg * 8 + hi * 4;
-                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(o0, o1), f5_pack2(o2, o3)};
-                if (two) *reinterpret_cast<u32x2*>(&rl[so]) = u32x2{f5_pack2_lo(o0, o1), f5_pack2_lo(o2, o3)};
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 32 / RPI; ++i) {
-            const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
-            const int grow = rowblk + lrow;
-            if (grow < p.M) {
-                const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
-                *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
-                if (two) *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// x += gate * ((acc + bias) * keep)  (dit.py:319,323): fp32 tile staged [32 rows][W+4] so that the read-modify-write of
-// the residual stream uses 16-byte accesses; the residual values are loaded before the LDS round trip.
-template <int MBW, int NBW>
-__device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], float* reg, int row0,
-                                                      int colbase, int lane) {
-    constexpr int W = 32 * NBW;
-    constexpr int LD = W + 4;
-    constexpr int CPR = W / 4;             // 16-byte chunks per row
-    constexpr int RPI = 64 / CPR;          // rows per instruction
-    constexpr int NI = 32 / RPI;           // instructions per 32-row pass
-    const int hi = lane >> 5, lcol = lane & 31;
-    float bcol[NBW];
-#pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
-    const int chunk = lane % CPR;
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gate + colbase + chunk * 4);
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) {
-        const int rowblk = row0 + mb * 32;
-        f32x4 xr[NI];
-        float kp[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int grow = rowblk + i * RPI + lane / CPR;
-            const bool ok = grow < p.M;
-            xr[i] = ok ? *reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4)
-                       : f32x4{0.f, 0.f, 0.f, 0.f};
-            kp[i] = (ok && p.rowkeep != nullptr) ? (float)p.rowkeep[grow] : 1.0f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lrow = (r & 3) + 8 * (r >> 2) + 4 * hi;
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) reg[lrow * LD + nb * 32 + lcol] = acc[mb][nb][r] + bcol[nb];
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int lrow = i * RPI + lane / CPR;
-            const int grow = rowblk + lrow;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&reg[lrow * LD + chunk * 4]);
-            if (grow < p.M) {
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = xr[i][e] + g4[e] * (v[e] * kp[i]);
-                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4) = o;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// a wave-uniform pointer the compiler can see is uniform (SGPR pair): lets global_load_lds use the "SGPR base + 32-bit VGPR
-// offset" addressing form, i.e. no per-load 64-bit VALU add
-__device__ __forceinline__ const char* v2_uniform_ptr(const void* ptr) {
-    const uint64_t u = reinterpret_cast<uint64_t>(ptr);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-}
 // SK = stream-K scheduling: the grid is one persistent workgroup per CU and workgroup `rid` owns the contiguous range
 // [rid*W/P, (rid+1)*W/P) of the W = ntiles*T K-steps (tile-major).  A range is: the HEAD of a tile that the next range
 // finishes (done FIRST: partial sums -> sk_part[rid], flag), the TAIL of a tile begun by the previous range (waits for
@@ -1278,8 +801,7 @@ int f5_gemm_streamk_error() {      // 1 if a consumer ever timed out waiting for
     if (hipMemcpy(&v, g_sk_flag + g_sk_P, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return v;
 }
-int f5_gemm_nband = 4;   // 256x256 kernel: column-tile band width of the tile numbering (0 = n fastest), f5_debug_set_gemm_nband.
-                         // 4 = 2 MB of W per band at K = 1024: sample() at batch 32 1 244 vs 1 260-1 275 ms (profiles/r02/gemm_nband_ab.txt)
+extern int f5_gemm_nband;   // gemm256.hip
 template <int EPI>
 static int launch_v2(const F5GemmArgs& a, hipStream_t stream) {
     F5_REQUIRE((size_t)(a.a_row_mod > 0 ? a.a_row_mod : a.M) * a.lda < (1ull << 31) && (size_t)(a.N + 256) * a.ldw < (1ull << 31),
@@ -2114,7 +1636,7 @@ int f5_launch_quantize_mx(const float* x, int ldx, uint8_t* q, int ldq, uint8_t*
 int f5_gemm_tile_override = 0;  // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 v2, 5 = 64x128 ring, 6 = 64x64 ring,
                                 // 7 = 128x256 v3, 8 = 128x192 8-wave ring, 9 = 128x128 8-wave ring, 10 / 11 = 64x128 / 128x128 split-K ring
 int f5_gemm_debug_flags = 0;
-int f5_gemm_big_kernel = 2;       // auto mode, large shapes: 2 = 256x256 (1 WG/CU), 3 = 128x256 (2 WG/CU, overlapped epilogue)
+int f5_gemm_big_kernel = 2;       // auto mode, large shapes: 2 = 256x256 role-split schedule (gemm256.hip), 3 = 128x256 (2 WG/CU), 4 = 256x256 lock-step
 int f5_gemm_qkv_small_tile = 0;   // small-M QKV projection with pair-major tables: 0 = auto tiles, 12 / 13 = 8-wave 128x256 ring, transposed q / k
 int f5_gemm_ring_default = 1;   // auto mode: small tiles use the global_load_lds ring kernel
 // the large-shape kernels (256x256, 128x256) have no fused LN tail (at those sizes LN-modulate is HBM-bound, not launch-bound)
@@ -2145,7 +1667,11 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     }
     if (sel == 4 || (sel == 0 && v2ok && t256 >= 512)) {
         F5_REQUIRE(v2ok, "gemm: the 256x256 kernel needs N %% 256 == 0 and M >= 256");
-        return launch_v2<EPI>(a, stream);
+        if (f5_gemm_big_kernel == 4 || f5_gemm_streamk) return launch_v2<EPI>(a, stream);      // lock-step predecessor (A/B)
+        if constexpr (EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_RESID_GATE || EPI == EPI_QKV_ROPE) {
+            if (f5_gemm_big_kernel == 5) return f5_launch_gemm128(a, EPI, stream);              // 128x256, two workgroups per CU
+        }
+        return f5_launch_gemm256(a, EPI, stream);
     }
     if constexpr (EPI == EPI_BF16) {
         const int abl = (a.debug_flags >> 4) & 15;

@@ -73,6 +73,10 @@ struct F5GemmArgs {
 };
 
 int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
+// the large-shape kernel (gemm256.hip: 256 x 256 tiles, one workgroup per CU); f5_launch_gemm routes N % 256 == 0, >= 512-tile shapes here
+int f5_launch_gemm256(const F5GemmArgs& a, int epi, hipStream_t stream);
+int f5_launch_gemm128(const F5GemmArgs& a, int epi, hipStream_t stream);   // gemm128.hip: 128 x 256 tiles, two workgroups per CU
+extern int f5_gemm128_pad_lds;
 // true when f5_launch_gemm(a, EPI_RESID_GATE) would run a small-tile kernel that implements the fused LN tail (a.ln_* unset or set)
 bool f5_gemm_resid_ln_fusable(const F5GemmArgs& a);
 

@@ -55,6 +55,8 @@ def gather_outputs(local: torch.Tensor, counts: Sequence[int], group=None) -> to
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bmax = max(counts)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()                       # gloo gathers host tensors (the RCCL job gathers device tensors)
     pad = torch.zeros((bmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None

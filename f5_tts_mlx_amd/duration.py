@@ -155,7 +155,7 @@ class DurationPredictor:
 
     def __init__(self, transformer: DurationTransformer, num_channels=None, mel_spec_kwargs: dict = dict(),
                  vocab_char_map: dict[str, int] | None = None):
-        self._mel_spec = MelSpec(**mel_spec_kwargs)
+        self._mel_spec = MelSpec(**dict(dict(device=getattr(transformer, "device", None)), **mel_spec_kwargs))
         self.num_channels = default(num_channels, self._mel_spec.n_mels)
         self.transformer = transformer
         self.dim = transformer.dim

@@ -37,13 +37,16 @@ class operand_type:
 
     def __init__(self, precision: str):
         self.fp16 = 1 if precision == "f16" else 0
+        self._saved = []
 
     def __enter__(self):
-        check(load_library().f5_op_set_operand_type(self.fp16), "f5_op_set_operand_type")
+        lib = load_library()
+        self._saved.append(int(lib.f5_op_get_operand_type()))      # nested blocks restore what they found, not bf16
+        check(lib.f5_op_set_operand_type(self.fp16), "f5_op_set_operand_type")
         return self
 
     def __exit__(self, *exc):
-        check(load_library().f5_op_set_operand_type(0), "f5_op_set_operand_type")
+        check(load_library().f5_op_set_operand_type(self._saved.pop()), "f5_op_set_operand_type")
         return False
 
 
@@ -119,11 +122,15 @@ def noise_normal(seeds: Sequence[int], durations: Sequence[int], N: int, mel: in
         raise ValueError("one seed per batch element")
     device = torch.device(device)
     y0 = torch.empty((B, int(N), int(mel)), dtype=torch.float32, device=device)
-    scratch = torch.empty(3 * B, dtype=torch.int32, device=device)
-    c_seeds = (C.c_uint64 * B)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds])
-    c_durs = (C.c_int32 * B)(*[int(d) for d in durations])
+    CH = 256                                                     # f5_noise_normal takes at most 256 elements per call
+    scratch = torch.empty(3 * min(B, CH), dtype=torch.int32, device=device)
     with torch.cuda.device(device):
-        check(lib.f5_noise_normal(c_seeds, B, c_durs, int(N), int(mel), ptr(y0), ptr(scratch), stream_ptr(device)), "f5_noise_normal")
+        for b0 in range(0, B, CH):
+            nb = min(CH, B - b0)
+            c_seeds = (C.c_uint64 * nb)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds[b0:b0 + nb]])
+            c_durs = (C.c_int32 * nb)(*[int(d) for d in durations[b0:b0 + nb]])
+            check(lib.f5_noise_normal(c_seeds, nb, c_durs, int(N), int(mel), ptr(y0[b0:b0 + nb]), ptr(scratch), stream_ptr(device)),
+                  "f5_noise_normal")
     return y0
 
 

@@ -118,6 +118,7 @@ int f5_dit_forward(f5_engine* e, const f5_sample_args* args, const float* x, flo
  * 16-bit operand buffers (a_hi, w_hi, qk_hi, out_hi ...) hold bf16 by default; f5_op_set_operand_type(1) switches every
  * f5_op_* call of the process to IEEE fp16 operands (the kernels are built for both), 0 switches back. */
 int f5_op_set_operand_type(int fp16);
+int f5_op_get_operand_type(void);   /* current setting: 0 bf16, 1 fp16 (callers that switch temporarily restore this) */
 /* C = A * W^T (+epilogue), bf16 MFMA; epi codes in csrc/gemm.hpp (0 = fp32 out + bias, 1 = bf16 out) */
 int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, float* out_f32,
                void* out_bf_hi, void* out_bf_lo, int M, int N, int K, int lda, int ldw, int ldo, int nseg, int epi,

@@ -81,7 +81,12 @@ def test_bench_gpus_flag_spawns_the_ranks():
     assert len(lines) == 1, r.stdout                      # rank 0 prints ONE JSON line
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["gpus_arg"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
-    assert rec["scaling"] == "weak" and rec["config"]["global_batch"] == 2 and rec["value"] > 0
+    # more than one GPU defaults to BASELINE configs[3]: 32 utterances per GPU (weak scaling), --batch overrides
+    assert rec["scaling"] == "weak" and rec["config"]["global_batch"] == 64 and rec["value"] > 0
+    rb = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "3", "--dry-run", "--steps", "1", "--warmup", "0"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert rb.returncode == 0, rb.stderr[-2000:]
+    assert json.loads([ln for ln in rb.stdout.splitlines() if ln.startswith("{")][0])["config"]["global_batch"] == 6
     # single process: no launcher, no collective
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0"],
                         capture_output=True, text=True, timeout=120, env=env)

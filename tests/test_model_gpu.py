@@ -510,6 +510,15 @@ def test_device_noise_matches_the_host_generator():
             assert np.isfinite(g).all() and abs(float(g.mean())) < 0.05 + 3.0 / np.sqrt(g.size) and (d * mel < 1000 or abs(float(g.std()) - 1) < 0.05)
         if len(durs) == 3:
             assert np.array_equal(got[0, :50], got[2, :50])
+    # odd element counts (the generator pairs counter i with i + ceil(n / 2): an odd n leaves the last pair half used) and more
+    # than 256 batch elements (the C entry point takes 256 per call; the wrapper chunks)
+    for mel_o, seeds, durs, N in ((7, [5, 6, 7], [5, 1, 9], 9), (3, list(range(300)), [1 + (i % 11) for i in range(300)], 11)):
+        got = noise_normal(seeds, durs, N, mel_o, DEV).cpu().numpy()
+        for b, (sd, d) in enumerate(zip(seeds, durs)):
+            ref = mlx_like_normal(sd, (mel_o, d)).T
+            assert np.all(got[b, d:] == 0.0)
+            diff = np.abs(got[b, :d].astype(np.float64) - ref.astype(np.float64))
+            assert np.all(diff <= np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)), (mel_o, b, d)
 
 
 def test_generate_end_to_end(tiny_weights, tmp_path):
@@ -658,6 +667,92 @@ def test_full_size_full_length_parity_golden():
     assert max(res["f16"]) <= MEL_L1_TOL, res
     assert max(res["bf16x3"]) <= MEL_L1_TOL, res
     assert max(res["bf16"]) <= 3e-2, res                                             # reported; NOT a parity mode
+
+
+def test_batch32_every_utterance_parity():
+    """BASELINE configs[2], the configuration the MFMA roofline is quoted on (335M, batch 32 x N = 937, 32-point Euler + sway +
+    CFG, f16 operands): EVERY utterance of the batched call -- the 256 x 256 GEMM tiles, the large-grid attention kernel, all row
+    ranges of the M = 59 968 launches -- against the same utterance solved alone at batch 1 in `bf16x3` (fp32-class arithmetic on
+    the small-shape kernels, itself pinned to the fp32 oracle's golden for utterance 0), mel L1 <= 1e-3 each (cfm.py:333-336: the
+    key-padding mask exists only when batch > 1; all durations are equal here, so it keeps every key)."""
+    import os
+    import sys
+    from f5test import ROOT
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    cfg = F5TTS_335M
+    w = synthetic_weights(cfg, seed=42)
+    B = 32
+    cond, text, y0, _ = bench.synth_batch(B, 0, DEV)
+    kw = dict(duration=bench.N_FRAMES, steps=bench.ODE_POINTS, method="euler", cfg_strength=2.0, sway_sampling_coef=-1.0)
+    m16 = _model(cfg, w, "f16")
+    out32, _ = F5TTS(transformer=m16).sample(cond, text, y0=y0, **kw)
+    torch.cuda.synchronize()
+    out32 = out32.cpu()
+    assert torch.isfinite(out32).all()
+    del m16
+    torch.cuda.empty_cache()
+    mx3 = _model(cfg, w, "bf16x3")
+    f5x3 = F5TTS(transformer=mx3)
+    worst = 0.0
+    for i in range(B):
+        ref, _ = f5x3.sample(cond[i:i + 1].contiguous(), text[i:i + 1].contiguous(), y0=y0[i:i + 1].contiguous(), **kw)
+        l1 = float((out32[i] - ref[0].cpu()).abs().mean())
+        worst = max(worst, l1)
+        assert l1 <= MEL_L1_TOL, (i, l1)
+        if i == 0:
+            g = np.load(os.path.join(ROOT, "tests", "golden", "full_b1_euler32.npz"))
+            l1g = float((ref[0].cpu() - torch.from_numpy(g["out"])).abs().mean())
+            print(f"[b32 parity] batch-1 bf16x3 reference of utterance 0 vs the fp32 oracle golden: {l1g:.3e}")
+            assert l1g <= 1e-4
+    print(f"[b32 parity] worst utterance of 32: mel L1 {worst:.3e} (gate {MEL_L1_TOL})")
+
+
+def test_f16_range_stress_outlier_weights():
+    """The range hazard of IEEE-half operands (+-65 504), tested instead of argued: trained DiTs carry activation outliers the
+    seeded-random weights do not, so a few adaLN scale rows, FF1 rows and q / k rows of the 335M weights are scaled by 1e2 ... 1e3
+    (LN-modulated activations and FF hidden values of 1e3 ... 1e5, attention scores far outside half's exponent range before the
+    softmax shift).  `f16` (saturating packers, op16.hpp f5_sat) must stay finite and agree with `bf16x3` (fp32-class, range of
+    fp32) to the gate; the scale at which it stops agreeing is reported."""
+    cfg = F5TTS_335M
+    base = synthetic_weights(cfg, seed=42)
+    cond, text, durations, y0 = synth_inputs(cfg, 1, 400, nt=64, n_ref=120, seed=5)
+    r = np.random.default_rng(11)
+    results = {}
+    for scale in (1.0, 1e2, 1e3):
+        w = {k: v.copy() for k, v in base.items()}
+        if scale != 1.0:
+            for blk in (0, 7, 21):
+                pre = f"transformer.transformer_blocks.{blk}."
+                ada = w[pre + "attn_norm.linear.weight"]                     # (6144, 1024): rows 1024..2047 = scale_msa, 4096..5119 = scale_mlp
+                for row in r.integers(1024, 2048, 4):
+                    ada[row] *= scale
+                for row in r.integers(4096, 5120, 4):
+                    ada[row] *= scale
+                ff1 = w[pre + "ff.ff.layers.0.layers.0.weight"]
+                for row in r.integers(0, ff1.shape[0], 4):
+                    ff1[row] *= scale
+                for name in ("attn.to_q.weight", "attn.to_k.weight"):
+                    m = w[pre + name]
+                    for row in r.integers(0, m.shape[0], 2):
+                        m[row] *= np.sqrt(scale)
+        outs = {}
+        for prec in ("bf16x3", "f16"):
+            m = _model(cfg, w, prec)
+            out, _ = F5TTS(transformer=m).sample(cond, text, duration=400, y0=y0, steps=6, method="euler", cfg_strength=2.0)
+            torch.cuda.synchronize()
+            outs[prec] = out.cpu()
+            del m
+            torch.cuda.empty_cache()
+        finite = bool(torch.isfinite(outs["f16"]).all() and torch.isfinite(outs["bf16x3"]).all())
+        l1 = float((outs["f16"] - outs["bf16x3"]).abs().mean())
+        rel = l1 / max(float(outs["bf16x3"].abs().mean()), 1e-12)
+        results[scale] = (finite, l1, rel)
+        print(f"[f16 range] outlier scale {scale:g}: finite {finite}, f16 vs bf16x3 mel L1 {l1:.3e} (relative {rel:.3e})")
+    assert all(v[0] for v in results.values()), results                      # never inf / nan: the packers saturate
+    assert results[1.0][1] <= MEL_L1_TOL and results[1e2][1] <= MEL_L1_TOL, results
+    assert results[1e3][2] <= 1e-2, results                                  # 1e3-scaled rows: still 1 % of the output magnitude
 
 
 def test_back_to_back_calls_without_host_sync_full_size():
