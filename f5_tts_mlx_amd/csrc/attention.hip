@@ -17,6 +17,9 @@
 // for Q, K, V and splits P in registers: 3 MFMAs per product.
 #include "attention.hpp"
 
+#ifndef F5_LAB
+#define F5_LAB 0
+#endif
 namespace F5_NS {
 
 #define KLD 72   // K  tile row stride in elements (144 B)
@@ -41,6 +44,7 @@ __device__ __forceinline__ bool attn_block_map(const F5AttnArgs& p, int qrows, i
     bh = (s / nqb) * 8 + (blockIdx.x & 7);
     return bh < p.B * p.H;
 }
+#if F5_LAB   // round-1 register-staged kernel (f5_debug_set_attn_version 1)
 template <bool HP>
 __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
     constexpr int NP = HP ? 2 : 1;
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(256) void f5_attn_kernel(F5AttnArgs p) {
     }
 }
 
+#endif  // F5_LAB
 // =================================================================================================
 // v2: same math / layouts, but K and V^T tiles go HBM -> LDS with global_load_lds into a ring of NST
 // tiles (3 for bf16: two tiles in flight while one is consumed; 2 for bf16x3), counted vmcnt, ONE barrier per
@@ -527,6 +532,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
     }
 }
 
+#if F5_LAB   // v2w: per-tile maximum, priority variants (superseded by v2f; A/B only)
 // =================================================================================================
 // v2w (bf16, large grids): v2 with TWO 32-query blocks per wave (workgroup = 256 queries).  Every K / V^T fragment read
 // from LDS and every staged tile now feeds twice the MFMAs: the v2 ablations (tools/attn_abl_b1.py) show the tile staging
@@ -738,6 +744,7 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
     }
 }
 
+#endif  // F5_LAB
 // =================================================================================================
 // v2f (large grids, default): v2w with the softmax BOOKKEEPING taken off the per-tile path.  MFMA time and VALU time add on a
 // SIMD (tools/probes/coissue.hip), and at head dim 64 a key costs more VALU than MFMA issue time, so every instruction removed
@@ -1252,6 +1259,7 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
     }
 }
 
+#if F5_LAB   // in-wave software pipelining experiments (v3 / v4 / v5 / v6), all measured slower
 // =================================================================================================
 // v3 (bf16 only): v2 + software pipelining inside the wave.  Ablations of v2 (tools/attn_ablate.py) show that
 // QK^T MFMAs, softmax VALU and PV MFMAs each cost ~1/3 of the time and do not overlap: co-resident waves run the
@@ -1767,14 +1775,20 @@ __global__ __launch_bounds__(64 * NW, 2) void f5_attn5_kernel(F5AttnArgs p) {
     }
 }
 
+#endif  // F5_LAB
+#if F5_LAB
 int f5_attn_version = 2;   // 1 = register-staged, 2 = global_load_lds ring (default), 3/4 = ring + in-wave software pipelining (measured slower); 5 / 6 = pipelined experiment
 int f5_attn_variant = 0;   // experiment bits (see the launcher): 1, 2 = pipelined kernel variants, 4 = plain 2-D block numbering, 8 = eager O rescale in the large-grid kernel
 int f5_attn_ablation = 0;  // timing experiments only
-int f5_attn_wide = -1;     // -1 auto (>= 1024 workgroups), 0 off, 1 force: 256-query workgroups, two query blocks per wave (bf16)
 int f5_attn_prio = 0;      // wide kernel: which phase holds issue priority (0 MFMA clusters, 1 none, 2 softmax section)
-int f5_attn_kvsplit = -1;  // -1 auto, 1 / 2 / 4 = force the in-workgroup KV split (debug hook)
+#else
+static constexpr int f5_attn_version = 2, f5_attn_variant = 0, f5_attn_ablation = 0, f5_attn_prio = 0;   // the shipped configuration
+#endif
+// test hooks that choose among the SHIPPED kernels (the shape heuristics below decide otherwise)
+int f5_attn_wide = -1;     // -1 auto (>= 512 workgroups of 256 queries), 0 off, 1 force: 256-query workgroups, two query blocks per wave
+int f5_attn_kvsplit = -1;  // -1 auto, 1 / 2 / 4 = force the in-workgroup KV split
 
-// 1-D XCD-aware grid (attn_block_map) unless f5_attn_variant bit 2 asks for the plain 2-D numbering
+// 1-D XCD-aware grid (attn_block_map); the lab build's f5_attn_variant bit 2 asks for the plain 2-D numbering
 static dim3 attn_grid(const F5AttnArgs& a, int qrows) {
     const int nqb = f5_cdiv(a.seq_len, qrows);
     if (f5_attn_variant & 4) return dim3(nqb, a.B * a.H);
@@ -1799,6 +1813,7 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
         // 256 WGs 21.4 / 19.1 / 20.1, 512 WGs 31.8 / 37.3 / 38.9
         ks = (wgs <= 160 && ntile >= 8) ? 4 : ((wgs <= 320 && ntile >= 4) ? 2 : 1);
     }
+#if F5_LAB
     // one-pass modes: in-wave software-pipelined kernel (256 queries per workgroup, 8 waves)
     if ((f5_attn_version == 5 || f5_attn_version == 6) && !a.hp && !a.out8 && f5_attn_ablation == 0) {
         // experiment matrix.  waves per workgroup: 8 (256 queries) or 4 (128); packed or single-issue softmax arithmetic;
@@ -1818,17 +1833,23 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
         F5_LAUNCH_CHECK();
         return 0;
     }
-    // large grids (bf16): two query blocks per wave (256 queries per workgroup)
+#endif
+    // large grids (one-pass modes): two query blocks per wave (256 queries per workgroup), no per-tile maximum
     if (f5_attn_version == 2 && f5_attn_ablation == 0 && !a.hp && ks <= 1 &&
         (f5_attn_wide >= 1 || (f5_attn_wide < 0 && (long)f5_cdiv(a.seq_len, 256) * a.B * a.H >= 512))) {
         const dim3 gw = attn_grid(a, 256);
-        if (f5_attn_prio == 0 && !(f5_attn_variant & (8 | 16))) {      // default: no per-tile maximum (variant bit 4 = 16: v2w)
-            if (a.q_prescaled) hipLaunchKernelGGL(f5_attn2f_kernel<true>, gw, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL(f5_attn2f_kernel<false>, gw, dim3(256), 0, stream, a);
-        } else if (f5_attn_prio == 1) hipLaunchKernelGGL(f5_attn2w_kernel<1>, gw, dim3(256), 0, stream, a);
-        else if (f5_attn_prio == 2) hipLaunchKernelGGL(f5_attn2w_kernel<2>, gw, dim3(256), 0, stream, a);
-        else if (f5_attn_variant & 8) hipLaunchKernelGGL((f5_attn2w_kernel<0, false>), gw, dim3(256), 0, stream, a);   // A/B: eager rescale
-        else hipLaunchKernelGGL(f5_attn2w_kernel<0>, gw, dim3(256), 0, stream, a);
+#if F5_LAB
+        if (f5_attn_prio != 0 || (f5_attn_variant & (8 | 16))) {       // A/B: the kernel with a per-tile maximum (v2w) and its priority variants
+            if (f5_attn_prio == 1) hipLaunchKernelGGL(f5_attn2w_kernel<1>, gw, dim3(256), 0, stream, a);
+            else if (f5_attn_prio == 2) hipLaunchKernelGGL(f5_attn2w_kernel<2>, gw, dim3(256), 0, stream, a);
+            else if (f5_attn_variant & 8) hipLaunchKernelGGL((f5_attn2w_kernel<0, false>), gw, dim3(256), 0, stream, a);   // eager rescale
+            else hipLaunchKernelGGL(f5_attn2w_kernel<0>, gw, dim3(256), 0, stream, a);
+            F5_LAUNCH_CHECK();
+            return 0;
+        }
+#endif
+        if (a.q_prescaled) hipLaunchKernelGGL(f5_attn2f_kernel<true>, gw, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(f5_attn2f_kernel<false>, gw, dim3(256), 0, stream, a);
         F5_LAUNCH_CHECK();
         return 0;
     }
@@ -1836,9 +1857,11 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
         if (a.hp) {
             F5_REQUIRE(a.qk[1] && a.vt[1] && a.out[1], "attention: bf16x3 needs lo buffers");
             hipLaunchKernelGGL((f5_attn2s_kernel<true, 2, 2>), grid, dim3(512), 0, stream, a);
+#if F5_LAB
         } else if (f5_attn_variant & 16) {               // A/B: tile maximum on every tile
             if (ks >= 4) hipLaunchKernelGGL((f5_attn2s_kernel<false, 4, 2>), grid, dim3(1024), 0, stream, a);
             else hipLaunchKernelGGL((f5_attn2s_kernel<false, 2, 3>), grid, dim3(512), 0, stream, a);
+#endif
         } else if (ks >= 4) {
             hipLaunchKernelGGL((f5_attn2s_kernel<false, 4, 2, true>), grid, dim3(1024), 0, stream, a);
         } else {
@@ -1849,9 +1872,16 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
     }
     if (a.hp) {
         F5_REQUIRE(a.qk[1] && a.vt[1] && a.out[1], "attention: bf16x3 needs lo buffers");
-        if (f5_attn_version >= 2) hipLaunchKernelGGL((f5_attn2_kernel<true, 0>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((f5_attn_kernel<true>), grid, dim3(256), 0, stream, a);
+#if F5_LAB
+        if (f5_attn_version < 2) {
+            hipLaunchKernelGGL((f5_attn_kernel<true>), grid, dim3(256), 0, stream, a);
+            F5_LAUNCH_CHECK();
+            return 0;
+        }
+#endif
+        hipLaunchKernelGGL((f5_attn2_kernel<true, 0>), grid, dim3(256), 0, stream, a);
     } else {
+#if F5_LAB
         if (f5_attn_version == 3) {
             hipLaunchKernelGGL((f5_attn3_kernel<3>), grid, dim3(256), 0, stream, a);
         } else if (f5_attn_version == 4) {
@@ -1869,6 +1899,9 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
             }
         }
         else hipLaunchKernelGGL((f5_attn_kernel<false>), grid, dim3(256), 0, stream, a);
+#else
+        hipLaunchKernelGGL((f5_attn2_kernel<false, 0>), grid, dim3(256), 0, stream, a);
+#endif
     }
     F5_LAUNCH_CHECK();
     return 0;

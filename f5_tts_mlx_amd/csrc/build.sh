@@ -1,28 +1,35 @@
 #!/bin/bash
 # Build the C-ABI shared library for gfx950 (cross-compiles without a GPU).
 # The kernel sources are compiled twice: bf16 MFMA operands (namespace f5bf) and fp16 operands (-DF5_F16=1, namespace f5hf).
+#   bash build.sh            product library: the kernels sample() / the vocoder / the mel front-end can reach
+#   F5_LAB=1 bash build.sh   lab library (same file name): + the superseded / rejected kernels and the hooks that select them
+#                            (include/f5tts_hip_lab.h).  Objects of the two flavours live in build/ and build_lab/.
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
-mkdir -p build
+LAB=${F5_LAB:-0}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DF5_LAB=$LAB"
+B=build
+KERNELS="gemm gemm256 gemm_f8 attention convpos rowops"
+if [ "$LAB" = 1 ]; then B=build_lab; KERNELS="$KERNELS gemm_lab gemm128"; fi
+mkdir -p $B
 pids=()
 stale() {  # $1 = source, $2 = object, $3 = 1 when the source includes the public C-ABI header
   [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer "$2")" ] || { [ "$3" = 1 ] && [ ../../include/f5tts_hip.h -nt "$2" ]; }
 }
 objs=()
-for f in gemm gemm256 gemm128 attention convpos rowops; do
+for f in $KERNELS; do
   for v in 0 1; do
-    o=build/${f}_h$v.o
+    o=$B/${f}_h$v.o
     objs+=($o)
     if stale $f.hip $o 0; then $HIPCC $FLAGS -DF5_F16=$v -c $f.hip -o $o & pids+=($!); fi
   done
 done
 for f in audio vocoder noise engine; do
-  o=build/$f.o
+  o=$B/$f.o
   objs+=($o)
   if stale $f.hip $o 1; then $HIPCC $FLAGS -c $f.hip -o $o & pids+=($!); fi
 done
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o libf5tts_hip.so
-echo "built $(pwd)/libf5tts_hip.so"
+echo "built $(pwd)/libf5tts_hip.so (F5_LAB=$LAB)"

@@ -68,7 +68,30 @@ struct GraphEntry {
     hipGraphExec_t exec;
     const void* workspace;   // the captured nodes reference this buffer
     uint64_t stamp;          // last use (LRU)
+    hipEvent_t done;         // recorded after every launch: an exec is only destroyed once its last replay has finished
 };
+
+// Per-engine launch options: everything that reaches a kernel as a by-value argument or changes the launch sequence of sample()
+// lives in the engine handle, so two engines of one process keep their own configuration (f5_engine_set_option).  The process-wide
+// f5_debug_set_* hooks only set the DEFAULTS a new engine starts from (and what the per-op entry points f5_op_* use).
+struct F5Options {
+    int q_premul = 1;     // q leaves the QKV epilogue multiplied by softmax_scale * log2(e) (single-segment operand modes)
+    int qkv_tr = 1;       // 256x256 QKV kernel: q / k tiles accumulated transposed (pair-major rotation tables)
+    int fuse_ln = 0;      // LN-modulate fused behind the small-tile residual GEMMs (measured slower, profiles/r02/ln_fusion_ab.txt)
+    int gemm_flags = 0;   // F5GemmArgs::debug_flags of this engine's GEMM launches
+};
+static F5Options g_default_options;
+// bumped by every process-wide launch knob change (f5_debug_set_*): part of the graph key, so a cached hipGraph captured under other
+// knob values is never replayed
+static int g_knob_epoch = 0;
+
+static void destroy_graph_entry(GraphEntry& g) {
+    if (g.done) {
+        (void)hipEventSynchronize(g.done);        // the exec may still be running on the stream of its last launch
+        (void)hipEventDestroy(g.done);
+    }
+    (void)hipGraphExecDestroy(g.exec);
+}
 
 struct f5_engine {
     f5_config cfg;
@@ -92,6 +115,7 @@ struct f5_engine {
     MatBF wout;
     size_t bout;
     Ops ops;                          // kernels of this engine's operand type
+    F5Options opt = g_default_options;
     std::vector<GraphEntry> graphs;   // cached hipGraphExecs, at most graph_cap (least recently used is destroyed)
     std::vector<std::string> seen;    // signatures sampled once in "auto" graph mode (captured on the second sighting)
     int graph_cap = 8;
@@ -266,7 +290,7 @@ extern "C" int f5_engine_create(const f5_config* cfg, int precision, f5_engine**
 
 extern "C" void f5_engine_destroy(f5_engine* e) {
     if (!e) return;
-    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : e->graphs) destroy_graph_entry(g);
     delete e;
 }
 
@@ -277,8 +301,34 @@ extern "C" int f5_engine_set_graph_cache(f5_engine* e, int max_graphs) {
         size_t lru = 0;
         for (size_t i = 1; i < e->graphs.size(); ++i)
             if (e->graphs[i].stamp < e->graphs[lru].stamp) lru = i;
-        (void)hipGraphExecDestroy(e->graphs[lru].exec);
+        destroy_graph_entry(e->graphs[lru]);
         e->graphs.erase(e->graphs.begin() + lru);
+    }
+    return 0;
+}
+extern "C" int f5_engine_set_option(f5_engine* e, const char* name, int value) {
+    F5_REQUIRE(e && name, "null argument");
+    const std::string n(name);
+    if (n == "q_premul") e->opt.q_premul = value ? 1 : 0;
+    else if (n == "qkv_transposed") e->opt.qkv_tr = value ? 1 : 0;
+    else if (n == "ln_fusion") e->opt.fuse_ln = value ? 1 : 0;
+    else if (n == "gemm_flags") e->opt.gemm_flags = value;
+    else {
+        f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags)", name);
+        return 2;
+    }
+    return 0;
+}
+extern "C" int f5_engine_get_option(f5_engine* e, const char* name, int* value) {
+    F5_REQUIRE(e && name && value, "null argument");
+    const std::string n(name);
+    if (n == "q_premul") *value = e->opt.q_premul;
+    else if (n == "qkv_transposed") *value = e->opt.qkv_tr;
+    else if (n == "ln_fusion") *value = e->opt.fuse_ln;
+    else if (n == "gemm_flags") *value = e->opt.gemm_flags;
+    else {
+        f5_set_error("unknown engine option %s", name);
+        return 2;
     }
     return 0;
 }
@@ -486,11 +536,9 @@ struct Ctx {
     int nseg() const { return e->np == 2 ? 3 : 1; }
 };
 
-static int g_q_premul = 1;       // q pre-multiplied by softmax_scale * log2(e) in the QKV epilogue (see run_dit); by-value kernel arguments => graph key
-static int g_qkv_tr = 1;         // 256x256 QKV kernel: q / k tiles accumulated transposed (pair-major rotation tables); by-value arguments => graph key
 // factor folded into q by the QKV epilogue (0 = none): single-segment operand modes only, see run_dit
 static float q_premul_factor(const f5_engine* e) {
-    return (g_q_premul && e->np == 1) ? (1.0f / sqrtf((float)e->cfg.dim_head)) * 1.4426950408889634f : 0.0f;
+    return (e->opt.q_premul && e->np == 1) ? (1.0f / sqrtf((float)e->cfg.dim_head)) * 1.4426950408889634f : 0.0f;
 }
 
 static F5GemmArgs gemm_base(const Ctx& c, const op16_t* a_hi, const op16_t* a_lo, int lda, const MatBF& w, int M, int N, int K,
@@ -508,6 +556,7 @@ static F5GemmArgs gemm_base(const Ctx& c, const op16_t* a_hi, const op16_t* a_lo
     g.K = K;
     g.nseg = c.nseg();
     g.bias = bias;
+    g.debug_flags = c.e->opt.gemm_flags;      // this engine's own flags (f5_engine_set_option)
     return g;
 }
 
@@ -581,8 +630,6 @@ static int run_prep(const Ctx& c, int nfe) {
 // default: bit-identical, but measured SLOWER at batch 1 (88.5 / 90.3 ms per sample against 75.1 / 78.6 on the same boxes,
 // profiles/r02/ln_fusion_ab.txt): a cross-XCD hand-over inside a kernel is three dependent trips to the memory side (write-through
 // ack, counter atomic, agent-scope re-read: ~10 us per GEMM) where the separate LN launch costs 5.2 us.
-namespace f5hf { extern int f5_gemm_debug_flags; }   // by-value kernel argument (set for both builds together) => graph key
-static int g_fuse_ln = 0;
 static int run_dit(const Ctx& c, int j) {
     const f5_engine* e = c.e;
     const f5_config& cf = e->cfg;
@@ -661,6 +708,7 @@ static int run_dit(const Ctx& c, int j) {
             g.K = K_;
             g.nseg = 1;
             g.bias = bias;
+            g.debug_flags = e->opt.gemm_flags;
             return g;
         };
         RC(f5_launch_ln_modulate_f8(c.p<float>(w.x), m6 + D, m6, c.p<uint8_t>(w.h8), c.p<uint8_t>(w.h8s), M, D, 1e-6f, s));
@@ -721,7 +769,7 @@ static int run_dit(const Ctx& c, int j) {
     const float* mf = mod + (size_t)L * 6 * D;  // final adaLN: (scale, shift) order, dit.py:287
     bool h_ready = false;
     auto fuse_ln = [&](F5GemmArgs& g, const float* scale, const float* shift) -> bool {
-        if (!g_fuse_ln || w.lncnt_words == 0 || !K.gemm_resid_ln_fusable(g)) return false;
+        if (!e->opt.fuse_ln || w.lncnt_words == 0 || !K.gemm_resid_ln_fusable(g)) return false;
         g.ln_counter = c.p<int>(w.lncnt);
         g.ln_scale = scale;
         g.ln_shift = shift;
@@ -747,7 +795,7 @@ static int run_dit(const Ctx& c, int j) {
         gq.vt[0] = c.pb(w.vt, 0);
         gq.vt[1] = c.pb(w.vt, 1);
         gq.q_premul = qpre;
-        if (g_qkv_tr) {                                  // pair-major tables (the q pair carries qpre, or 1): used by the 256x256 kernel
+        if (e->opt.qkv_tr) {                             // pair-major tables (the q pair carries qpre, or 1): used by the 256x256 kernel
             const float* t = c.p<float>(w.rope_t);
             const size_t tn = (size_t)32 * c.N;
             gq.rope_cos_tq = t;
@@ -974,8 +1022,8 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-             (int)c.use_mask, g_fuse_ln, g_q_premul, g_qkv_tr, f5hf::f5_gemm_debug_flags, a->workspace);
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, g_knob_epoch, a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
         // a text-to-speech service sees a new (N, nt) on almost every call and capture + instantiate of ~5000 nodes costs more
@@ -1001,7 +1049,7 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
             // entries captured against another workspace are dead (the caller re-allocated it); then make room (LRU)
             for (size_t i = 0; i < e->graphs.size();) {
                 if (e->graphs[i].workspace != a->workspace) {
-                    (void)hipGraphExecDestroy(e->graphs[i].exec);
+                    destroy_graph_entry(e->graphs[i]);
                     e->graphs.erase(e->graphs.begin() + i);
                 } else {
                     ++i;
@@ -1011,7 +1059,7 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
                 size_t lru = 0;
                 for (size_t i = 1; i < e->graphs.size(); ++i)
                     if (e->graphs[i].stamp < e->graphs[lru].stamp) lru = i;
-                (void)hipGraphExecDestroy(e->graphs[lru].exec);
+                destroy_graph_entry(e->graphs[lru]);
                 e->graphs.erase(e->graphs.begin() + lru);
             }
             hipGraph_t graph_h = nullptr;
@@ -1025,9 +1073,13 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
             F5_HIP_CHECK(ec);
             F5_HIP_CHECK(hipGraphInstantiate(&exec, graph_h, nullptr, nullptr, 0));
             (void)hipGraphDestroy(graph_h);
-            e->graphs.push_back({key, exec, a->workspace, ++e->clock});
+            hipEvent_t done = nullptr;
+            F5_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            e->graphs.push_back({key, exec, a->workspace, ++e->clock, done});
         }
         F5_HIP_CHECK(hipGraphLaunch(exec, s));
+        for (auto& g : e->graphs)
+            if (g.exec == exec) F5_HIP_CHECK(hipEventRecord(g.done, s));
     } else {
         RC(run_sample_body(c, a));
     }
@@ -1063,27 +1115,27 @@ extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float
 // ------------------------------------------------------------------------------------------------
 // per-op entry points
 // ------------------------------------------------------------------------------------------------
-// debug knobs live in both kernel builds
+// Test hooks.  They live in both kernel builds (bf16 / fp16 operands) and are process-wide: meant for the op-level tests and the
+// A/B tools, which set them once; a change bumps g_knob_epoch, so no cached hipGraph captured under other values is replayed.
+// The PRODUCT library keeps only the hooks that choose among the kernels sample() itself can reach (tile shapes, attention
+// workgroup shapes, conv-pos pipeline step, tile numbering); everything that selects an experiment exists in the lab build only
+// (F5_LAB=1 bash build.sh: superseded / rejected kernels, ablations, stream-K, priorities).
 #define F5_DECL_KNOB(v) namespace f5bf { extern int v; } namespace f5hf { extern int v; }
-#define F5_SET_BOTH(v, x) do { f5bf::v = (x); f5hf::v = (x); } while (0)
-F5_DECL_KNOB(f5_attn_version)
-F5_DECL_KNOB(f5_attn_ablation)
+#define F5_SET_BOTH(v, x) do { f5bf::v = (x); f5hf::v = (x); ++g_knob_epoch; } while (0)
+#ifndef F5_LAB
+#define F5_LAB 0
+#endif
 F5_DECL_KNOB(f5_convpos_tps)
 F5_DECL_KNOB(f5_convpos_xcd_map)
-F5_DECL_KNOB(f5_attn_variant)
 F5_DECL_KNOB(f5_attn_wide)
 F5_DECL_KNOB(f5_attn_kvsplit)
-F5_DECL_KNOB(f5_attn_prio)
-F5_DECL_KNOB(f5_gemm_big_kernel)
-F5_DECL_KNOB(f5_gemm128_pad_lds)
-F5_DECL_KNOB(f5_gemm_v3_stagger)
-F5_DECL_KNOB(f5_gemm_v3_prio)
 F5_DECL_KNOB(f5_gemm_ring_default)
 F5_DECL_KNOB(f5_gemm_order)
 F5_DECL_KNOB(f5_gemm_nband)
 F5_DECL_KNOB(f5_gemm_qkv_small_tile)
 F5_DECL_KNOB(f5_gemm_debug_flags)
 F5_DECL_KNOB(f5_gemm_tile_override)
+extern "C" int f5_lab_build(void) { return F5_LAB; }      // 1 = this library also carries the experiments
 extern "C" int f5_op_set_operand_type(int fp16) {
     F5_REQUIRE(fp16 == 0 || fp16 == 1, "operand type must be 0 (bf16) or 1 (fp16)");
     g_ops.h = fp16 != 0;
@@ -1094,11 +1146,6 @@ extern "C" int f5_op_get_operand_type(void) { return g_ops.h ? 1 : 0; }
 extern "C" uint16_t f5_debug_f2h_bits(float f) { return f5_f2h_bits(f); }
 extern "C" float f5_debug_h_bits2f(uint16_t h) { return f5_h_bits2f(h); }
 extern "C" uint16_t f5_debug_f2bf_bits(float f) { return f5_f2bf_bits(f); }
-extern "C" int f5_debug_set_attn_version(int v) {
-    F5_REQUIRE(v >= 1 && v <= 6, "attention version must be 1..6");
-    F5_SET_BOTH(f5_attn_version, v);
-    return 0;
-}
 extern "C" int f5_debug_set_convpos_tps(int v) {
     F5_REQUIRE(v == 0 || v == 1 || v == 2 || v == 4, "conv-pos taps per pipeline step must be 0 (auto), 1, 2 or 4");
     F5_SET_BOTH(f5_convpos_tps, v);
@@ -1108,16 +1155,73 @@ extern "C" int f5_debug_set_convpos_xcd_map(int on) {
     F5_SET_BOTH(f5_convpos_xcd_map, on ? 1 : 0);
     return 0;
 }
+// process DEFAULTS of the per-engine options (f5_engine_set_option changes one engine; engines that already exist keep theirs)
 extern "C" int f5_debug_set_ln_fusion(int on) {
-    g_fuse_ln = on ? 1 : 0;       // part of the launch sequence, hence of the graph key
+    g_default_options.fuse_ln = on ? 1 : 0;
     return 0;
 }
 extern "C" int f5_debug_set_qkv_transposed(int on) {
-    g_qkv_tr = on ? 1 : 0;
+    g_default_options.qkv_tr = on ? 1 : 0;
     return 0;
 }
 extern "C" int f5_debug_set_q_premul(int on) {
-    g_q_premul = on ? 1 : 0;
+    g_default_options.q_premul = on ? 1 : 0;
+    return 0;
+}
+extern "C" int f5_debug_set_attn_wide(int v) {
+    F5_REQUIRE(v >= -1 && v <= 1, "attention wide-workgroup switch must be -1 (auto), 0 or 1");
+    F5_SET_BOTH(f5_attn_wide, v);
+    return 0;
+}
+extern "C" int f5_debug_set_attn_kvsplit(int v) {
+    F5_REQUIRE(v == -1 || v == 1 || v == 2 || v == 4, "attention KV split must be -1 (auto), 1, 2 or 4");
+    F5_SET_BOTH(f5_attn_kvsplit, v);
+    return 0;
+}
+extern "C" int f5_debug_set_gemm_qkv_tile(int v) {
+    F5_REQUIRE(v == 0 || v == 12 || v == 13, "small-M QKV tile must be 0 (auto), 12 or 13 (8-wave 128x256 ring with transposed q / k wave tiles)");
+    F5_SET_BOTH(f5_gemm_qkv_small_tile, v);
+    return 0;
+}
+extern "C" int f5_debug_set_gemm_nband(int v) {
+    F5_REQUIRE(v >= 0 && v <= 16, "column-tile band width of the 256x256 tile numbering must be 0 (n fastest) .. 16");
+    F5_SET_BOTH(f5_gemm_nband, v);
+    return 0;
+}
+extern "C" int f5_debug_set_gemm_ring(int v) {
+    F5_SET_BOTH(f5_gemm_ring_default, v ? 1 : 0);
+    return 0;
+}
+extern "C" int f5_debug_set_gemm_order(int v) {
+    F5_REQUIRE(v >= 0 && v <= 2, "gemm order must be 0 (auto), 1 (n fastest) or 2 (m fastest)");
+    F5_SET_BOTH(f5_gemm_order, v);
+    return 0;
+}
+// process-wide GEMM flags, OR-ed into every GEMM launch of the process (op-level tests, A/B tools); an engine's own flags are
+// f5_engine_set_option(e, "gemm_flags", v)
+extern "C" int f5_debug_set_gemm_flags(int v) {
+    F5_SET_BOTH(f5_gemm_debug_flags, v);
+    return 0;
+}
+extern "C" int f5_debug_set_gemm_tile(int sel) {
+    F5_REQUIRE(sel >= 0 && sel <= 13, "gemm tile override must be 0 (auto) .. 13");
+    F5_REQUIRE(F5_LAB || sel != 7, "gemm tile 7 (128x256, two workgroups per CU) exists in the lab build only");
+    F5_SET_BOTH(f5_gemm_tile_override, sel);
+    return 0;
+}
+#if F5_LAB
+F5_DECL_KNOB(f5_attn_version)
+F5_DECL_KNOB(f5_attn_ablation)
+F5_DECL_KNOB(f5_attn_variant)
+F5_DECL_KNOB(f5_attn_prio)
+F5_DECL_KNOB(f5_gemm_big_kernel)
+F5_DECL_KNOB(f5_gemm128_pad_lds)
+F5_DECL_KNOB(f5_gemm_v3_stagger)
+F5_DECL_KNOB(f5_gemm_v3_prio)
+F5_DECL_KNOB(f5_gemm_streamk)
+extern "C" int f5_debug_set_attn_version(int v) {
+    F5_REQUIRE(v >= 1 && v <= 6, "attention version must be 1..6");
+    F5_SET_BOTH(f5_attn_version, v);
     return 0;
 }
 extern "C" int f5_debug_set_attn_variant(int v) {
@@ -1129,19 +1233,9 @@ extern "C" int f5_debug_set_attn_ablation(int v) {
     F5_SET_BOTH(f5_attn_ablation, v);
     return 0;
 }
-extern "C" int f5_debug_set_attn_wide(int v) {
-    F5_REQUIRE(v >= -1 && v <= 1, "attention wide-workgroup switch must be -1 (auto), 0 or 1");
-    F5_SET_BOTH(f5_attn_wide, v);
-    return 0;
-}
 extern "C" int f5_debug_set_attn_prio(int v) {
     F5_REQUIRE(v >= 0 && v <= 2, "attention priority scheme must be 0 (MFMA clusters), 1 (none) or 2 (softmax section)");
     F5_SET_BOTH(f5_attn_prio, v);
-    return 0;
-}
-extern "C" int f5_debug_set_attn_kvsplit(int v) {
-    F5_REQUIRE(v == -1 || v == 1 || v == 2 || v == 4, "attention KV split must be -1 (auto), 1, 2 or 4");
-    F5_SET_BOTH(f5_attn_kvsplit, v);
     return 0;
 }
 extern "C" int f5_debug_set_gemm_streamk(int v) {
@@ -1164,39 +1258,12 @@ extern "C" int f5_debug_set_gemm128_pad(int bytes) {
     F5_SET_BOTH(f5_gemm128_pad_lds, bytes);
     return 0;
 }
-extern "C" int f5_debug_set_gemm_qkv_tile(int v) {
-    F5_REQUIRE(v == 0 || v == 12 || v == 13, "small-M QKV tile must be 0 (auto), 12 or 13 (8-wave 128x256 ring with transposed q / k wave tiles)");
-    F5_SET_BOTH(f5_gemm_qkv_small_tile, v);
-    return 0;
-}
-extern "C" int f5_debug_set_gemm_nband(int v) {
-    F5_REQUIRE(v >= 0 && v <= 16, "column-tile band width of the 256x256 tile numbering must be 0 (n fastest) .. 16");
-    F5_SET_BOTH(f5_gemm_nband, v);
-    return 0;
-}
 extern "C" int f5_debug_set_gemm_v3_prio(int v) {
     F5_REQUIRE(v >= 0 && v <= 2, "128x256 GEMM priority scheme must be 0 (MFMA clusters), 1 (none) or 2 (epilogue)");
     F5_SET_BOTH(f5_gemm_v3_prio, v);
     return 0;
 }
-extern "C" int f5_debug_set_gemm_ring(int v) {
-    F5_SET_BOTH(f5_gemm_ring_default, v ? 1 : 0);
-    return 0;
-}
-extern "C" int f5_debug_set_gemm_order(int v) {
-    F5_REQUIRE(v >= 0 && v <= 2, "gemm order must be 0 (auto), 1 (n fastest) or 2 (m fastest)");
-    F5_SET_BOTH(f5_gemm_order, v);
-    return 0;
-}
-extern "C" int f5_debug_set_gemm_flags(int v) {
-    F5_SET_BOTH(f5_gemm_debug_flags, v);
-    return 0;
-}
-extern "C" int f5_debug_set_gemm_tile(int sel) {
-    F5_REQUIRE(sel >= 0 && sel <= 13, "gemm tile override must be 0 (auto) .. 13");
-    F5_SET_BOTH(f5_gemm_tile_override, sel);
-    return 0;
-}
+#endif  // F5_LAB
 
 extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                           float* out_f32, void* out_bf_hi, void* out_bf_lo, int M, int N, int K, int lda, int ldw, int ldo,

@@ -75,16 +75,20 @@ struct F5GemmArgs {
 int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
 // the large-shape kernel (gemm256.hip: 256 x 256 tiles, one workgroup per CU); f5_launch_gemm routes N % 256 == 0, >= 512-tile shapes here
 int f5_launch_gemm256(const F5GemmArgs& a, int epi, hipStream_t stream);
-int f5_launch_gemm128(const F5GemmArgs& a, int epi, hipStream_t stream);   // gemm128.hip: 128 x 256 tiles, two workgroups per CU
+#if defined(F5_LAB) && F5_LAB
+int f5_launch_gemm128(const F5GemmArgs& a, int epi, hipStream_t stream);   // gemm128.hip: 128 x 256 tiles, two workgroups per CU (experiment)
 extern int f5_gemm128_pad_lds;
+#endif
 // true when f5_launch_gemm(a, EPI_RESID_GATE) would run a small-tile kernel that implements the fused LN tail (a.ln_* unset or set)
 bool f5_gemm_resid_ln_fusable(const F5GemmArgs& a);
 
-// stream-K schedule of the 256x256 kernel (large shapes): device scratch for partial tiles; must be initialised outside of a
-// stream capture (engine creation does it).  f5_gemm_streamk_error() != 0 means a consumer timed out (results invalid).
+#if defined(F5_LAB) && F5_LAB
+// stream-K schedule of the lock-step 256x256 kernel (gemm_lab.hip): device scratch for partial tiles; must be initialised outside
+// of a stream capture.  f5_gemm_streamk_error() != 0 means a consumer timed out (results invalid).
 int f5_gemm_streamk_init();
 int f5_gemm_streamk_error();
 extern int f5_gemm_streamk;
+#endif
 
 // MX-fp8 GEMM (256x256x128 tiles, v_mfma_scale_f32_32x32x64_f8f6f4): M >= 1, N % 256 == 0, K % 128 == 0.
 // epi: EPI_F32, EPI_BF16, EPI_GELU_TANH (fp8 + scales out), EPI_RESID_GATE, EPI_QKV_ROPE.

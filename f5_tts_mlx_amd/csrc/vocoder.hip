@@ -33,7 +33,15 @@ struct VGraph {
     const void* workspace;
     hipGraphExec_t exec;
     uint64_t stamp;
+    hipEvent_t done;         // recorded after every launch: an exec is only destroyed once its last replay has finished
 };
+static void destroy_vgraph(VGraph& g) {
+    if (g.done) {
+        (void)hipEventSynchronize(g.done);
+        (void)hipEventDestroy(g.done);
+    }
+    (void)hipGraphExecDestroy(g.exec);
+}
 struct VWorkspace {
     size_t total = 0;
     size_t mel, x0, x, y, frames, wave;
@@ -139,7 +147,7 @@ extern "C" int f5_vocoder_create(const f5_vocos_config* cfg, int precision, f5_v
 
 extern "C" void f5_vocoder_destroy(f5_vocoder* v) {
     if (!v) return;
-    for (auto& g : v->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : v->graphs) destroy_vgraph(g);
     delete v;
 }
 
@@ -336,7 +344,7 @@ extern "C" int f5_vocode(f5_vocoder* v, const float* mel, int B, int N, float* w
         if (!exec) {
             for (size_t i = 0; i < v->graphs.size();) {
                 if (v->graphs[i].workspace != workspace) {
-                    (void)hipGraphExecDestroy(v->graphs[i].exec);
+                    destroy_vgraph(v->graphs[i]);
                     v->graphs.erase(v->graphs.begin() + i);
                 } else {
                     ++i;
@@ -346,7 +354,7 @@ extern "C" int f5_vocode(f5_vocoder* v, const float* mel, int B, int N, float* w
                 size_t lru = 0;
                 for (size_t i = 1; i < v->graphs.size(); ++i)
                     if (v->graphs[i].stamp < v->graphs[lru].stamp) lru = i;
-                (void)hipGraphExecDestroy(v->graphs[lru].exec);
+                destroy_vgraph(v->graphs[lru]);
                 v->graphs.erase(v->graphs.begin() + lru);
             }
             hipGraph_t graph = nullptr;
@@ -360,9 +368,13 @@ extern "C" int f5_vocode(f5_vocoder* v, const float* mel, int B, int N, float* w
             F5_HIP_CHECK(ec);
             F5_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(graph);
-            v->graphs.push_back({B, N, workspace, exec, ++v->clock});
+            hipEvent_t done = nullptr;
+            F5_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            v->graphs.push_back({B, N, workspace, exec, ++v->clock, done});
         }
         F5_HIP_CHECK(hipGraphLaunch(exec, s));
+        for (auto& g : v->graphs)
+            if (g.exec == exec) F5_HIP_CHECK(hipEventRecord(g.done, s));
     } else {
         RC(vocode_body(v, w, ws, B, N, s));
     }

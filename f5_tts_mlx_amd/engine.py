@@ -213,6 +213,16 @@ class Engine:
     def graph_count(self) -> int:
         return int(self.lib.f5_engine_graph_count(self._h))
 
+    def set_option(self, name: str, value: int) -> None:
+        """Per-engine launch option ("q_premul", "qkv_transposed", "ln_fusion", "gemm_flags"; include/f5tts_hip.h): other engines of
+        the process keep their own values, cached hipGraphs are keyed on them."""
+        check(self.lib.f5_engine_set_option(self._h, name.encode(), int(value)), f"f5_engine_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        check(self.lib.f5_engine_get_option(self._h, name.encode(), C.byref(v)), f"f5_engine_get_option({name})")
+        return int(v.value)
+
     def mark_loaded_from_broadcast(self) -> None:
         """Arena content arrived by a collective (dist.broadcast_weights) instead of load_weights."""
         check(self.lib.f5_mark_weights_loaded(self._h), "f5_mark_weights_loaded")

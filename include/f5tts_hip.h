@@ -60,6 +60,13 @@ void f5_engine_destroy(f5_engine* e);   /* also destroys every cached hipGraphEx
 /* at most `max_graphs` (default 8) captured sample graphs are kept per engine; the least recently used one is destroyed */
 int f5_engine_set_graph_cache(f5_engine* e, int max_graphs);
 int f5_engine_graph_count(f5_engine* e);
+/* Per-engine launch options (two engines of one process keep their own): "q_premul" (1: q leaves the QKV epilogue multiplied by
+ * softmax_scale * log2 e), "qkv_transposed" (1: transposed q / k tiles in the 256x256 QKV kernel), "ln_fusion" (0; 1 = LN-modulate
+ * fused behind small-tile residual GEMMs, measured slower), "gemm_flags" (0; F5GemmArgs debug bits of this engine's launches).
+ * Part of the hipGraph cache key.  New engines start from the process defaults (f5_debug_set_ln_fusion / _qkv_transposed /
+ * _q_premul). */
+int f5_engine_set_option(f5_engine* e, const char* name, int value);
+int f5_engine_get_option(f5_engine* e, const char* name, int* value);
 
 /* ---- weights: replaces F5TTS.load_weights / from_pretrained upload (cfm.py:475-518) ------------
  * The caller allocates `f5_weights_bytes` of device memory (one contiguous arena, so that a single
@@ -213,56 +220,43 @@ int f5_op_istft(const float* x, int ldx, const float* window, float* frames_scra
 uint16_t f5_debug_f2h_bits(float f);
 float f5_debug_h_bits2f(uint16_t h);
 uint16_t f5_debug_f2bf_bits(float f);
-/* debug / benchmarking hook: force the GEMM block tile (0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 256x256 global_load_lds kernel,
- * 5 / 6 = ring 64x128 / 64x64, 7 = 128x256 two-per-CU, 8 / 9 = 8-wave ring 128x192 / 128x128, 10 / 11 = in-workgroup split-K
- * 64x128 / 128x128, 12 / 13 = 8-wave ring 128x256 with 64x64 / 32x128 wave tiles) */
+/* ---- test hooks of the product library.  Process-wide (set them once, before the calls they should affect); they choose among
+ * kernels that sample() itself reaches by shape, so that small test shapes can exercise every shipped tile path.  Hooks that select
+ * experiments (superseded kernels, ablations, stream-K, priorities) exist in the lab build only: include/f5tts_hip_lab.h,
+ * `F5_LAB=1 bash f5_tts_mlx_amd/csrc/build.sh`; f5_lab_build() tells which library is loaded. */
+int f5_lab_build(void);
+/* force the GEMM block tile: 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64 (register-staged), 4 = 256x256 (gemm256.hip), 5 / 6 = ring
+ * 64x128 / 64x64, 8 / 9 = 8-wave ring 128x192 / 128x128, 10 / 11 = in-workgroup split-K 64x128 / 128x128, 12 / 13 = 8-wave ring
+ * 128x256 with 64x64 / 32x128 wave tiles (7 = the lab build's 128x256 two-per-CU kernel) */
 int f5_debug_set_gemm_tile(int sel);
-/* bit 0: skip GEMM epilogues of the 256x256 / 128x256 kernels (timing experiments only; results are garbage);
+/* GEMM flag bits, OR-ed into every GEMM launch of the process (an engine's own: f5_engine_set_option "gemm_flags"):
+ * bit 0: skip the epilogue of the 256x256 kernel (timing only; results are garbage);
  * bit 1: small-tile kernels use the direct (2-byte store) epilogue instead of the LDS-staged one;
- * bit 3 (8): experiment, measured slower -- the gated residual update x += gate * v (EPI_RESID_GATE) uses no-return L2 atomic adds
- *            instead of load / add / store (one add per element per launch either way, so both forms are deterministic);
  * bit 8 (256): the small-tile ring kernels load x / bias / gate / keep of the residual update in the epilogue instead of
  *            requesting them before the K loop (A/B of the default; identical bits);
- * bits 9-11 (512 / 1024 / 2048): experiment -- the 256x256 residual GEMM touches 1/4, 1/2 or all 128-byte lines of its x tile
- *            before the main loop (cache prefetch of the read half of the read-modify-write; identical bits);
  * bit 14 (16384): the 256x256 kernel accumulates 16-bit-output tiles (FF1, plain 16-bit, q / k of QKV) in the straight order with
  *            2-byte staging writes instead of transposed with 8-byte ones (A/B; identical bits for FF1 / plain);
- * bits 4-7 (timing only, garbage results; tile overrides 10 / 13 with the bf16 epilogue): 16 = no operand loads after the prologue,
- * 32 = no MFMAs, 64 = no LDS fragment reads, 128 = no workgroup barrier (combinations 96, 112, 144, 240 are instantiated) */
+ * lab build only: bit 3 (8) residual update by no-return L2 atomics, bits 9-11 x-tile prefetch, bits 4-7 ring-loop ablations */
 int f5_debug_set_gemm_flags(int v);
 /* small-tile GEMM tile numbering: 0 auto, 1 n fastest, 2 m fastest */
 int f5_debug_set_gemm_order(int v);
 /* small-tile GEMM staging: 1 = global_load_lds ring (default), 0 = register-staged double buffer */
 int f5_debug_set_gemm_ring(int v);
-/* large-shape GEMM kernel in auto mode: 2 = 256x256 (one workgroup per CU), 3 = 128x256 (two per CU); stagger < 0 = auto */
-int f5_debug_set_gemm_big_kernel(int v, int stagger_cycles);
-/* 128x256 two-per-CU kernel: issue priority 0 = MFMA clusters, 1 = none, 2 = epilogue */
-int f5_debug_set_gemm_v3_prio(int v);
-/* large-shape GEMM schedule: 0 = one tile per workgroup (default), 1 = stream-K (persistent workgroup per CU over contiguous
- * K-step ranges), 2 = hybrid (lockstep rounds + stream-K tail);
- * f5_debug_gemm_streamk_error() returns 1 if a partial-tile hand-off ever timed out (results invalid) */
-int f5_debug_set_gemm_streamk(int v);
-int f5_debug_gemm_streamk_error(void);
-/* 1 = register-staged attention kernel, 2 = global_load_lds ring (default) */
-int f5_debug_set_attn_version(int v);
-/* timing-only ablations of the attention kernel (results are wrong unless 0) */
-int f5_debug_set_convpos_tps(int taps);     /* conv-pos kernel: weight slabs per pipeline step, 0 = auto (4 for small grids), 1 / 2 / 4 */
-int f5_debug_set_convpos_xcd_map(int on);   /* conv-pos kernel: 1 (default) = groups dealt to XCDs, 0 = plain 3-D block numbering */
 int f5_debug_set_gemm_qkv_tile(int sel);    /* small-M QKV projection with pair-major tables: 0 = auto tiles, 12 / 13 = 8-wave 128x256 ring, q / k wave tiles transposed */
 int f5_debug_set_gemm_nband(int n);         /* 256x256 GEMM: tiles numbered in bands of n column tiles (0 = n fastest) */
-int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the residual GEMMs of small-M launches (default 0: measured slower) */
-int f5_debug_set_qkv_transposed(int on);    /* 1 (default): sample() hands the pair-major rotation tables to the QKV projection (256x256 kernel: transposed q / k tiles) */
-int f5_debug_set_op_rope_tables_t(const float* cos_tq, const float* sin_tq, const float* cos_tk, const float* sin_tk); /* op-level twin for f5_op_qkv_rope; NULLs = off */
-int f5_debug_set_q_premul(int on);          /* 1 (default): sample() multiplies q by softmax_scale * log2(e) in the QKV epilogue (single-segment operand modes) */
-int f5_debug_set_op_q_premul(float factor); /* op-level twin: f5_op_qkv_rope scales q by factor, f5_op_attention expects q pre-scaled; 0 = off (default) */
-int f5_debug_set_attn_variant(int bits);   /* experiment bits of attention versions 5 / 6 (see attention.hip) */
-int f5_debug_set_attn_ablation(int v);
-/* 256-query workgroups with two query blocks per wave (bf16, large grids): -1 auto, 0 off, 1 force */
+int f5_debug_set_convpos_tps(int taps);     /* conv-pos kernel: weight slabs per pipeline step, 0 = auto (4 for small grids), 1 / 2 / 4 */
+int f5_debug_set_convpos_xcd_map(int on);   /* conv-pos kernel: 1 (default) = groups dealt to XCDs, 0 = plain 3-D block numbering */
+/* 256-query attention workgroups with two query blocks per wave (one-pass modes, large grids): -1 auto, 0 off, 1 force */
 int f5_debug_set_attn_wide(int v);
-/* large-grid attention kernel: which phase of a wave holds SIMD issue priority: 0 MFMA clusters, 1 none, 2 softmax VALU section */
-int f5_debug_set_attn_prio(int v);
 /* in-workgroup KV split of the attention kernel: -1 auto (by grid size), 1 none, 2 / 4 wave groups */
 int f5_debug_set_attn_kvsplit(int v);
+/* process DEFAULTS of the per-engine options (f5_engine_set_option); engines that already exist keep their own values */
+int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the residual GEMMs of small-M launches (default 0: measured slower) */
+int f5_debug_set_qkv_transposed(int on);    /* 1 (default): sample() hands the pair-major rotation tables to the QKV projection (256x256 kernel: transposed q / k tiles) */
+int f5_debug_set_q_premul(int on);          /* 1 (default): sample() multiplies q by softmax_scale * log2(e) in the QKV epilogue (single-segment operand modes) */
+/* op-level twins for f5_op_qkv_rope / f5_op_attention */
+int f5_debug_set_op_rope_tables_t(const float* cos_tq, const float* sin_tq, const float* cos_tk, const float* sin_tk); /* NULLs = off */
+int f5_debug_set_op_q_premul(float factor); /* f5_op_qkv_rope scales q by factor, f5_op_attention expects q pre-scaled; 0 = off (default) */
 
 /* ---- MX-fp8 path (BASELINE configs[4]; gfx950 v_mfma_scale_f32_32x32x64_f8f6f4): OCP e4m3 elements, one E8M0 scale per 32
  * consecutive K elements (scale = 2^ceil(log2(amax/448))).  No reference counterpart (the reference's reduced-precision mode

@@ -133,6 +133,12 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert lib.f5_version() >= 1
+    # the lab header's hooks exist exactly when the library says it is the lab build (product: none of them leaks in)
+    lab_hdr = open(os.path.join(ROOT, "include", "f5tts_hip_lab.h")).read()
+    lab_names = sorted(set(re.findall(r"\b(f5_[a-z0-9_]+)\s*\(", lab_hdr)) - set(names))
+    assert len(lab_names) >= 8
+    have = [hasattr(lib, n) for n in lab_names]
+    assert all(have) if lib.f5_lab_build() else not any(have), dict(zip(lab_names, have))
 
 
 def test_struct_layouts_match_the_header(tmp_path):

@@ -202,6 +202,7 @@ def test_attention_ragged_mask(lib, nseg):
     _attention_case(lib, 3, 2, 200, [200, 130, 1], nseg, seed=7)
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("version", [5, 6])
 @pytest.mark.parametrize("N", [1, 63, 64, 65, 130, 257, 499, 937])
 def test_attention_pipelined_kernel_shapes(lib, version, N):
@@ -214,6 +215,7 @@ def test_attention_pipelined_kernel_shapes(lib, version, N):
         E.check(lib.f5_debug_set_attn_version(2))
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("version", [5])
 def test_attention_pipelined_kernel_ragged_and_batched(lib, version):
     E.check(lib.f5_debug_set_attn_version(version))
@@ -595,6 +597,7 @@ def test_attention_path_with_v2_qkv(lib, force_v2, nseg):
     _attention_case(lib, 2, 4, 300, [300, 211], nseg, seed=21)     # D = 256: QKV GEMM runs on the 256x256 kernel
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("ver", [1, 3, 4])
 def test_attention_other_kernel_versions(lib, ver):
     """the older kernels stay selectable through the debug hook (A/B benchmarking); default is version 2"""
@@ -649,6 +652,7 @@ def test_attention_without_tile_maximum(lib, path, premul):
         E.check(lib.f5_debug_set_attn_kvsplit(-1))
 
 
+@pytest.mark.lab
 def test_attention_tile_maximum_kernels_still_selectable(lib):
     """attention variant bit 16 = the kernels of round 1 / early round 2 (tile maximum on every tile), kept for A/B runs"""
     E.check(lib.f5_debug_set_attn_variant(16))
@@ -798,6 +802,7 @@ def test_gemm_resid_gate_fused_ln_is_bit_identical(lib, tile, nseg):
         E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("nseg", [1, 3])
 @pytest.mark.parametrize("tile", [0, 2, 4, 5, 9, 10])
 def test_gemm_resid_gate_atomic_vs_load_add_store(lib, tile, nseg):
@@ -912,6 +917,7 @@ def test_gemm_wide_ring_kernels(lib, tile):
         E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+@pytest.mark.lab
 def test_gemm_streamk_schedule(lib):
     """256x256 kernel under the stream-K schedule (>= one tile per CU): split tiles are handed over through the partial-tile
     scratch; every epilogue; bitwise run-to-run determinism; agreement with the one-tile-per-workgroup schedule."""
@@ -968,6 +974,7 @@ def force_v3(lib):
     E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("M,N,K", [(256, 256, 32), (300, 512, 96), (1874, 1024, 1024), (700, 768, 2048)])
 def test_gemm_v3_f32_out(lib, force_v3, M, N, K):
     r = rng(M + N + K + 3)
@@ -982,6 +989,7 @@ def test_gemm_v3_f32_out(lib, force_v3, M, N, K):
         assert float((out3.double() - ref32).abs().max()) <= 5e-5 * max(1.0, float(ref32.abs().max()))
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("epi", [1, 2, 8])
 def test_gemm_v3_bf16_epilogues(lib, force_v3, epi):
     r = rng(50 + epi)
@@ -994,6 +1002,7 @@ def test_gemm_v3_bf16_epilogues(lib, force_v3, epi):
     assert mx <= 1e-4
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("nseg", [1, 3])
 def test_attention_path_with_v3_qkv(lib, force_v3, nseg):
     _attention_case(lib, 2, 4, 300, [300, 211], nseg, seed=22)
