@@ -10,7 +10,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 LAB=${F5_LAB:-0}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DF5_LAB=$LAB"
 B=build
-KERNELS="gemm gemm256 gemm_f8 attention convpos rowops"
+KERNELS="gemm gemm256 gemm_rs128 gemm_f8 attention convpos rowops"
 if [ "$LAB" = 1 ]; then B=build_lab; KERNELS="$KERNELS gemm_lab gemm128"; fi
 mkdir -p $B
 pids=()

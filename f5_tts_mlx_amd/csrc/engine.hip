@@ -1179,7 +1179,7 @@ extern "C" int f5_debug_set_attn_kvsplit(int v) {
     return 0;
 }
 extern "C" int f5_debug_set_gemm_qkv_tile(int v) {
-    F5_REQUIRE(v == 0 || v == 12 || v == 13, "small-M QKV tile must be 0 (auto), 12 or 13 (8-wave 128x256 ring with transposed q / k wave tiles)");
+    F5_REQUIRE(v == 0 || v == 1 || v == 12 || v == 13 || v == 14, "small-M QKV tile must be 0 (auto), 1 (small tiles), 12 / 13 (8-wave 128x256 ring) or 14 (role-split 128x256)");
     F5_SET_BOTH(f5_gemm_qkv_small_tile, v);
     return 0;
 }
@@ -1204,7 +1204,7 @@ extern "C" int f5_debug_set_gemm_flags(int v) {
     return 0;
 }
 extern "C" int f5_debug_set_gemm_tile(int sel) {
-    F5_REQUIRE(sel >= 0 && sel <= 13, "gemm tile override must be 0 (auto) .. 13");
+    F5_REQUIRE(sel >= 0 && sel <= 14, "gemm tile override must be 0 (auto) .. 14");
     F5_REQUIRE(F5_LAB || sel != 7, "gemm tile 7 (128x256, two workgroups per CU) exists in the lab build only");
     F5_SET_BOTH(f5_gemm_tile_override, sel);
     return 0;

@@ -714,6 +714,18 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
         if (abl && (sel == 13 || sel == 10) && a.N % 256 == 0) return launch_ring_ablate(a, sel, abl, stream);
     }
 #endif
+    if constexpr (EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_RESID_GATE || EPI == EPI_QKV_ROPE) {
+        // role-split 128 x 256 tiles (gemm_rs128.hip): forced by tile 14, or by the QKV-only knob at batch-1-sized shapes
+        long t128x256 = (long)f5_cdiv(a.M, 128) * (a.N / 256);
+        if (EPI == EPI_QKV_ROPE && a.seq_len > 0) t128x256 = (long)(a.M / a.seq_len) * f5_cdiv(a.seq_len, 128) * (a.N / 256);   // per-element row tiles
+        // QKV at batch-1-sized shapes: one round of role-split 128 x 256 tiles when they fill >= 70 % of the CUs (M = 2 x 937: 192 tiles,
+        // 22.0 vs 27.3 us for the 64 x 128 register-staged tiles, sample() 78.3 -> 73.7-76.4 ms; smaller grids stay with the small
+        // tiles: M = 3 x 431 22.4 vs 18.4 us).  f5_gemm_qkv_small_tile: 0 = this rule, 14 = whenever one round, 12 / 13 = lock-step ring.
+        const bool qkv14 = EPI == EPI_QKV_ROPE && sel == 0 && a.rope_cos_tk != nullptr && t128x256 <= 256 &&
+                           (f5_gemm_qkv_small_tile == 14 || (f5_gemm_qkv_small_tile == 0 && t128x256 >= 176));
+        if ((sel == 14 || qkv14) && a.N % 256 == 0 && a.ln_counter == nullptr) return f5_launch_gemm_rs128(a, EPI, stream);
+        if (sel == 14) sel = 0;
+    }
     if constexpr (EPI == EPI_QKV_ROPE) {
         // batch-1-sized QKV projection with pair-major tables: one round of 8-wave 128 x 256 tiles with transposed q / k wave tiles
         // (f5_gemm_qkv_small_tile = 13 / 12) instead of 64 x 128 register-staged tiles (0)

@@ -75,6 +75,8 @@ struct F5GemmArgs {
 int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
 // the large-shape kernel (gemm256.hip: 256 x 256 tiles, one workgroup per CU); f5_launch_gemm routes N % 256 == 0, >= 512-tile shapes here
 int f5_launch_gemm256(const F5GemmArgs& a, int epi, hipStream_t stream);
+// batch-1-sized shapes: role-split 128 x 256 tiles, one round of 8-wave workgroups (gemm_rs128.hip)
+int f5_launch_gemm_rs128(const F5GemmArgs& a, int epi, hipStream_t stream);
 #if defined(F5_LAB) && F5_LAB
 int f5_launch_gemm128(const F5GemmArgs& a, int epi, hipStream_t stream);   // gemm128.hip: 128 x 256 tiles, two workgroups per CU (experiment)
 extern int f5_gemm128_pad_lds;

@@ -242,7 +242,7 @@ int f5_debug_set_gemm_flags(int v);
 int f5_debug_set_gemm_order(int v);
 /* small-tile GEMM staging: 1 = global_load_lds ring (default), 0 = register-staged double buffer */
 int f5_debug_set_gemm_ring(int v);
-int f5_debug_set_gemm_qkv_tile(int sel);    /* small-M QKV projection with pair-major tables: 0 = auto tiles, 12 / 13 = 8-wave 128x256 ring, q / k wave tiles transposed */
+int f5_debug_set_gemm_qkv_tile(int sel);    /* small-M QKV projection with pair-major tables: 0 = auto (role-split 128x256 tiles when one round of >= 176), 1 = small tiles, 12 / 13 = lock-step 8-wave 128x256 ring, 14 = role-split whenever one round */
 int f5_debug_set_gemm_nband(int n);         /* 256x256 GEMM: tiles numbered in bands of n column tiles (0 = n fastest) */
 int f5_debug_set_convpos_tps(int taps);     /* conv-pos kernel: weight slabs per pipeline step, 0 = auto (4 for small grids), 1 / 2 / 4 */
 int f5_debug_set_convpos_xcd_map(int on);   /* conv-pos kernel: 1 (default) = groups dealt to XCDs, 0 = plain 3-D block numbering */

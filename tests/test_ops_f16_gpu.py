@@ -62,13 +62,20 @@ def test_attention_softmax_spike_f16(lib):
     T.test_attention_softmax_spike(lib, hp=0)
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("N", [1, 64, 130, 937])
 def test_attention_pipelined_kernel_f16(lib, N):
     T.test_attention_pipelined_kernel_shapes(lib, 5, N)
 
 
+@pytest.mark.lab
 def test_attention_pipelined_kernel_ragged_f16(lib):
     T.test_attention_pipelined_kernel_ragged_and_batched(lib, 5)
+
+
+@pytest.mark.parametrize("tile", [4, 13, 14])
+def test_transposed_qkv_tiles_race_screen_f16(lib, tile):
+    T.test_transposed_qkv_tiles_race_screen(lib, tile)
 
 
 @pytest.mark.parametrize("tps", [0, 1, 2])

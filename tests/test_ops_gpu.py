@@ -592,6 +592,52 @@ def test_qkv_transposed_wave_tiles_ring8(lib, tile, nseg):
         E.check(lib.f5_debug_set_gemm_qkv_tile(0))
 
 
+@pytest.mark.parametrize("tile", [4, 12, 13, 14])
+def test_transposed_qkv_tiles_race_screen(lib, tile):
+    """Round 2 saw a transposed-tile QKV epilogue WITHOUT LDS staging return a few hundred wrong elements on lanes 48-63, differently
+    on every launch, on 4-wave kernels only (cause not found; that experiment never shipped and is not in the product library).  The
+    SHIPPED transposed tiles (staged through LDS, 8-wave kernels: the 256x256 kernel and the 128x256 ring tiles) are screened here the
+    way a race shows: 40 launches per shape -- row tails, ragged batches, batch-1 and multi-round grids -- each compared bit for bit
+    with the straight-tile epilogue (gemm flag 16384) of the same kernel."""
+    import ctypes as C
+    D, H = 1024, 16
+    r = rng(99 + tile)
+    w = randn(r, 3 * D, D, scale=D ** -0.5)
+    bias = randn(r, 3 * D, scale=0.1).to(DEV)
+    w_hi, _ = split_bf16(w.to(DEV))
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        for B, n in ((2, 937), (1, 2100), (3, 431), (5, 1000)):
+            M = B * n
+            npad = (n + 63) // 64 * 64
+            a_hi, _ = split_bf16(randn(r, M, D).to(DEV))
+            cos_t, sin_t = torch.empty(n, 32, device=DEV), torch.empty(n, 32, device=DEV)
+            E.check(lib.f5_op_rope_table(P(cos_t), P(sin_t), n, 64, stream()))          # token-major (straight tiles) ...
+            tt = [torch.empty(32, n, device=DEV) for _ in range(4)]
+            E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), n, 64, C.c_float(1.0), stream()))   # ... and pair-major twins
+
+            def run(flags):
+                E.check(lib.f5_debug_set_gemm_flags(flags))
+                E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
+                qk = torch.zeros(M, 2 * D, dtype=op_dtype(), device=DEV)
+                vt = torch.zeros(B * H, 64, npad, dtype=op_dtype(), device=DEV)
+                E.check(lib.f5_op_qkv_rope(P(a_hi), P(None), P(w_hi), P(None), P(bias), P(cos_t), P(sin_t), P(qk), P(None), P(vt), P(None),
+                                           B, n, npad, H, D, 1, stream()), "qkv_rope")
+                sync()
+                return qk, vt
+            try:
+                ref_qk, ref_vt = run(16384)                                # straight tiles
+                assert float(ref_qk.float().abs().mean()) > 0.1
+                for i in range(40):
+                    qk, vt = run(0)                                         # transposed q / k tiles
+                    assert torch.equal(qk, ref_qk) and torch.equal(vt, ref_vt), (tile, B, n, i, int((qk != ref_qk).sum()))
+            finally:
+                E.check(lib.f5_debug_set_gemm_flags(0))
+                E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))
+
+
 @pytest.mark.parametrize("nseg", [1, 3])
 def test_attention_path_with_v2_qkv(lib, force_v2, nseg):
     _attention_case(lib, 2, 4, 300, [300, 211], nseg, seed=21)     # D = 256: QKV GEMM runs on the 256x256 kernel
@@ -683,7 +729,7 @@ def test_attention_kv_split(lib, ks):
         E.check(lib.f5_debug_set_attn_kvsplit(-1))
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, pytest.param(7, marks=pytest.mark.lab), 8, 9, 10, 11, 14])
 @pytest.mark.parametrize("nseg", [1, 3])
 def test_gemm_resid_gate(lib, tile, nseg):
     """x += gate * ((A W^T + b) * keep[row])  (dit.py:172-173, 319, 323) on both GEMM kernels."""
