@@ -283,6 +283,13 @@ __device__ __forceinline__ attn_f32x2 attn_exp_block(f32x16& s, float c2, float 
     return sum2;
 }
 
+// The compiler does not see hand-counted `s_waitcnt vmcnt(N)` (inline asm).  Q fragments loaded from global memory before a tile
+// loop are first USED inside the loop, so the compiler's own wait for them lands in the loop body -- as vmcnt(0) on every
+// iteration, draining the K / V^T prefetch each time.  A use it can see, placed before the loop, keeps that wait in the prologue.
+#define ATTN_PIN_Q(qf_, n0_, n1_)                                                                            \
+    _Pragma("unroll") for (int a_ = 0; a_ < (n0_); ++a_)                                                     \
+        _Pragma("unroll") for (int b_ = 0; b_ < (n1_); ++b_) asm volatile("" ::"v"((qf_)[a_][b_]));
+
 __device__ __forceinline__ void attn_glds16(const op16_t* gptr, op16_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
@@ -375,6 +382,7 @@ __global__ __launch_bounds__(256, HP ? 2 : 3) void f5_attn2_kernel(F5AttnArgs p)
 
     A2_ISSUE(0);
     if (NST == 3 && ntile > 1) A2_ISSUE(1);
+    ATTN_PIN_Q(qf, NP, 4);
 
     for (int j = 0; j < ntile; ++j) {
         // wait for tile j (own loads), then make every wave's part visible; tile j+1 may stay in flight (NST == 3)
@@ -620,6 +628,7 @@ __global__ __launch_bounds__(256, 2) void f5_attn2w_kernel(F5AttnArgs p) {
 
     A2W_ISSUE(0);
     if (ntile > 1) A2W_ISSUE(1);
+    ATTN_PIN_Q(qf, 2, 4);
 
     for (int j = 0; j < ntile; ++j) {
         if (j + 1 < ntile) {
@@ -875,6 +884,7 @@ __global__ __launch_bounds__(256, 2) void f5_attn2f_kernel(F5AttnArgs p) {
 
     A2F_ISSUE(0);
     if (ntile > 1) A2F_ISSUE(1);
+    ATTN_PIN_Q(qf, 2, 4);
 
     for (int j = 0; j < ntile; ++j) {
         if (j + 1 < ntile) {
@@ -986,6 +996,279 @@ __global__ __launch_bounds__(256, 2) void f5_attn2f_kernel(F5AttnArgs p) {
     }
 }
 
+#if F5_LAB   // role-split attention (round 3): measured 7-12 % slower than v2f (profiles/r03/attention_role_split_ab.txt)
+// =================================================================================================
+// v2r (large grids, round 3): v2f's arithmetic under a ROLE-SPLIT schedule.  In v2f two waves of different workgroups share a
+// SIMD and drift freely: both may sit in their softmax (VALU, transcendentals) or both in their MFMA clusters at the same time,
+// and the counters say so (MFMA busy 31 %, VALU 48 %, waits 31-37 %).  Here a workgroup is 8 waves = 2 groups x 4 waves of 64
+// queries (512 queries), K / V^T tiles shared in LDS; per key tile j a wave alternates
+//     MATRIX(j): O^T += V^T(j-1) P^T(j-1) [16 MFMAs], S^T(j) = K(j) Q^T [16 MFMAs]          (s_setprio 1)
+//     VALU(j):   p = exp2(s - m_ref), row sums, pack P(j) to 16 bit (the slow path -- first tile, or a row sum above 2^14 --
+//                recomputes the scores of the tile and moves the reference point; K(j) is still in LDS)
+// each closed by a workgroup barrier, and group 1 runs ONE barrier behind group 0: in every interval one wave of each SIMD streams
+// MFMAs while its partner runs the softmax of its own tile.  1 024 MFMA cycles against ~900 VALU cycles per tile and wave.
+// Ring of 4 K / V^T tiles (64 KB), tile j+2 issued at the head of MATRIX(j) (the slot held tile j-2, whose V^T was last read in
+// group 1's MATRIX(j-1), one barrier earlier), `vmcnt(2)` at the end of MATRIX(j) retires tile j+1 one barrier before its first
+// reader.  The arithmetic is v2w's / v2f's without the -m_ref C operand: exp2(fma(s, c2, -m_ref)) (c2 = 1 when q is pre-multiplied).
+// The first tile and the last PV are peeled so that the loop body is straight-line (with `if (j > 0)` / `if (live)` around the
+// MFMA clusters the compiler moved all 64 accumulator registers through v_mov_b64 on every iteration); waves past the sequence
+// compute on clamped rows.  QLDS: the Q^T fragments live in LDS and are re-read per tile (185 VGPRs) instead of in registers (216).
+// RESULT (64 x 16 x 937, f16, interleaved runs on one box): v2f 305-316 us (754 TF), v2r 336-341 us (Q in registers) / 338-344 us
+// (Q in LDS).  MFMA time and VALU time of a SIMD ADD on this chip whichever wave they come from (tools/probes/coissue.hip), so
+// pairing one wave's MFMA cluster with its partner's softmax buys nothing, and the two extra workgroup barriers per tile cost.
+// =================================================================================================
+template <bool PRE, bool QLDS>
+__global__ __launch_bounds__(512, 1) void f5_attn2r_kernel(F5AttnArgs p) {
+    constexpr int NST = 4;
+    constexpr int TILE = 64 * 64;
+    // ONE array: with two, the LDS lowering tags the accesses with alias scopes and the compiler then orders every ds_read of the
+    // ring behind the outstanding global_load_lds of the SAME array with its own vmcnt(0) -- the hand-counted prefetch is gone
+    __shared__ __attribute__((aligned(16))) op16_t smem[NST * 2 * TILE + (QLDS ? 8 * 8 * 64 * 8 : 0)];   // [slot][K | V^T][64*64], then Q: 64 KB
+    op16_t* const qsm = smem + NST * 2 * TILE;                                                // [wave][query block x k step][lane][8]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // 0..7; group = wave >> 2
+    const int grp = wave >> 2;
+    const int hi = lane >> 5, lq = lane & 31;
+    int bh, qblk;
+    if (!attn_block_map(p, 512, bh, qblk)) return;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qblk * 512 + wave * 64;
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
+    const int ntile = (kvlen + 63) >> 6;
+    const size_t rowbase = (size_t)b * p.seq_len;
+
+    // Q^T fragments of the wave: 8 x 16 bytes per lane.  They live in LDS, lane-linear per fragment (conflict-free b128 reads), and
+    // are re-read next to the K fragments of every tile: 32 registers that the score / probability / output tiles need (at two
+    // waves per SIMD a wave has 256 registers; with Q resident the compiler spilled it to scratch inside the loop)
+    op16_t* qs = qsm + wave * (8 * 64 * 8) + lane * 8;
+    op16x8 qf[2][4];                                                      // !QLDS: the fragments stay in registers
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = q0 + qb * 32 + lq;
+        if (qr > p.seq_len - 1) qr = p.seq_len - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[qb][ks] = *reinterpret_cast<const op16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+            if (QLDS) *reinterpret_cast<op16x8*>(qs + (qb * 4 + ks) * (64 * 8)) = qf[qb][ks];
+        }
+    }
+
+    // staging: a K tile and a V^T tile are 512 16-byte chunks each = one per thread
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
+    const int krow = attn_kperm(srow);
+    const int kcol = p.dmodel + h * 64 + schunk * 8;
+    const int ldsoff = wave * 64 * 8;
+    const op16_t* kptr = p.qk[0] + (rowbase + krow) * p.ldqk + kcol;
+    const op16_t* vptr = p.vt[0] + ((size_t)bh * 64 + srow) * p.npad + schunk * 8;
+    const size_t kstep = (size_t)64 * p.ldqk;
+#define A2R_ISSUE(j_)                                                                                        \
+    {                                                                                                        \
+        op16_t* st_ = smem + ((j_) & (NST - 1)) * (2 * TILE);                                                \
+        const op16_t* ks_ = kptr;                                                                            \
+        if (((j_) * 64 + 63) > p.seq_len - 1) {                                                              \
+            int key_ = (j_) * 64 + krow;                                                                     \
+            if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                                  \
+            ks_ = p.qk[0] + (rowbase + key_) * p.ldqk + kcol;                                                \
+        }                                                                                                    \
+        attn_glds16(ks_, st_ + ldsoff);                                                                      \
+        attn_glds16(vptr, st_ + TILE + ldsoff);                                                              \
+        kptr += kstep;                                                                                       \
+        vptr += 64;                                                                                          \
+    }
+#define A2R_BARRIER()                          \
+    {                                          \
+        __builtin_amdgcn_sched_barrier(0);     \
+        asm volatile("" ::: "memory");         \
+        __builtin_amdgcn_s_barrier();          \
+        asm volatile("" ::: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);     \
+    }
+    // S^T blocks of tile j_ for both query blocks (K of the tile in sK_), raw units (exp2 units when q is pre-multiplied).  v2f's
+    // -m_ref C operand (32 more live registers) does not fit next to the packed probabilities that cross the barrier here: the
+    // reference point is subtracted by the packed fma of the softmax instead (the VALU segment stays shorter than the MATRIX one)
+#define A2R_QK(j_, sK_)                                                                               \
+    {                                                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                   \
+            const op16x8 qa = QLDS ? *reinterpret_cast<const op16x8*>(qs + ks * (64 * 8)) : qf[0][ks];       \
+            const op16x8 qb_ = QLDS ? *reinterpret_cast<const op16x8*>(qs + (4 + ks) * (64 * 8)) : qf[1][ks]; \
+            _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                               \
+                const op16x8 a = *reinterpret_cast<const op16x8*>(&(sK_)[attn_swz(kb * 32 + lq, ks * 2 + hi)]); \
+                s[0][kb] = F5_MFMA32(a, qa, ks == 0 ? zero16 : s[0][kb], 0, 0, 0);                           \
+                s[1][kb] = F5_MFMA32(a, qb_, ks == 0 ? zero16 : s[1][kb], 0, 0, 0);                          \
+            }                                                                                                \
+        }                                                                                                    \
+        if ((j_) * 64 + 64 > kvlen) {                                                                        \
+            _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                                 \
+                _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+                        const int key = (j_) * 64 + kb * 32 + 16 * hi + r;                                   \
+                        if (key >= kvlen) s[qb][kb][r] = -INFINITY;                                          \
+                    }                                                                                        \
+        }                                                                                                    \
+    }
+    // O^T += V^T P^T with the packed probabilities of the previous tile (V^T of that tile in sV_)
+#define A2R_PV(sV_)                                                                                          \
+    {                                                                                                        \
+        _Pragma("unroll") for (int ks4 = 0; ks4 < 4; ++ks4) {                                                \
+            const int kb = ks4 >> 1, sp = ks4 & 1;                                                           \
+            _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                               \
+                const op16x8 a = *reinterpret_cast<const op16x8*>(&(sV_)[attn_swz(db * 32 + lq, 4 * kb + 2 * hi + sp)]); \
+                o[0][db] = F5_MFMA32(a, __builtin_bit_cast(op16x8, pk[0][kb][sp]), o[0][db], 0, 0, 0);       \
+                o[1][db] = F5_MFMA32(a, __builtin_bit_cast(op16x8, pk[1][kb][sp]), o[1][db], 0, 0, 0);       \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+    // probabilities of query block qb_ -> 16-bit MFMA operands (the score registers of the block die here)
+#define A2R_PACK(qb_)                                                                                        \
+    {                                                                                                        \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
+            _Pragma("unroll") for (int sp = 0; sp < 2; ++sp) {                                               \
+                uint32_t pw[4];                                                                              \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                \
+                    pw[e] = f5_pack2_bounded(s[qb_][kb][8 * sp + 2 * e], s[qb_][kb][8 * sp + 2 * e + 1]);    \
+                pk[qb_][kb][sp] = u32x4{pw[0], pw[1], pw[2], pw[3]};                                         \
+            }                                                                                                \
+    }
+    f32x16 o[2][2], s[2][2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    u32x4 pk[2][2][2];                                  // packed probabilities [query block][key block][8-key half]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            o[qb][0][e] = 0.0f;
+            o[qb][1][e] = 0.0f;
+        }
+    }
+    float m_ref[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};   // m_ref in exp2 units (scores * c2)
+    const float c2 = PRE ? 1.0f : p.scale * 1.4426950408889634f;
+    constexpr float SUM_LIMIT = 16384.0f;
+
+    A2R_ISSUE(0);
+    if (ntile > 1) {
+        A2R_ISSUE(1);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (!QLDS) { ATTN_PIN_Q(qf, 2, 4); }
+    A2R_BARRIER();
+    if (grp == 1) A2R_BARRIER();                        // group 1 runs one barrier behind
+
+    // softmax of tile j_: fast path p = exp2(s - m_ref) with the old reference point; the row sums say whether that was safe
+#define A2R_SOFTMAX(j_, sK_, FIRST_)                                                                         \
+    {                                                                                                        \
+        float psum[2];                                                                                       \
+        bool slow = (FIRST_);                                                                                \
+        if (!(FIRST_)) {                                                                                     \
+            bool bad = false;                                                                                \
+            _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                               \
+                attn_f32x2 ps2 = {0.0f, 0.0f};                                                               \
+                ps2 = attn_exp_block(s[qb][0], c2, m_ref[qb], ps2);                                          \
+                ps2 = attn_exp_block(s[qb][1], c2, m_ref[qb], ps2);                                          \
+                psum[qb] = ps2[0] + ps2[1];                                                                  \
+                bad = bad || !(psum[qb] <= SUM_LIMIT);                                                       \
+                A2R_PACK(qb);                                   /* redone by the slow path */                \
+            }                                                                                                \
+            slow = __any(bad);                                                                               \
+            if (slow) A2R_QK(j_, sK_);                         /* rare: the raw scores again (K is still in LDS) */ \
+        }                                                                                                    \
+        if (slow) {                                            /* wave-uniform: first tile, or a score far above m_ref */ \
+            _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                               \
+                float tmax = -INFINITY;                                                                      \
+                _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[qb][kb][r]);         \
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));                                                \
+                const float m_new = fmaxf(m_ref[qb], tmax * c2);                                             \
+                const float alpha = __builtin_amdgcn_exp2f(m_ref[qb] - m_new);                               \
+                m_ref[qb] = m_new;                                                                           \
+                l_run[qb] *= alpha;                                                                          \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                             \
+                    o[qb][0][e] *= alpha;                                                                    \
+                    o[qb][1][e] *= alpha;                                                                    \
+                }                                                                                            \
+                attn_f32x2 ps2 = {0.0f, 0.0f};                                                               \
+                ps2 = attn_exp_block(s[qb][0], c2, m_new, ps2);                                              \
+                ps2 = attn_exp_block(s[qb][1], c2, m_new, ps2);                                              \
+                psum[qb] = ps2[0] + ps2[1];                                                                  \
+                A2R_PACK(qb);                                                                                \
+            }                                                                                                \
+        }                                                                                                    \
+        l_run[0] += psum[0];                                                                                 \
+        l_run[1] += psum[1];                                                                                 \
+    }
+#define A2R_WAIT(j_)                                                                                         \
+    if ((j_) + 2 < ntile) {                                                                                  \
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); /* tile j+1 landed (this wave's share), j+2 in flight */ \
+    } else {                                                                                                 \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+    }
+
+    // ---- tile 0 (peeled: no PV yet, the softmax takes the maximum) -- waves past the sequence compute on clamped rows
+    {
+        if (2 < ntile) A2R_ISSUE(2);
+        __builtin_amdgcn_s_setprio(1);
+        A2R_QK(0, smem);
+        __builtin_amdgcn_s_setprio(0);
+        A2R_WAIT(0);
+        A2R_BARRIER();
+        A2R_SOFTMAX(0, smem, true);
+        A2R_BARRIER();
+    }
+    // ---- tiles 1 .. ntile-1: MATRIX(j) = PV(j-1), QK(j) | VALU(j) = softmax(j)
+    for (int j = 1; j < ntile; ++j) {
+        if (j + 2 < ntile) A2R_ISSUE(j + 2);
+        const op16_t* sK = smem + (j & (NST - 1)) * (2 * TILE);
+        const op16_t* sVp = smem + ((j - 1) & (NST - 1)) * (2 * TILE) + TILE;
+        __builtin_amdgcn_s_setprio(1);
+        A2R_PV(sVp);
+        __builtin_amdgcn_sched_barrier(0);              // the packed probabilities die here, before the score registers are born
+        A2R_QK(j, sK);
+        __builtin_amdgcn_s_setprio(0);
+        A2R_WAIT(j);
+        A2R_BARRIER();
+        A2R_SOFTMAX(j, sK, false);
+        A2R_BARRIER();
+    }
+    // ---- the last PV
+    {
+        const op16_t* sVp = smem + ((ntile - 1) & (NST - 1)) * (2 * TILE) + TILE;
+        A2R_PV(sVp);
+    }
+    if (grp == 0) A2R_BARRIER();                        // balance group 1's extra barrier
+#undef A2R_ISSUE
+#undef A2R_BARRIER
+#undef A2R_QK
+#undef A2R_PV
+#undef A2R_PACK
+#undef A2R_SOFTMAX
+#undef A2R_WAIT
+    if (q0 >= p.seq_len) return;
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qr = q0 + qb * 32 + lq;
+        if (qr < p.seq_len) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d = db * 32 + 8 * rg + 4 * hi;
+                    const float v0 = o[qb][db][rg * 4 + 0] * inv, v1 = o[qb][db][rg * 4 + 1] * inv;
+                    const float v2 = o[qb][db][rg * 4 + 2] * inv, v3 = o[qb][db][rg * 4 + 3] * inv;
+                    const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
+                    *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2_bounded(v0, v1), f5_pack2_bounded(v2, v3)};
+                }
+        }
+    }
+}
+#endif  // F5_LAB (v2r)
+
 // =================================================================================================
 // v2s: v2 with the KV range split across KS wave groups INSIDE the workgroup (small batches: B*H*ceil(N/128)
 // workgroups of 4 waves leave the 256 CUs with one wave per SIMD and the whole kernel is one workgroup's latency
@@ -1081,6 +1364,7 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
 
     if (ntg > 0) A2S_ISSUE(0);
     if (NST == 3 && ntg > 1) A2S_ISSUE(1);
+    ATTN_PIN_Q(qf, NP, 4);
 
     for (int jj = 0; jj < nit; ++jj) {
         if (NST == 3 && jj + 1 < ntg) {
@@ -1785,7 +2069,7 @@ int f5_attn_prio = 0;      // wide kernel: which phase holds issue priority (0 M
 static constexpr int f5_attn_version = 2, f5_attn_variant = 0, f5_attn_ablation = 0, f5_attn_prio = 0;   // the shipped configuration
 #endif
 // test hooks that choose among the SHIPPED kernels (the shape heuristics below decide otherwise)
-int f5_attn_wide = -1;     // -1 auto (>= 512 workgroups of 256 queries), 0 off, 1 force: 256-query workgroups, two query blocks per wave
+int f5_attn_wide = -1;     // -1 auto (>= 512 workgroups of 256 queries), 0 off, 1 force: 256-query workgroups, two query blocks per wave; lab: 2 = role-split v2r
 int f5_attn_kvsplit = -1;  // -1 auto, 1 / 2 / 4 = force the in-workgroup KV split
 
 // 1-D XCD-aware grid (attn_block_map); the lab build's f5_attn_variant bit 2 asks for the plain 2-D numbering
@@ -1844,6 +2128,20 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
             else if (f5_attn_prio == 2) hipLaunchKernelGGL(f5_attn2w_kernel<2>, gw, dim3(256), 0, stream, a);
             else if (f5_attn_variant & 8) hipLaunchKernelGGL((f5_attn2w_kernel<0, false>), gw, dim3(256), 0, stream, a);   // eager rescale
             else hipLaunchKernelGGL(f5_attn2w_kernel<0>, gw, dim3(256), 0, stream, a);
+            F5_LAUNCH_CHECK();
+            return 0;
+        }
+#endif
+#if F5_LAB
+        if (f5_attn_wide == 2 && !a.out8) {              // role-split schedule: 512-query workgroups of 8 waves
+            const dim3 gr = attn_grid(a, 512);
+            if (!(f5_attn_variant & 32)) {              // variant bit 5: Q fragments in LDS instead of registers
+                if (a.q_prescaled) hipLaunchKernelGGL((f5_attn2r_kernel<true, false>), gr, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((f5_attn2r_kernel<false, false>), gr, dim3(512), 0, stream, a);
+            } else {
+                if (a.q_prescaled) hipLaunchKernelGGL((f5_attn2r_kernel<true, true>), gr, dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((f5_attn2r_kernel<false, true>), gr, dim3(512), 0, stream, a);
+            }
             F5_LAUNCH_CHECK();
             return 0;
         }

@@ -1169,7 +1169,11 @@ extern "C" int f5_debug_set_q_premul(int on) {
     return 0;
 }
 extern "C" int f5_debug_set_attn_wide(int v) {
-    F5_REQUIRE(v >= -1 && v <= 1, "attention wide-workgroup switch must be -1 (auto), 0 or 1");
+#if F5_LAB
+    F5_REQUIRE(v >= -1 && v <= 2, "attention wide-workgroup switch must be -1 (auto), 0, 1 (256-query workgroups) or 2 (lab: role-split 512-query workgroups)");
+#else
+    F5_REQUIRE(v >= -1 && v <= 1, "attention wide-workgroup switch must be -1 (auto), 0 or 1 (256-query workgroups)");
+#endif
     F5_SET_BOTH(f5_attn_wide, v);
     return 0;
 }
@@ -1225,7 +1229,7 @@ extern "C" int f5_debug_set_attn_version(int v) {
     return 0;
 }
 extern "C" int f5_debug_set_attn_variant(int v) {
-    F5_REQUIRE(v >= 0 && v <= 31, "attention variant bits: 1 = single-issue softmax VALU, 2 = one workgroup per CU, 4 = 2-D block numbering, 8 = eager rescale, 16 = per-tile maximum (v2w) in the large-grid kernel");
+    F5_REQUIRE(v >= 0 && v <= 63, "attention variant bits: 1 = single-issue softmax VALU, 2 = one workgroup per CU, 4 = 2-D block numbering, 8 = eager rescale, 16 = per-tile maximum (v2w) in the large-grid kernel, 32 = role-split kernel keeps Q in LDS");
     F5_SET_BOTH(f5_attn_variant, v);
     return 0;
 }

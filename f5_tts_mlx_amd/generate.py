@@ -174,7 +174,8 @@ def main(argv=None):
     for flag, kind, dflt, doc in _CLI:
         ap.add_argument(flag, type=kind, default=dflt, help=doc)
     ap.add_argument("--method", default="rk4", choices=("euler", "midpoint", "rk4"), help="ODE solver")
-    ap.add_argument("--q", type=int, default=None, choices=(4, 8), help="load the MLX 4/8-bit checkpoint (expanded to fp32 on load)")
+    ap.add_argument("--q", type=int, default=None, choices=(4, 8), help="load the MLX 4/8-bit checkpoint (model_v1_{4,8}b.safetensors).  The group-quantised weights are EXPANDED to fp32 on load and run "
+                         "through the same 16-bit MFMA kernels as the full checkpoint: unlike in the reference this saves neither memory nor time here")
     ns = ap.parse_args(argv)
 
     text = ns.text

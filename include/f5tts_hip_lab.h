@@ -22,7 +22,8 @@ int f5_debug_gemm_streamk_error(void);
  * pipelining, 5 / 6 = pipelined 8- / 4-wave experiment */
 int f5_debug_set_attn_version(int v);
 /* experiment bits: 1 = single-issue softmax VALU (v5 / v6), 2 = one workgroup per CU, 4 = plain 2-D block numbering, 8 = eager O
- * rescale, 16 = per-tile maximum (v2w / non-fast split kernels) */
+ * rescale, 16 = per-tile maximum (v2w / non-fast split kernels), 32 = the role-split kernel re-reads Q from LDS.
+ * f5_debug_set_attn_wide(2) (lab build only) selects the role-split large-grid kernel f5_attn2r_kernel */
 int f5_debug_set_attn_variant(int bits);
 int f5_debug_set_attn_ablation(int v);      /* timing-only ablations of the mid-size ring kernel (results wrong unless 0) */
 /* large-grid kernel with a per-tile maximum: which phase holds SIMD issue priority: 0 MFMA clusters, 1 none, 2 softmax section */

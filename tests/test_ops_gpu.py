@@ -699,6 +699,30 @@ def test_attention_without_tile_maximum(lib, path, premul):
 
 
 @pytest.mark.lab
+@pytest.mark.parametrize("premul", [False, True])
+@pytest.mark.parametrize("q_in_lds", [False, True])
+def test_attention_role_split_kernel(lib, q_in_lds, premul):
+    """f5_attn2r_kernel (lab: measured slower than f5_attn2f, kept as the evidence): 512-query workgroups of 8 waves, the two
+    wave groups alternate MFMA and softmax segments one barrier apart.  Same cases as the shipped large-grid kernel: plain,
+    ragged, one-tile and partial-tile sequences, waves entirely past the sequence, spikes that force the exact path."""
+    E.check(lib.f5_debug_set_attn_wide(2))
+    E.check(lib.f5_debug_set_attn_kvsplit(1))
+    E.check(lib.f5_debug_set_attn_variant(32 if q_in_lds else 0))
+    try:
+        _attention_case(lib, 1, 2, 50, None, 1, seed=1, premul=premul)
+        _attention_case(lib, 3, 2, 200, [200, 130, 1], 1, seed=7, premul=premul)
+        _attention_case(lib, 2, 4, 300, [300, 211], 1, seed=21, premul=premul)
+        _attention_case(lib, 1, 2, 937, None, 1, seed=8, premul=premul)
+        _attention_case(lib, 6, 16, 1100, [1100, 1099, 513, 512, 64, 7], 1, seed=9, premul=premul)
+        for N, spikes in ((300, ((70, 30.0), (200, 60.0))), (937, ((936, 400.0),)), (500, ((3, 100.0),)), (700, ((64, 50.0), (65, 90.0), (640, 20.0)))):
+            test_attention_softmax_spike(lib, hp=0, premul=premul, N=N, spikes=spikes)
+    finally:
+        E.check(lib.f5_debug_set_attn_variant(0))
+        E.check(lib.f5_debug_set_attn_wide(-1))
+        E.check(lib.f5_debug_set_attn_kvsplit(-1))
+
+
+@pytest.mark.lab
 def test_attention_tile_maximum_kernels_still_selectable(lib):
     """attention variant bit 16 = the kernels of round 1 / early round 2 (tile maximum on every tile), kept for A/B runs"""
     E.check(lib.f5_debug_set_attn_variant(16))

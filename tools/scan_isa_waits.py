@@ -1,0 +1,50 @@
+"""Scan gfx950 ISA (hipcc -S output) for `s_waitcnt vmcnt(..)` that the COMPILER put inside a loop.
+
+Why: the kernels here count their own outstanding loads (`asm volatile("s_waitcnt vmcnt(N)")`) so that K / V^T or A / W tiles stay
+in flight across barriers.  The compiler's waitcnt pass does not read inline asm.  If a value loaded global -> register before a
+loop is first used inside it, the compiler adds its own wait at that use -- in the loop body, typically vmcnt(0), which drains the
+hand-counted prefetch on every iteration (found in round 3 in the attention kernels: profiles/r03/attention_q_pin_ab.txt).  The
+same happens to every ds_read of a kernel that has TWO __shared__ arrays and uses global_load_lds (alias scopes from the LDS
+lowering).  Hand-written waits appear between `;;#ASMSTART` / `;;#ASMEND` markers and are skipped.
+
+usage:  python tools/scan_isa_waits.py f5_tts_mlx_amd/csrc/attention.hip [-DF5_F16=1 ...]      (compiles, then scans)
+        python tools/scan_isa_waits.py file.s                                                  (scans)
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+
+def scan(asm_text):
+    """-> {kernel symbol: [(line number, instruction), ...]} of compiler-inserted vmcnt waits inside loop blocks"""
+    out, fn, inloop = {}, None, False
+    lines = asm_text.split("\n")
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            fn, inloop = m.group(1), False
+        if re.match(r"^\.LBB", l) or re.match(r"^; %bb", l):
+            inloop = "in Loop" in l or "Loop Header" in l
+        if fn and inloop and "s_waitcnt" in l and "vmcnt" in l and not lines[i - 1].strip().startswith(";;#ASMSTART"):
+            out.setdefault(fn, []).append((i + 1, l.strip()))
+    return out
+
+
+def compile_to_asm(src, flags=()):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        o = os.path.join(d, "k.s")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DF5_LAB=0", *flags, "-S", "--cuda-device-only", src, "-o", o]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        return open(o).read()
+
+
+if __name__ == "__main__":
+    path, flags = sys.argv[1], sys.argv[2:]
+    text = open(path).read() if path.endswith(".s") else compile_to_asm(path, flags)
+    res = scan(text)
+    for k, v in res.items():
+        print(k, len(v), v[:6])
+    print(f"{len(res)} kernel(s) with compiler-inserted vmcnt waits inside loops")
