@@ -802,6 +802,9 @@ __global__ __launch_bounds__(256, 2) void f5_attn2f_kernel(F5AttnArgs p) {
     const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
     const int ntile = (kvlen + 63) >> 6;
     const size_t rowbase = (size_t)b * p.seq_len;
+    // wave-uniform: at N = 937 one wave in 16 lies entirely past the sequence; it used to compute on clamped rows (6 % of the
+    // launch's MFMA and softmax work, thrown away at the store -- on a power-limited part that is 6 % of the time)
+    const bool live = q0 < p.seq_len;
 
     op16x8 qf[2][4];
 #pragma unroll
@@ -900,6 +903,7 @@ __global__ __launch_bounds__(256, 2) void f5_attn2f_kernel(F5AttnArgs p) {
         const op16_t* sK = smem + (j % NST) * (2 * TILE);
         const op16_t* sV = sK + TILE;
 
+        if (!live) continue;                              // a wave entirely past the sequence only stages tiles and keeps the barriers
         f32x16 s[2][2];                                   // [query block][key block]
         float psum[2];
         bool slow = j == 0;
