@@ -49,12 +49,25 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
     const int kt = p.K / BK;
     const int T = kt * p.nseg;
 
-    // XCD-chunked tile list, M FASTEST: the row tiles of one W panel sit on one XCD (its private L2 fetches the 256-column panel once;
-    // the whole A operand of a batch-1 launch, 3.8 MB, fits every L2)
-    const int q = ntiles >> 3, r = ntiles & 7;
+    // Workgroups are dealt to the 8 XCDs round-robin by block id, each XCD has a private L2, and what an L2 does not hold comes
+    // over the fabric (the weights of 22 blocks never stay on chip).  Two numberings:
+    //  * XCD GRID 2 x 4 (tiles_m even, tiles_n a multiple of 4): XCD x owns row-tile half x & 1 and column-tile quarter x >> 1, so
+    //    an L2 fetches HALF of A and a QUARTER of W.  Batch-1 QKV (16 x 12 tiles): 15 + 12.6 MB of operand fetches;
+    //  * XCD-chunked list, M fastest (the fallback, and debug flag 4096): an XCD's consecutive tiles share W panels but every L2
+    //    fetches ALL of A: 30 + 8.4 MB for the same launch (PMC: 52.6 MB per launch including the 11.5 MB of output).
     const int xcd = bid & 7, idx = bid >> 3;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tn = tile / tiles_m, tm = tile - tn * tiles_m;
+    int tn, tm;
+    if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0 && (p.debug_flags & 4096) == 0) {
+        const int hm = tiles_m >> 1, qn = tiles_n >> 2;
+        const int tl = idx / hm;
+        tm = (xcd & 1) * hm + (idx - tl * hm);
+        tn = (xcd >> 1) * qn + tl;
+    } else {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tn = tile / tiles_m;
+        tm = tile - tn * tiles_m;
+    }
     const int n0 = tn * 256;
     // Row tiles.  Plain: 128 consecutive rows of the [M][K] operand.  EPI_QKV_ROPE (rows = [batch element][position]): tiles are
     // laid out PER BATCH ELEMENT (tiles_per_elem = ceil(seq_len / 128) each) and never straddle two of them, so a tile's first

@@ -234,6 +234,8 @@ int f5_debug_set_gemm_tile(int sel);
  * bit 1: small-tile kernels use the direct (2-byte store) epilogue instead of the LDS-staged one;
  * bit 8 (256): the small-tile ring kernels load x / bias / gate / keep of the residual update in the epilogue instead of
  *            requesting them before the K loop (A/B of the default; identical bits);
+ * bit 12 (4096): the role-split 128x256 kernel numbers its tiles as an XCD-chunked list (M fastest) instead of dealing a 2 x 4
+ *            grid of tile blocks to the XCDs (A/B of the default; identical bits);
  * bit 14 (16384): the 256x256 kernel accumulates 16-bit-output tiles (FF1, plain 16-bit, q / k of QKV) in the straight order with
  *            2-byte staging writes instead of transposed with 8-byte ones (A/B; identical bits for FF1 / plain);
  * lab build only: bit 3 (8) residual update by no-return L2 atomics, bits 9-11 x-tile prefetch, bits 4-7 ring-loop ablations */
