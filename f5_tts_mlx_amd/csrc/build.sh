@@ -17,12 +17,18 @@ pids=()
 stale() {  # $1 = source, $2 = object, $3 = 1 when the source includes the public C-ABI header
   [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer "$2")" ] || { [ "$3" = 1 ] && [ ../../include/f5tts_hip.h -nt "$2" ]; }
 }
+# The GEMM files are built WITHOUT the SLP vectoriser.  On gfx950 a packed-f32 VALU instruction whose LO result reads the HI
+# register of src1 (v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[x,1]) returns that operand as 0 on lanes 48-63 now and then when
+# another wave of the same SIMD has MFMAs in flight (tools/probes/pk_f32_vs_mfma2.hip, DESIGN.md "packed f32 next to MFMA").  The
+# SLP vectoriser produces exactly that form from the rotation / gate arithmetic of the GEMM epilogues, which run next to other
+# workgroups' (or the other wave group's) MFMA loops.  tests/test_isa.py checks the ISA of every kernel that contains MFMAs.
+noslp() { case "$1" in gemm|gemm256|gemm_rs128|gemm_f8|gemm_lab|gemm128) echo "-fno-slp-vectorize";; *) echo "";; esac; }
 objs=()
 for f in $KERNELS; do
   for v in 0 1; do
     o=$B/${f}_h$v.o
     objs+=($o)
-    if stale $f.hip $o 0; then $HIPCC $FLAGS -DF5_F16=$v -c $f.hip -o $o & pids+=($!); fi
+    if stale $f.hip $o 0 || [ build.sh -nt $o ]; then $HIPCC $FLAGS $(noslp $f) -DF5_F16=$v -c $f.hip -o $o & pids+=($!); fi
   done
 done
 for f in audio vocoder noise engine; do

@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tools.scan_isa_waits import compile_to_asm, scan  # noqa: E402
+from tools.scan_isa_waits import compile_to_asm, scan, scan_pk_hazard  # noqa: E402
 
 
 @pytest.mark.parametrize("f16", [1])
@@ -21,3 +21,31 @@ def test_attention_loops_have_no_compiler_vmcnt_wait(f16):
     found = {k: v for k, v in scan(asm).items() if "f5_attn" in k}
     assert "v_mfma_f32_32x32x16_f16" in asm and "f5_attn2f_kernel" in asm and "f5_attn2s_kernel" in asm
     assert not found, found
+
+
+NOSLP = ("gemm", "gemm256", "gemm_rs128", "gemm_f8")       # as in csrc/build.sh
+
+
+def _asm(job):
+    name, f16 = job
+    flags = [f"-DF5_F16={f16}"] + (["-fno-slp-vectorize"] if name in NOSLP else [])
+    return name, compile_to_asm(os.path.join(ROOT, "f5_tts_mlx_amd", "csrc", name + ".hip"), flags)
+
+
+def test_no_packed_f32_with_hi_to_lo_select_in_mfma_kernels():
+    """Round-2 hazard (a), root-caused in round 3: v_pk_mul_f32 / v_pk_add_f32 whose LO result reads the HI register of src1
+    (op_sel:[x,1]) returns 0 for that operand on lanes 48-63 when another wave of the SIMD has MFMAs in flight
+    (tools/probes/pk_f32_vs_mfma2.hip: 0 wrong in 4e10 with idle partners, hundreds with MFMA partners; plain selects never).  The
+    SLP vectoriser emits that form for the epilogue arithmetic, so the GEMM files are built with -fno-slp-vectorize: no kernel
+    that contains MFMAs may carry the form, in the flags the library is built with."""
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    build_sh = open(os.path.join(ROOT, "f5_tts_mlx_amd", "csrc", "build.sh")).read()
+    assert "gemm|gemm256|gemm_rs128|gemm_f8" in build_sh and "-fno-slp-vectorize" in build_sh
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [(n, 1) for n in ("gemm", "gemm256", "gemm_rs128", "gemm_f8", "attention", "convpos")]
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        for name, asm in ex.map(_asm, jobs):
+            assert "v_mfma" in asm, name
+            found = scan_pk_hazard(asm)
+            assert not found, (name, found)

@@ -32,6 +32,29 @@ def scan(asm_text):
     return out
 
 
+_PK = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32)\s.*op_sel:\[(\d),(\d)(?:,(\d))?\]")
+
+
+def scan_pk_hazard(asm_text):
+    """-> {kernel symbol: count} of packed-f32 VALU instructions whose LO result reads the HI register of src1 (op_sel:[x,1,..]) in
+    kernels that also contain MFMAs.  On gfx950 that operand comes back as 0 on lanes 48-63 now and then while ANOTHER wave of the
+    SIMD has MFMAs in flight (tools/probes/pk_f32_vs_mfma2.hip; profiles/r03/pk_f32_next_to_mfma_hazard.txt) -- the root cause of the
+    'lanes 48-63' nondeterminism of round 2.  The SLP vectoriser emits the form; the GEMM files are built with -fno-slp-vectorize."""
+    out, mfma, fn = {}, set(), None
+    for l in asm_text.split("\n"):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            fn = m.group(1)
+        if not fn:
+            continue
+        if "v_mfma" in l:
+            mfma.add(fn)
+        m = _PK.match(l)
+        if m and m.group(3) == "1":
+            out[fn] = out.get(fn, 0) + 1
+    return {k: v for k, v in out.items() if k in mfma}
+
+
 def compile_to_asm(src, flags=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     with tempfile.TemporaryDirectory() as d:
@@ -48,3 +71,7 @@ if __name__ == "__main__":
     for k, v in res.items():
         print(k, len(v), v[:6])
     print(f"{len(res)} kernel(s) with compiler-inserted vmcnt waits inside loops")
+    pk = scan_pk_hazard(text)
+    for k, v in pk.items():
+        print(k, v)
+    print(f"{len(pk)} MFMA kernel(s) with packed-f32 instructions whose lo result reads src1's hi register")
