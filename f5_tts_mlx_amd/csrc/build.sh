@@ -22,7 +22,8 @@ stale() {  # $1 = source, $2 = object, $3 = 1 when the source includes the publi
 # another wave of the same SIMD has MFMAs in flight (tools/probes/pk_f32_vs_mfma2.hip, DESIGN.md "packed f32 next to MFMA").  The
 # SLP vectoriser produces exactly that form from the rotation / gate arithmetic of the GEMM epilogues, which run next to other
 # workgroups' (or the other wave group's) MFMA loops.  tests/test_isa.py checks the ISA of every kernel that contains MFMAs.
-noslp() { case "$1" in gemm|gemm256|gemm_rs128|gemm_f8|gemm_lab|gemm128) echo "-fno-slp-vectorize";; *) echo "";; esac; }
+# rowops.hip follows because it shares lnrow.hpp with the LN tail fused into gemm.hip: the two must produce the same bits.
+noslp() { case "$1" in gemm|gemm256|gemm_rs128|gemm_f8|gemm_lab|gemm128|rowops) echo "-fno-slp-vectorize";; *) echo "";; esac; }
 objs=()
 for f in $KERNELS; do
   for v in 0 1; do

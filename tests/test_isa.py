@@ -23,7 +23,7 @@ def test_attention_loops_have_no_compiler_vmcnt_wait(f16):
     assert not found, found
 
 
-NOSLP = ("gemm", "gemm256", "gemm_rs128", "gemm_f8")       # as in csrc/build.sh
+NOSLP = ("gemm", "gemm256", "gemm_rs128", "gemm_f8", "rowops")       # as in csrc/build.sh
 
 
 def _asm(job):
@@ -41,10 +41,10 @@ def test_no_packed_f32_with_hi_to_lo_select_in_mfma_kernels():
     if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
         pytest.skip("no hipcc")
     build_sh = open(os.path.join(ROOT, "f5_tts_mlx_amd", "csrc", "build.sh")).read()
-    assert "gemm|gemm256|gemm_rs128|gemm_f8" in build_sh and "-fno-slp-vectorize" in build_sh
+    assert "gemm|gemm256|gemm_rs128|gemm_f8|gemm_lab|gemm128|rowops" in build_sh and "-fno-slp-vectorize" in build_sh
     from concurrent.futures import ThreadPoolExecutor
-    jobs = [(n, 1) for n in ("gemm", "gemm256", "gemm_rs128", "gemm_f8", "attention", "convpos")]
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    jobs = [(n, 1) for n in ("gemm", "gemm256", "gemm_rs128", "gemm_f8", "attention", "convpos", "rowops")]
+    with ThreadPoolExecutor(max_workers=7) as ex:
         for name, asm in ex.map(_asm, jobs):
             assert "v_mfma" in asm, name
             found = scan_pk_hazard(asm)
