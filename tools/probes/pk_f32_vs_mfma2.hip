@@ -12,6 +12,9 @@
 //   7  v_pk_fma_f32 d, s, a, b op_sel:[0,0,1]                lo = s0 a0 + b1
 //   8  v_pk_fma_f32 d, s, a, b op_sel_hi:[0,1,1]             hi = s0 a1 + b1              src0.lo broadcast (rotation form)
 //   9  v_pk_fma_f32 d, s, a, b                               plain selects
+//  10  v_mov_b64 d, s                                        (the attention kernel copies accumulator pairs with it)
+//  11  v_pk_add_f32 d, s, a op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]   lo = s0 - a0, hi = s1 - a0   (the attention softmax form, literally)
+//  12  v_pk_mul_f32 d, s, a op_sel:[1,1]                     lo = s1 a1   both sources hi -> lo
 // Build: hipcc --offload-arch=gfx950 -O3 tools/probes/pk_f32_vs_mfma2.hip -o tools/probes/bin/pk_f32_vs_mfma2
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -87,6 +90,9 @@ __global__ __launch_bounds__(512) void k_mix(unsigned long long* __restrict__ cn
         if (TEST == 7) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=&v"(d) : "v"(s), "v"(a), "v"(b)); w0 = ufma(s[0], a[0], b[1]); w1 = ufma(s[1], a[1], b[1]); }
         if (TEST == 8) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=&v"(d) : "v"(s), "v"(a), "v"(b)); w0 = ufma(s[0], a[0], b[0]); w1 = ufma(s[0], a[1], b[1]); }
         if (TEST == 9) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(s), "v"(a), "v"(b)); w0 = ufma(s[0], a[0], b[0]); w1 = ufma(s[1], a[1], b[1]); }
+        if (TEST == 10) { asm volatile("v_mov_b64 %0, %1" : "=&v"(d) : "v"(s)); w0 = s[0]; w1 = s[1]; }
+        if (TEST == 11) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(d) : "v"(s), "v"(a)); w0 = uadd(s[0], -a[0]); w1 = uadd(s[1], -a[0]); }
+        if (TEST == 12) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1]" : "=&v"(d) : "v"(s), "v"(a)); w0 = umul(s[1], a[1]); w1 = umul(s[1], a[1]); }
         if (d[0] != w0) {
             if (atomicAdd(&rec_n, 1u) == 0) { rec[0] = d[0]; rec[1] = s[0]; rec[2] = s[1]; rec[3] = a[0]; rec[4] = a[1]; rec[5] = (float)lane; rec[6] = d[1]; rec[7] = w0; }
             ++bad0;
@@ -98,8 +104,8 @@ __global__ __launch_bounds__(512) void k_mix(unsigned long long* __restrict__ cn
     if (bad1) atomicAdd(&cnt[4 + q], (unsigned long long)bad1);
 }
 
-static const char* names[10] = {"pk_mul plain", "pk_mul op_sel:[0,1] op_sel_hi:[0,0]", "pk_mul op_sel:[0,1]", "pk_mul op_sel_hi:[0,0]", "pk_mul op_sel:[1,0]",
-                                "pk_mul op_sel_hi:[1,0]", "pk_add op_sel:[0,1]", "pk_fma op_sel:[0,0,1]", "pk_fma op_sel_hi:[0,1,1]", "pk_fma plain"};
+static const char* names[13] = {"pk_mul plain", "pk_mul op_sel:[0,1] op_sel_hi:[0,0]", "pk_mul op_sel:[0,1]", "pk_mul op_sel_hi:[0,0]", "pk_mul op_sel:[1,0]",
+                                "pk_mul op_sel_hi:[1,0]", "pk_add op_sel:[0,1]", "pk_fma op_sel:[0,0,1]", "pk_fma op_sel_hi:[0,1,1]", "pk_fma plain", "v_mov_b64", "pk_add op_sel_hi:[1,0] neg", "pk_mul op_sel:[1,1]"};
 
 template <int TEST>
 static void run(unsigned long long* dcnt, float* dsink, int blocks, int iters) {
@@ -142,5 +148,8 @@ int main() {
     run<7>(dcnt, dsink, blocks, iters);
     run<8>(dcnt, dsink, blocks, iters);
     run<9>(dcnt, dsink, blocks, iters);
+    run<10>(dcnt, dsink, blocks, iters);
+    run<11>(dcnt, dsink, blocks, iters);
+    run<12>(dcnt, dsink, blocks, iters);
     return 0;
 }
