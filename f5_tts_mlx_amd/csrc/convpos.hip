@@ -98,6 +98,22 @@ __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
     CP_STOREW(0);
     __syncthreads();
 
+    // mode 1 accumulates into x.  `out[off] += v` element by element in the epilogue made the compiler keep every
+    // read-modify-write in program order (it cannot rule out that one store aliases the next load): 32 dependent memory round
+    // trips per lane at the end of the kernel.  The old values are requested HERE, before the tap loop (clamped rows, so the loads
+    // are straight-line), and are long there when the epilogue adds and stores.
+    float old[2][16];
+    if (p.mode != 0) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int n = n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (n > p.seq_len - 1) n = p.seq_len - 1;
+                old[nb][r] = p.out_f32[(rowbase + n) * p.ldo + g * 64 + nb * 32 + lr];
+            }
+    }
+
     for (int t0 = 0, step = 0; t0 < taps; t0 += TPS, ++step) {
         const int cur = step & 1;
         if (t0 + TPS < taps) CP_LOADW(t0 + TPS);
@@ -130,10 +146,15 @@ __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
     }
 
     // ---- epilogue: + bias, Mish, store ----------------------------------------------------------
+    // the two bias values are requested together and waited for ONCE, outside the per-row conditionals: with the load inside the
+    // nb loop the compiler put its `s_waitcnt vmcnt(0)` for it into every conditional row block, where it also waits for all the
+    // stores issued so far -- the stores of a lane went out one memory round trip apart
+    float bias2[2] = {p.bias[g * 64 + lr], p.bias[g * 64 + 32 + lr]};
+    asm volatile("" : "+v"(bias2[0]), "+v"(bias2[1]));
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int co = g * 64 + nb * 32 + lr;
-        const float bias = p.bias[co];
+        const float bias = bias2[nb];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
                     p.out_bf[0][off] = h;
                     if (p.out_bf[1]) p.out_bf[1][off] = l;
                 } else {
-                    p.out_f32[off] += v;
+                    p.out_f32[off] = old[nb][r] + v;
                 }
             }
         }

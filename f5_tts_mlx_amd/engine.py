@@ -7,6 +7,7 @@ is missing or a call fails, this module raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Dict, Optional, Sequence
 
@@ -15,7 +16,9 @@ import torch
 
 from .weights import DiTConfig, check_weights
 
-_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libf5tts_hip.so"
+# F5TTS_HIP_LIB: another build of the SAME library (A/B runs of two builds, tools/sample_ab.py); never a fallback -- a path that does
+# not exist fails like a missing default build does
+_LIB_PATH = Path(os.environ["F5TTS_HIP_LIB"]).resolve() if os.environ.get("F5TTS_HIP_LIB") else Path(__file__).resolve().parent / "csrc" / "libf5tts_hip.so"
 _lib = None
 
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2}
