@@ -24,6 +24,16 @@ __device__ __forceinline__ void f5_ln_modulate_row(const f32x4 (&v)[NV], const f
                                                    const float* __restrict__ shift, op16_t* __restrict__ out_hi,
                                                    op16_t* __restrict__ out_lo, size_t row, int lane, float eps) {
     constexpr int DIM = NV * 256;
+    // the modulation vectors do not depend on the row: all of them are requested before the reductions.  Loaded chunk by chunk
+    // inside the output loop, each chunk cost a full memory round trip behind the previous chunk's store (the compiler's
+    // `s_waitcnt vmcnt(0)` for the new loads also waits for that store)
+    f32x4 scv[NV], shv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        scv[i] = *reinterpret_cast<const f32x4*>(scale + i * 256 + lane * 4);
+        shv[i] = *reinterpret_cast<const f32x4*>(shift + i * 256 + lane * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // (the scheduler otherwise sinks them behind the reductions again)
     float sum = 0.0f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -41,8 +51,7 @@ __device__ __forceinline__ void f5_ln_modulate_row(const f32x4 (&v)[NV], const f
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+        const f32x4 sc = scv[i], sh = shv[i];
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * (1.0f + sc[e]) + sh[e];

@@ -15,10 +15,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-if os.environ.get("F5_PROBE_LIB"):                      # A/B of two LIBRARIES: run the tool once per library (same settings)
-    from pathlib import Path
-    from f5_tts_mlx_amd import engine as _E
-    _E._LIB_PATH = Path(os.environ["F5_PROBE_LIB"]).resolve()
+# A/B of two LIBRARIES: run the tool once per library with F5TTS_HIP_LIB=<other build> (f5_tts_mlx_amd/engine.py reads it)
 
 
 def main():
@@ -61,7 +58,7 @@ def main():
                 f5.sample(cond, text, **kw)
             torch.cuda.synchronize()
             ms[i].append(round((time.perf_counter() - t0) / a.iters * 1e3, 2))
-    print(json.dumps(dict(lib=os.path.basename(os.environ.get("F5_PROBE_LIB", "libf5tts_hip.so")), batch=a.batch, precision=a.precision, settings=a.settings, ms=ms,
+    print(json.dumps(dict(lib=os.path.basename(os.environ.get("F5TTS_HIP_LIB", "libf5tts_hip.so")), batch=a.batch, precision=a.precision, settings=a.settings, ms=ms,
                           median=[sorted(m)[len(m) // 2] for m in ms],
                           identical=[bool(torch.equal(outs[0], o)) for o in outs])))
 
