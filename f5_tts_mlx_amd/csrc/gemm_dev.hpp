@@ -30,6 +30,11 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
         bcol[nb] = (EPI != EPI_ADDROWS && p.bias != nullptr && colok[nb]) ? p.bias[col[nb]] : 0.0f;
         gcol[nb] = (EPI == EPI_RESID_GATE && colok[nb]) ? p.gate[col[nb]] : 0.0f;
     }
+    // waited for ONCE, here: a value whose first use sits inside the per-row conditionals gets the compiler's `s_waitcnt vmcnt(0)` in
+    // every one of those blocks, where it also waits for all the stores issued so far (the stores of a lane then leave one memory
+    // round trip apart; found in the conv-pos kernel, profiles/r03/convpos_epilogue_ab.txt)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(bcol[nb]), "+v"(gcol[nb]));
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int rowblk = m0 + wm * (32 * MB) + mb * 32 + hi * 4;   // row of (rg, ri) = rowblk + rg*8 + ri
@@ -54,6 +59,10 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                     pre[r][nb] = v;
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(pre[r][nb]));     // (the batch is waited for once, see above)
         }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
@@ -443,7 +452,8 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
     const int chunk = lane % CPR;
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gate + colbase + chunk * 4);
+    f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gate + colbase + chunk * 4);
+    asm volatile("" : "+v"(g4));
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
         const int rowblk = row0 + mb * 32;
@@ -463,6 +473,11 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) reg[lrow * LD + nb * 32 + lcol] = acc[mb][nb][r] + bcol[nb];
         }
+        // the x rows (requested above, in flight during the staging writes) are waited for ONCE, here.  Their first use used to be
+        // inside the `grow < M` blocks below: the compiler's `s_waitcnt vmcnt(0)` for them sat in every block and also waited for
+        // the store of the previous block -- the eight 16-byte stores of a lane left one memory round trip apart
+#pragma unroll
+        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(xr[i]), "+v"(kp[i]));
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
