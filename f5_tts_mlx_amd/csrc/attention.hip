@@ -792,6 +792,10 @@ __global__ __launch_bounds__(256, 2) void f5_attn2f_kernel(F5AttnArgs p) {
     constexpr int TILE = 64 * 64;
     __shared__ __attribute__((aligned(16))) op16_t smem[NST * 2 * TILE];   // [stage][K | V^T][64*64]
 
+    // the whole argument block in ONE scalar-load clause (left alone the compiler loads each field where it is first used: three or
+    // four dependent s_load / s_waitcnt rounds in the prologue of a kernel that is one latency chain at batch 1)
+    asm volatile("" ::"s"(p.qk[0]), "s"(p.vt[0]), "s"(p.out[0]), "s"(p.kv_len), "s"(p.B), "s"(p.H), "s"(p.seq_len), "s"(p.npad), "s"(p.ldqk),
+                 "s"(p.ldo), "s"(p.dmodel), "s"(p.scale), "s"(p.out8));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lq = lane & 31;
@@ -1290,6 +1294,10 @@ __global__ __launch_bounds__(256 * KS, 1) void f5_attn2s_kernel(F5AttnArgs p) {
     static_assert((KS - 1) * 4 * 34 * 64 * 4 <= KS * RING * 2, "merge area must fit in the rings");
     __shared__ __attribute__((aligned(16))) op16_t smem_all[KS * RING];
 
+    // the whole argument block in ONE scalar-load clause (left alone the compiler loads each field where it is first used: three or
+    // four dependent s_load / s_waitcnt rounds in the prologue of a kernel that is one latency chain at batch 1)
+    asm volatile("" ::"s"(p.qk[0]), "s"(p.vt[0]), "s"(p.out[0]), "s"(p.kv_len), "s"(p.B), "s"(p.H), "s"(p.seq_len), "s"(p.npad), "s"(p.ldqk),
+                 "s"(p.ldo), "s"(p.dmodel), "s"(p.scale), "s"(p.out8));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave_all >> 2, wave = wave_all & 3;

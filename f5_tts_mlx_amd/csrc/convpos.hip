@@ -22,6 +22,8 @@ __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
     __shared__ __attribute__((aligned(16))) op16_t sX[NP][HALO * XLD];
     __shared__ __attribute__((aligned(16))) op16_t sW[2][TPS][NP][64 * XLD];
 
+    asm volatile("" ::"s"(p.in[0]), "s"(p.W[0]), "s"(p.bias), "s"(p.B), "s"(p.seq_len), "s"(p.groups), "s"(p.taps), "s"(p.ld), "s"(p.mode),
+                 "s"(p.out_bf[0]), "s"(p.out_f32), "s"(p.ldo));              // the argument block in one scalar-load clause
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lr = lane & 31;
     // workgroup -> (token tile, group, batch element).  Every workgroup of a group streams that group's 31 weight slabs

@@ -342,6 +342,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     static_assert(KS * RING * 2 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) op16_t smem_all[KS * RING];
 
+    // the argument-block fields of the prologue in ONE scalar-load clause (left alone the compiler loads each field where it is
+    // first used: three dependent s_load / s_waitcnt rounds before the first tile request of a one-round launch)
+    asm volatile("" ::"s"(p.A[0]), "s"(p.W[0]), "s"(p.lda), "s"(p.ldw), "s"(p.K), "s"(p.nseg), "s"(p.M), "s"(p.N), "s"(p.a_row_mod),
+                 "s"(p.debug_flags), "s"(tiles_n), "s"(ntiles));
+    if (EPI == EPI_RESID_GATE)                          // (the residual operands are requested before the K loop)
+        asm volatile("" ::"s"(p.bias), "s"(p.out_f32), "s"(p.ldo), "s"(p.gate), "s"(p.rowkeep), "s"(p.ln_counter));
     const int bid = blockIdx.x;
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = bid & 7, idx = bid >> 3;

@@ -41,6 +41,11 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
     constexpr int SLOT = 2 * AH + 2 * BH;       // 24576 elements = 48 KB
     __shared__ __attribute__((aligned(16))) op16_t smem[3 * SLOT];
 
+    // everything the prologue needs from the argument block is requested in ONE scalar-load clause: left to itself the compiler loads
+    // the fields where they are first used -- three dependent s_load / s_waitcnt rounds before the first tile request of a kernel
+    // that is a single latency chain
+    asm volatile("" ::"s"(p.seq_len), "s"(p.A[0]), "s"(p.W[0]), "s"(p.lda), "s"(p.ldw), "s"(p.K), "s"(p.nseg), "s"(p.M), "s"(p.a_row_mod),
+                 "s"(p.debug_flags), "s"(tiles_n), "s"(ntiles), "s"(tiles_m));
     const int bid = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
