@@ -1,4 +1,5 @@
-"""Scan gfx950 ISA (hipcc -S output) for `s_waitcnt vmcnt(..)` that the COMPILER put inside a loop.
+"""Scan gfx950 ISA (hipcc -S output) for what the compiler added behind hand-scheduled memory traffic: `s_waitcnt vmcnt(..)` it put
+inside a loop (scan), waits that serialise stores (scan_store_waits), packed-f32 forms that are unsafe next to MFMAs (scan_pk_hazard).
 
 Why: the kernels here count their own outstanding loads (`asm volatile("s_waitcnt vmcnt(N)")`) so that K / V^T or A / W tiles stay
 in flight across barriers.  The compiler's waitcnt pass does not read inline asm.  If a value loaded global -> register before a
@@ -55,6 +56,49 @@ def scan_pk_hazard(asm_text):
     return {k: v for k, v in out.items() if k in mfma}
 
 
+def scan_store_waits(asm_text, min_cluster=4, gap=150):
+    """-> {kernel symbol: [(first line, last line, count), ...]}: clusters of compiler-inserted vmcnt waits that are reached with
+    stores outstanding.  A value loaded before a run of `if (row < M) { ... store }` blocks and first USED inside them gets the
+    compiler's wait inside every block (the blocks are separate basic blocks, any of them may be the first one executed); with no
+    separate store counter on gfx9 that `s_waitcnt vmcnt(0)` also waits for every store issued so far, so the stores of a lane
+    leave one memory round trip apart.  Found in the conv-pos, residual and direct GEMM epilogues in round 3
+    (profiles/r03/convpos_epilogue_ab.txt); the cure is one `asm volatile("" : "+v"(x))` on the loaded values before the blocks.
+    Clusters in code that is never executed (e.g. the fused LN tail, default off) are reported too: read the listing."""
+    out, fn, pend, ev = {}, None, 0, []
+    lines = asm_text.split("\n")
+
+    def flush():
+        if fn is None or not ev:
+            return
+        cl = []
+        for e in ev:
+            if cl and e - cl[-1][1] < gap:
+                cl[-1][1] = e
+                cl[-1][2] += 1
+            else:
+                cl.append([e, e, 1])
+        cl = [tuple(c) for c in cl if c[2] >= min_cluster]
+        if cl:
+            out[fn] = cl
+
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            flush()
+            fn, pend, ev = m.group(1), 0, []
+        if fn is None:
+            continue
+        if "global_store" in l or "buffer_store" in l:
+            pend += 1
+        m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+        if m and not lines[i - 1].strip().startswith(";;#ASMSTART"):
+            if pend > int(m.group(1)):
+                ev.append(i + 1)
+            pend = min(pend, int(m.group(1)))
+    flush()
+    return out
+
+
 def compile_to_asm(src, flags=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     with tempfile.TemporaryDirectory() as d:
@@ -74,4 +118,8 @@ if __name__ == "__main__":
     pk = scan_pk_hazard(text)
     for k, v in pk.items():
         print(k, v)
-    print(f"{len(pk)} MFMA kernel(s) with packed-f32 instructions whose lo result reads src1's hi register")
+    print(f"{len(pk)} MFMA kernel(s) with packed-f32 instructions whose lo result reads a source's hi register")
+    sw = scan_store_waits(text)
+    for k, v in sw.items():
+        print(k, v)
+    print(f"{len(sw)} kernel(s) with clusters of compiler-inserted vmcnt waits reached with stores outstanding")
