@@ -122,14 +122,41 @@ __device__ inline float f5_mish(float x) {
 }
 
 // ---- wave helpers ----------------------------------------------------------------------------
+// All-lanes butterfly reductions (offsets 32, 16, 8, 4, 2, 1; every lane ends with the result) WITHOUT the six LDS round trips of
+// __shfl_xor (ds_bpermute_b32): lanes i / i + 32 exchange with v_permlane32_swap, rows of 16 lanes with v_permlane16_swap, and inside a
+// row a rotation by 8 / 4 / 2 / 1 (DPP row_ror, fused into the add) delivers the butterfly partner because after the previous step the
+// values are already symmetric under the larger offsets.  Same pairs added in the same order: bit-identical to the __shfl_xor loop
+// (tools/probes: 262 144 wave sums compared on the GPU, 0 different).  One-row-per-wave kernels are latency chains at batch 1.
+template <int CTRL>
+__device__ __forceinline__ float f5_dpp_row(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float f5_xor32(float v, unsigned lane) {
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((lane & 32u) ? s[0] : s[1]);
+}
+__device__ __forceinline__ float f5_xor16(float v, unsigned lane) {
+    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((lane & 16u) ? s[0] : s[1]);
+}
 __device__ inline float f5_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    v += f5_xor32(v, lane);
+    v += f5_xor16(v, lane);
+    v += f5_dpp_row<0x128>(v);   // row_ror:8
+    v += f5_dpp_row<0x124>(v);   // row_ror:4
+    v += f5_dpp_row<0x122>(v);   // row_ror:2
+    v += f5_dpp_row<0x121>(v);   // row_ror:1
     return v;
 }
 __device__ inline float f5_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    v = fmaxf(v, f5_xor32(v, lane));
+    v = fmaxf(v, f5_xor16(v, lane));
+    v = fmaxf(v, f5_dpp_row<0x128>(v));
+    v = fmaxf(v, f5_dpp_row<0x124>(v));
+    v = fmaxf(v, f5_dpp_row<0x122>(v));
+    v = fmaxf(v, f5_dpp_row<0x121>(v));
     return v;
 }
 
