@@ -458,14 +458,16 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
     for (int mb = 0; mb < MBW; ++mb) {
         const int rowblk = row0 + mb * 32;
         f32x4 xr[NI];
-        float kp[NI];
+        uint32_t kraw[NI];                 // the keep byte as loaded: converting it inside this loop put a `s_waitcnt vmcnt(0)` behind
+                                           // every byte load, i.e. behind every x-row load -- the rows of a lane were fetched one
+                                           // memory round trip after the other
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int grow = rowblk + i * RPI + lane / CPR;
             const bool ok = grow < p.M;
             xr[i] = ok ? *reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4)
                        : f32x4{0.f, 0.f, 0.f, 0.f};
-            kp[i] = (ok && p.rowkeep != nullptr) ? (float)p.rowkeep[grow] : 1.0f;
+            kraw[i] = (ok && p.rowkeep != nullptr) ? (uint32_t)p.rowkeep[grow] : 1u;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -476,8 +478,12 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
         // the x rows (requested above, in flight during the staging writes) are waited for ONCE, here.  Their first use used to be
         // inside the `grow < M` blocks below: the compiler's `s_waitcnt vmcnt(0)` for them sat in every block and also waited for
         // the store of the previous block -- the eight 16-byte stores of a lane left one memory round trip apart
+        float kp[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(xr[i]), "+v"(kp[i]));
+        for (int i = 0; i < NI; ++i) {
+            asm volatile("" : "+v"(xr[i]), "+v"(kraw[i]));
+            kp[i] = (float)kraw[i];
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
