@@ -99,6 +99,33 @@ def scan_store_waits(asm_text, min_cluster=4, gap=150):
     return out
 
 
+def scan_small_load_batches(asm_text, max_loads=2, min_count=4):
+    """-> {kernel symbol: (drain points with <= max_loads loads issued since the previous drain, all drain points)} for kernels with
+    at least min_count such points.  A "drain point" is a compiler-inserted `s_waitcnt vmcnt(0 | 1)`.  Many of them with one or two
+    loads in between = loads fetched one memory round trip after the other.  Found in the residual epilogue of the 256x256 kernel: the
+    row-keep byte was converted to float inside the loop that requests the x rows, so every row load was followed by a full drain
+    (profiles/r03/resid_epilogue_loads_ab.txt: batch-32 sample() -2.1 % once the byte stays raw until all rows are requested)."""
+    out, fn, nl, small, tot = {}, None, 0, 0, 0
+    lines = asm_text.split("\n")
+    for i, l in enumerate(lines + ["_Zend:"]):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            if fn and small >= min_count:
+                out[fn] = (small, tot)
+            fn, nl, small, tot = m.group(1), 0, 0, 0
+        if fn is None:
+            continue
+        if re.search(r"\b(global_load|buffer_load)_", l) and "lds" not in l:
+            nl += 1
+        m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+        if m and i > 0 and not lines[i - 1].strip().startswith(";;#ASMSTART") and int(m.group(1)) <= 1:
+            if nl > 0:
+                tot += 1
+                small += nl <= max_loads
+            nl = 0
+    return out
+
+
 def compile_to_asm(src, flags=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     with tempfile.TemporaryDirectory() as d:
@@ -123,3 +150,7 @@ if __name__ == "__main__":
     for k, v in sw.items():
         print(k, v)
     print(f"{len(sw)} kernel(s) with clusters of compiler-inserted vmcnt waits reached with stores outstanding")
+    sb = scan_small_load_batches(text)
+    for k, v in sb.items():
+        print(k, v)
+    print(f"{len(sb)} kernel(s) with runs of full drains behind one or two loads")
