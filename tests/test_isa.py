@@ -49,3 +49,28 @@ def test_no_packed_f32_with_hi_to_lo_select_in_mfma_kernels():
             assert "v_mfma" in asm, name
             found = scan_pk_hazard(asm)
             assert not found, (name, found)
+
+
+def test_isa_scanners_on_synthetic_listings():
+    """The scanners themselves, on hand-written listings (no compiler needed)."""
+    from tools.scan_isa_waits import scan_small_load_batches, scan_store_waits
+    asm = "\n".join([
+        "_Zk1:",
+        "\tglobal_load_dword v1, v[2:3], off",
+        ".LBB0_1:                               ; =>This Inner Loop Header: Depth=1",
+        "\ts_waitcnt vmcnt(0)",                                  # compiler wait inside a loop -> flagged
+        "\tv_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]",
+        "\t;;#ASMSTART",
+        "\ts_waitcnt vmcnt(2)",                                  # hand-written -> ignored
+        "\t;;#ASMEND",
+        "\tv_pk_mul_f32 v[4:5], v[6:7], v[8:9] op_sel:[0,1] op_sel_hi:[0,0]",   # hi -> lo select in an MFMA kernel -> flagged
+        "\tv_pk_add_f32 v[4:5], v[6:7], v[8:9] op_sel_hi:[1,0]",                # broadcast form -> fine
+        "\ts_cbranch_scc1 .LBB0_1",
+        "_Zk2:",
+        "\tv_pk_mul_f32 v[4:5], v[6:7], v[8:9] op_sel:[0,1]",                   # no MFMA in this kernel -> not flagged
+    ] + sum([["\tglobal_load_dword v1, v[2:3], off", "\ts_waitcnt vmcnt(0)", "\tglobal_store_dword v[2:3], v1, off"] for _ in range(6)], []))
+    assert list(scan(asm)) == ["_Zk1"] and len(scan(asm)["_Zk1"]) == 1
+    assert scan_pk_hazard(asm) == {"_Zk1": 1}
+    sw = scan_store_waits(asm)
+    assert list(sw) == ["_Zk2"] and sw["_Zk2"][0][2] == 5        # five of the six drains are reached with a store outstanding
+    assert scan_small_load_batches(asm) == {"_Zk2": (6, 6)}
