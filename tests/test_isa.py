@@ -44,11 +44,23 @@ def test_no_packed_f32_with_hi_to_lo_select_in_mfma_kernels():
     assert "gemm|gemm256|gemm_rs128|gemm_f8|gemm_lab|gemm128|rowops" in build_sh and "-fno-slp-vectorize" in build_sh
     from concurrent.futures import ThreadPoolExecutor
     jobs = [(n, 1) for n in ("gemm", "gemm256", "gemm_rs128", "gemm_f8", "attention", "convpos", "rowops")]
+    from tools.scan_isa_waits import scan_small_load_batches, scan_store_waits
     with ThreadPoolExecutor(max_workers=7) as ex:
         for name, asm in ex.map(_asm, jobs):
             assert "v_mfma" in asm, name
             found = scan_pk_hazard(asm)
             assert not found, (name, found)
+            # the serialised epilogues found in round 3 stay fixed (profiles/r03/convpos_epilogue_ab.txt, resid_epilogue_loads_ab.txt,
+            # ln_modulate_loads_ab.txt): no store-serialising wait clusters in the conv-pos kernels or in the residual epilogue of
+            # the 256x256 kernel, no runs of full drains behind single loads in the residual epilogue or in LN-modulate
+            if name == "convpos":
+                assert not scan_store_waits(asm), scan_store_waits(asm)
+            if name == "gemm256":
+                resid = "f5_gemm256_kernelILi4E"
+                assert not [k for k in scan_store_waits(asm) if resid in k]
+                assert not [k for k in scan_small_load_batches(asm) if resid in k]
+            if name == "rowops":
+                assert not [k for k in scan_small_load_batches(asm) if "ln_modulate_kernel" in k]
 
 
 def test_isa_scanners_on_synthetic_listings():
