@@ -105,6 +105,40 @@ def _time_launches(run, dev, iters: int) -> float:
     return e0.elapsed_time(e1) / iters
 
 
+def mfma_peak_measured(precision: str, dev) -> dict:
+    """The MFMA rate this box delivers right now, measured ("print the measured MFMA micro-benchmark peak you
+    divide by"): f5_op_mfma_peak = every wave of 1 024 workgroups streams v_mfma_f32_32x32x16 on register operands, no memory
+    traffic -- once on lane-constant registers (what zero-filled benchmarks see) and once on workload-like operand registers that
+    change from MFMA to MFMA (the delivered clock depends on how many operand bits toggle, MI355X_MICROARCH.md "DVFS give-back").
+    `frac` in the roofline records keeps the data-sheet 2.5 PF denominator; `frac_of_measured` divides by the workload-like figure."""
+    import ctypes as C
+    from f5_tts_mlx_amd import engine as E
+    lib = E.load_library()
+    opd = E.operand_dtype(precision)
+    sink = torch.zeros(4, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    ops = torch.randn(16 * 64 * 8, generator=g).to(dev).to(opd)
+    out = {}
+    with E.operand_type(precision):
+        for key, operands in (("constant_operands", None), ("workload_like_operands", ops)):
+            fl = C.c_double()
+            run = lambda: E.check(lib.f5_op_mfma_peak(E.ptr(operands), 1024, 2000, E.ptr(sink), C.byref(fl), E.stream_ptr(dev)))   # noqa: E731
+            best = None
+            for _ in range(3):
+                run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 3
+                best = ms if best is None else min(best, ms)
+            out[key] = fl.value / (best * 1e-3) / 1e12
+    return out
+
+
 def _pmc_traffic(key: str, shape: str, precision: str):
     """HBM/fabric bytes per launch from the last committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE, separate passes, collected by tools/gpu_pmc_ops.sh), if there is an entry for this kernel, shape and precision."""
@@ -118,12 +152,13 @@ def _pmc_traffic(key: str, shape: str, precision: str):
     return None
 
 
-def kernel_rooflines(precision: str, dev, B: int, iters: int = 20):
+def kernel_rooflines(precision: str, dev, B: int, iters: int = 20, peak_meas: dict | None = None):
     """Live timing of the five kernels that make up a DiT block (>= 95 % of sample() time), each launched through its C-ABI op entry
     point at the bench shape M = 2*B*N rows (cond + null branch), from a hipGraph, HIP events around `iters` launches.
     `share` = launches per block x average time / block total; the entry with the largest share is the dominant kernel."""
     from f5_tts_mlx_amd import engine as E
     lib = E.load_library()
+    peak_meas = peak_meas or mfma_peak_measured(precision, dev)
     M, D, FF, H = 2 * B * N_FRAMES, 1024, 2048, 16
     npad = (N_FRAMES + 63) // 64 * 64
     nseg = 3 if precision == "bf16x3" else 1
@@ -192,7 +227,9 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20):
             ms = _time_launches(fn, dev, iters)
             ach = flops / (ms * 1e-3) / 1e12
             out.append(dict(key=key, bound="mfma", kernel=name, shape=shape, avg_launch_ms=ms, achieved=ach, peak=BF16_PEAK_TFLOPS,
-                            unit="TFLOP/s", frac=ach / BF16_PEAK_TFLOPS, traffic=_pmc_traffic(key, shape, precision),
+                            unit="TFLOP/s", frac=ach / BF16_PEAK_TFLOPS, peak_measured_tflops=peak_meas["workload_like_operands"],
+                            peak_measured_constant_operands_tflops=peak_meas["constant_operands"],
+                            frac_of_measured=ach / peak_meas["workload_like_operands"], traffic=_pmc_traffic(key, shape, precision),
                             traffic_unit="bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", algorithmic_bytes=alg_bytes,
                             algorithmic_flops=flops))
     lib.f5_debug_set_op_q_premul(C.c_float(0.0))
@@ -347,6 +384,11 @@ def main():
                     help="c5 = BASELINE configs[4]: MX-fp8 block GEMMs + Vocos, 16-point midpoint, batch 32")
     ap.add_argument("--method", default="euler")
     ap.add_argument("--ode-points", type=int, default=ODE_POINTS)
+    ap.add_argument("--weights", default=os.environ.get("F5_WEIGHTS"),
+                    help="directory of a REAL checkpoint (model_v1.safetensors + vocab.txt, as F5TTS.from_pretrained reads it; "
+                         "default $F5_WEIGHTS): timed instead of the seeded synthetic weights (SURVEY.md section 8(d)).  The parity figure "
+                         "against the committed golden applies to the synthetic weights only and is omitted then; "
+                         "tools/real_checkpoint_parity.py measures the drift of a real checkpoint against the oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (batch 32, bf16, wave-to-wave RTF)")
@@ -426,12 +468,27 @@ def main():
         m = DiT.from_config(F5TTS_335M, precision=precision, device=device)
         return m
 
-    model = make_model(args.precision)
     weights = None
     t_w = time.perf_counter()
-    if rank == 0:
-        weights = synthetic_weights(F5TTS_335M, seed=42)
-        model.load_weights(weights)
+    real = args.weights is not None
+    if real:
+        # a real checkpoint: rank 0 goes through F5TTS.from_pretrained (cfm.py:404-520: upstream key renames, conv layouts, vocab), the
+        # other ranks build the same empty model and receive the arena by the broadcast below
+        if not os.path.isdir(args.weights):
+            raise SystemExit(f"--weights / $F5_WEIGHTS: {args.weights!r} is not a directory")
+        if rank == 0:
+            model = F5TTS.from_pretrained(args.weights, precision=args.precision, device=str(device), vocoder_name_or_path=None).transformer
+            from safetensors.numpy import load_file
+            from f5_tts_mlx_amd.weights import convert_upstream_weights
+            wf = load_file(os.path.join(args.weights, "model_v1.safetensors"))
+            weights = {k: np.asarray(v, np.float32) for k, v in (convert_upstream_weights(wf) if any(k.startswith("ema_model.") for k in wf) else wf).items()}
+        else:
+            model = make_model(args.precision)
+    else:
+        model = make_model(args.precision)
+        if rank == 0:
+            weights = synthetic_weights(F5TTS_335M, seed=42)
+            model.load_weights(weights)
     bcast_ms = None
     if dist_on:
         from f5_tts_mlx_amd.dist import broadcast_weights
@@ -476,10 +533,14 @@ def main():
             "metric": "mel_frames_per_sec", "value": head["value"], "unit": "mel-frames/s", "n_gpus": world, "gpus_arg": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_TEXT[args.precision],
-            "data": "synthetic (seeded random-init 335M weights, white-noise reference audio, random token ids)",
+            "data": ("REAL checkpoint " + os.path.abspath(args.weights) + ", synthetic inputs (white-noise reference audio, random token ids)") if real
+                    else "synthetic (seeded random-init 335M weights, white-noise reference audio, random token ids)",
             "config": {"workload": f"{'BASELINE configs[3] (32 utterances / GPU, weak scaling)' if (world > 1 and B == 32) else ('BASELINE configs[1]' if (world == 1 and B == 1) else ('BASELINE configs[2]' if (world == 1 and B == 32) else 'custom batch'))}: "
                                    f"F5-TTS 335M, {args.ode_points}-point {args.method} (={n_fwd} DiT forwards, CFG), "
                                    f"batch {B}/GPU x 10 s (N=937) utterances, hipGraph={not args.no_graph}"
+                                   + ("; f16 (IEEE half) MFMA operands IN PLACE OF BASELINE's bf16 -- same width and MFMA rate, three more "
+                                      "significand bits; plain bf16 fails the 1e-3 parity gate, see sub.b1_bf16" if args.precision == "f16" else "")
+                                   + ("; mxfp8 is a reduced-precision mode OUTSIDE the 1e-3 parity gate" if args.precision == "mxfp8" else "")
                                    + (", + Vocos vocoder (mel -> waveform) in the timed region" if args.vocoder else ""),
                        "global_batch": world * B, "seq_len": N_FRAMES, "parallelism": f"dp{world} (utterance sharding)"},
             "per_gpu_value": head["value"] / world,
@@ -489,7 +550,13 @@ def main():
             "weights_load_s": load_s, "weights_broadcast_ms": bcast_ms, "ranks_seen_by_rccl": ranks_in_group,
             "roofline": dominant, "roofline_kernels": kernels, "roofline_symbol_shares": sym,
         }
-        par = parity_against_golden(out[0], args) if not args.vocoder else None
+        if dominant.get("peak_measured_tflops"):
+            # the measured MFMA micro-benchmark peak next to the data-sheet figure every `frac` divides by
+            rec["peak_tflops_datasheet"] = BF16_PEAK_TFLOPS
+            rec["peak_measured_tflops"] = dominant["peak_measured_tflops"]
+            rec["peak_measured_constant_operands_tflops"] = dominant["peak_measured_constant_operands_tflops"]
+            rec["whole_path_frac_of_measured_peak"] = head["whole_path_tflops"] / (world * dominant["peak_measured_tflops"])
+        par = parity_against_golden(out[0], args) if not (args.vocoder or real) else None
         if par:
             rec.update(par)
 
@@ -523,7 +590,7 @@ def main():
                 el, o32 = timed_samples(f5, c32, t32, kw32, n32, 1, barrier)
                 s32 = summarize(el / n32 * 1e3, 32)
                 s32["timed_iterations"] = n32
-                p32 = parity_against_golden(o32[0], args)
+                p32 = parity_against_golden(o32[0], args) if not real else None
                 if p32:
                     s32.update(p32)
                 del c32, t32, y32, o32
@@ -533,6 +600,7 @@ def main():
                     k32, sym32 = kernel_rooflines(args.precision, device, 32, iters=10)
                     s32["roofline_kernels"] = k32
                     s32["roofline_symbol_shares"] = sym32
+                    s32["whole_path_frac_of_measured_peak"] = s32["whole_path_tflops"] / k32[0]["peak_measured_tflops"]
                     torch.cuda.empty_cache()
                 sub[f"b32_{args.precision}"] = s32
             # (3) the north-star's nominal dtype next to the parity-valid one
@@ -541,7 +609,7 @@ def main():
                 mb.load_weights(weights)
                 el, ob = timed_samples(F5TTS(transformer=mb), cond, text, kw, 3, 1, barrier)
                 sb = summarize(el / 3 * 1e3, B)
-                pb = parity_against_golden(ob[0], args)
+                pb = parity_against_golden(ob[0], args) if not real else None
                 if pb:
                     sb.update(pb)
                 sub["b1_bf16"] = sb

@@ -205,6 +205,7 @@ class F5TTS:
         y0: Optional[torch.Tensor] = None,       # extension: inject the initial noise (b, n, d)
         use_graph="auto",                        # extension: True / False / "auto" (graph from the 2nd call of a shape on)
         pad_to: Optional[int] = None,            # extension: padded length of a SHARD of a larger batch = that batch's max duration
+                                                 # (the key-padding mask of cfm.py:333-336 is then built even for a one-utterance shard)
     ) -> tuple[torch.Tensor, torch.Tensor]:
         self.eval()
         device = self.transformer.device
@@ -225,12 +226,15 @@ class F5TTS:
             assert text.shape[0] == batch
         if duration is None and self._duration_predictor is not None:
             duration = self.predict_duration(cond, text, speed)
+        max_duration_cap = int(max_duration)
         text, lens, duration, max_duration = prepare_lengths(text, cond_seq_len, batch, duration, lens, max_duration, method)
         if pad_to is not None:
             # GRN (convnext_v2.py:16) and the unmasked conv-pos-embed (dit.py:251) see the padding, so a shard of a batch only
             # reproduces its rows of the unsharded call when it is padded to the WHOLE batch's maximum (dist.shard_batch)
             if int(pad_to) < max_duration:
                 raise ValueError(f"pad_to={pad_to} is shorter than this shard's longest duration {max_duration}")
+            if int(pad_to) > max_duration_cap:       # the cap prepare_lengths enforces on durations (cfm.py:318) holds for the padding too
+                raise ValueError(f"pad_to={pad_to} exceeds max_duration={max_duration_cap}")
             max_duration = int(pad_to)
         cond = cond.to(device, torch.float32)
 
@@ -255,7 +259,7 @@ class F5TTS:
 
         out, trajectory = self.transformer.engine.sample(
             text.to(device).contiguous(), cond_p, lens.tolist(), duration.tolist(), y0, t, method=method,
-            cfg_strength=float(cfg_strength), use_mask=batch > 1, use_graph=use_graph, return_trajectory=True)
+            cfg_strength=float(cfg_strength), use_mask=(batch > 1 or pad_to is not None), use_graph=use_graph, return_trajectory=True)
 
         if exists(self._vocoder):
             out = self._vocoder(out)

@@ -1004,6 +1004,451 @@ __global__ __launch_bounds__(256, 2) void f5_attn2f_kernel(F5AttnArgs p) {
     }
 }
 
+// =================================================================================================
+// v2p (large grids, q pre-multiplied): v2f's arithmetic, software-pipelined INSIDE the wave, ONE wave per SIMD.
+//
+// A wave's VALU / LDS instructions overlap matrix work only when they sit between the MFMAs of the SAME instruction stream: a
+// 32-cycle v_mfma_f32_32x32x16 leaves ~8 issue slots, of which ~5 can be filled for free (MI355X_MICROARCH.md, "one wave per SIMD");
+// two co-resident waves do not do that for each other (tools/probes/coissue.hip).  v2f runs S = K Q^T -> exp -> O += V^T P one after
+// the other, so per 64-key tile its 32 MFMAs (1 024 cycles) and ~160 VALU + 16 LDS reads ADD: 2 720 cycles per wave tile.  The
+// round-2 attempt at in-wave pipelining (v5, lab) kept 32 queries per wave -- one LDS fragment per MFMA -- and the per-tile maximum:
+// 9+ fillers per MFMA, slower.  With v2f's softmax (no tile maximum, -m_ref as the C operand of the first QK^T MFMA, scores already
+// in exp2 units) and 64 queries per wave (every K / V^T fragment feeds TWO MFMAs) a 64-key tile is 32 MFMAs next to
+//     64 v_exp_f32 + 64 v_add_f32 + 32 v_cvt_pk + 16 ds_read_b128  =  5.5 fillers per MFMA.
+// The pipeline step is HALF a tile (32 keys x 64 queries).  Half-step (j, kb) issues, as ONE stream of independent work,
+//     MFMA:  S(next half) = K Q^T - m_ref      (8: the other key block of tile j, or key block 0 of tile j+1)
+//            O^T += V^T(prev half) P(prev half) (8: P packed in the previous half-step)
+//     VALU:  P(j, kb) = exp2(S(j, kb)), row sums (S computed in the previous half-step)
+// as 16 half-slots of {2 exp, 2 add + 1 cvt_pk of the previous pair, 1 MFMA, every other one a fragment read three fragments ahead},
+// pinned with sched_barrier.  S and P are double-buffered per key block (static roles: block 0 <-> buffer A, block 1 <-> buffer B).
+//
+// Registers.  VALU instructions cannot read the accumulator half of the register file, an MFMA's C and D must sit in the same
+// half, and left to itself the compiler parks MFMA results in AGPRs as soon as a kernel needs more than 256 registers and copies
+// them back one v_accvgpr_read at a time (the first build of this kernel: 130 reads + 226 writes per tile, 362 spilled registers).
+// So the MFMAs are inline asm with the register class in the constraint: O^T (64), Q^T (32) and the K / V^T fragments (16) live in
+// AGPRs ("a"); the two S buffers (64), -m_ref (32) and the two P buffers (32) in VGPRs ("v").  An asm MFMA is opaque to the
+// compiler's hazard padding; the places where an MFMA result or operand is touched by another instruction class within the hazard
+// window are padded by hand (A2P_PAD, s_nop 1).
+//
+// LDS: a K ring and a V^T ring of 4 stages each (2 x 32 KB), tile t in stage t & 3.  Iteration j reads K(j) (key block 1), K(j+1)
+// (key block 0), V^T(j-1) (second half) and V^T(j) (first half); after its barrier it issues K(j+3) and V^T(j+2) (global_load_lds,
+// uniform base + 32-bit lane offset), and the counted wait at its top lets the previous iteration's group stay in flight: every
+// tile has two iterations to arrive (the first build issued one tile ahead behind vmcnt(0): each iteration then waited out a full
+// HBM / L2 round trip, 4 800 cycles per tile).  One barrier per tile.  The tile loop is unrolled four times so that every fragment
+// address is one loop-invariant VGPR plus an immediate.
+// The slow path (a row sum above 2^14: some score far above the reference point) runs at the END of the half-step: S(j, kb) is
+// still in registers (the exponentials are not taken in place), so the reference point moves by delta = max(S) and O, l, -m_ref,
+// the already computed next S and this P follow.  The first half tile takes its true maximum in the prologue.  Same layouts
+// (permuted K rows, XOR-swizzled 128-byte rows, P fed from the S accumulators) and the same results as v2f up to the order of the
+// row-sum additions and the reference point of the rows.
+// =================================================================================================
+#if F5_F16
+#define A2P_MFMA_OP "v_mfma_f32_32x32x16_f16"
+#else
+#define A2P_MFMA_OP "v_mfma_f32_32x32x16_bf16"
+#endif
+// 20 wait states: more than the 12 an 8-pass MFMA needs before another instruction class may touch its result
+#define A2P_PAD "s_nop 15\n\ts_nop 3"
+#define ATTN2P_TILE (64 * 64)
+// The compiler may place a register copy (v_mov / v_accvgpr_mov / v_accvgpr_write, or the v_cvt_pk that produced a P word) directly in
+// front of an asm statement; a VALU result needs 2 wait states before an MFMA may read it and the hazard recogniser does not look
+// into asm (first build: stale O accumulators and P words wherever such a copy sat in front of an MFMA).  Every asm MFMA therefore
+// opens with its own two states.
+#define A2P_GUARD "s_nop 1\n\t"
+// d (VGPRs) = a * b + c: first MFMA of a score block, c = -m_ref (VGPRs: C and D share one half of the register file)
+template <int ABL = 0>
+__device__ __forceinline__ void a2p_mfma_first(f32x16& d, const op16x8& a, const op16x8& b, const f32x16& c) {
+    if (ABL == 5) { asm volatile("" : "=v"(d) : "a"(a), "a"(b), "v"(c)); return; }
+    if (ABL == 6 || ABL == 8) asm volatile(A2P_MFMA_OP " %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
+    else asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
+}
+// d (VGPRs) = a * b (C = inline constant 0)
+__device__ __forceinline__ void a2p_mfma_first0(f32x16& d, const op16x8& a, const op16x8& b) {
+    asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b));
+}
+// d (VGPRs) += a * b
+template <int ABL = 0>
+__device__ __forceinline__ void a2p_mfma_s(f32x16& d, const op16x8& a, const op16x8& b) {
+    if (ABL == 5) { asm volatile("" : "+v"(d) : "a"(a), "a"(b)); return; }
+    if (ABL == 6 || ABL == 8) asm volatile(A2P_MFMA_OP " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+    else asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+}
+// d (AGPRs) += a * b, b = P (VGPRs)
+template <int ABL = 0>
+__device__ __forceinline__ void a2p_mfma_o(f32x16& d, const op16x8& a, const op16x8& b) {
+    if (ABL == 5) { asm volatile("" : "+a"(d) : "a"(a), "v"(b)); return; }
+    if (ABL == 6 || ABL == 8) asm volatile(A2P_MFMA_OP " %0, %1, %2, %0" : "+a"(d) : "a"(a), "v"(b));
+    else asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, %0" : "+a"(d) : "a"(a), "v"(b));
+}
+// a wave-uniform pointer the compiler can see is uniform (SGPR pair): global_load_lds then uses the "SGPR base + 32-bit VGPR offset" form
+__device__ __forceinline__ const char* attn_uniform_ptr(const void* ptr) {
+    const uint64_t u = reinterpret_cast<uint64_t>(ptr);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+// One half-step.  s_cur: the scores of this 32-key block (both query blocks); s_nxt: the scores of the next block, taken from key
+// block KBN of the K tile in ring stage ST_K; p_prev: P of the previous block = key block KBP of the tile whose V^T sits in stage
+// ST_V; nvalid (MASK instantiations = last tile only): keys of THIS block that exist (>= 32: all).  pk / pv: LDS addresses of this
+// lane's K / V^T fragments inside stage 0 (loop invariant; stage, key / d block are immediates).
+// N_*: the same four parameters of the half-step that FOLLOWS (its first three fragments are requested at the end of this one)
+template <int ABL, int ST_K, int KBN, int ST_V, int KBP, int N_ST_K, int N_KBN, int N_ST_V, int N_KBP>
+__device__ __forceinline__ void attn2p_half(const op16_t* const (&pk)[4], const op16_t* const (&pv)[4], const op16x8 (&qf)[2][4],
+                                            op16x8 (&fr)[4], f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], f32x16 (&o)[2][2], f32x16 (&mneg)[2],
+                                            const uint32_t (&p_prev)[2][8], uint32_t (&p_cur)[2][8], float (&l_run)[2], int hi,
+                                            int nvalid) {
+    constexpr int NF = 8;                                    // LDS fragments of this half-step; each feeds two MFMAs (query blocks 0, 1)
+    constexpr bool HAS_QK = true;
+    constexpr float SUM_LIMIT = 16384.0f;
+    if (__builtin_expect(nvalid < 32, 0)) {                  // wave-uniform; only the last tile of a sequence can be partial
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (16 * hi + r >= nvalid) s_cur[qb][r] = -INFINITY;
+    }
+    // fragment f (compile-time after unrolling: lane address + immediate).  K and V^T fragments ALTERNATE -- K step 0, V^T piece 0,
+    // K step 1, ... -- so that an MFMA and the next one on the same accumulator are four MFMAs apart in both chains (S: two query
+    // blocks x K steps; O: two query blocks x two d blocks); f >= 8 = fragment f - 8 of the next half-step
+    auto frag = [&](int f) -> op16x8 {
+        const bool nx = f >= NF;
+        const int ff = nx ? f - NF : f, g = ff >> 1;
+        if ((ff & 1) == 0) return *reinterpret_cast<const op16x8*>(pk[g] + (nx ? N_ST_K : ST_K) * ATTN2P_TILE + (nx ? N_KBN : KBN) * 2048);   // k-step g
+        return *reinterpret_cast<const op16x8*>(pv[2 * (nx ? N_KBP : KBP) + (g >> 1)] + (4 + (nx ? N_ST_V : ST_V)) * ATTN2P_TILE + (g & 1) * 2048);   // (16-key step g >> 1, d block g & 1)
+    };
+    float sa[2] = {0.0f, 0.0f}, sb[2] = {0.0f, 0.0f};        // two partial row sums per query block (even / odd key of a pair)
+    float y0 = 0.0f, y1 = 0.0f;                              // exponentials of the previous pair (summed / packed one half-slot later)
+#pragma unroll
+    for (int h = 0; h < 2 * NF; ++h) {
+        const int f = h >> 1, qb = h & 1;
+        // three fragments ahead, into the slot of fragment f - 1 (both of its MFMAs are out); the last three requests are the first
+        // three fragments of the NEXT half-step, which therefore starts without an exposed LDS round trip
+        if (ABL != 3 && qb == 0) fr[(f + 3) & 3] = frag(f + 3);
+        if (ABL != 2) {
+            const int pr = h;                                // pair (query block, i): scores 2i, 2i + 1 of s_cur[.]
+            const int pq = pr >> 3, pi = pr & 7;
+            float x0 = ABL == 1 ? s_cur[pq][2 * pi] : __builtin_amdgcn_exp2f(s_cur[pq][2 * pi]);
+            float x1 = ABL == 1 ? s_cur[pq][2 * pi + 1] : __builtin_amdgcn_exp2f(s_cur[pq][2 * pi + 1]);
+            asm volatile("" : "+v"(x0), "+v"(x1));
+            if (pr > 0) {
+                const int qq = (pr - 1) >> 3, w = (pr - 1) & 7;
+                sa[qq] += y0;
+                sb[qq] += y1;
+                p_cur[qq][w] = f5_pack2_bounded(y0, y1);
+                asm volatile("" : "+v"(sa[qq]), "+v"(sb[qq]), "+v"(p_cur[qq][w]));
+            }
+            y0 = x0;
+            y1 = x1;
+        }
+        if ((f & 1) == 0) {
+            const int ks = f >> 1;
+            if (ks == 0) a2p_mfma_first<ABL>(s_nxt[qb], fr[f & 3], qf[qb][ks], mneg[qb]);
+            else a2p_mfma_s<ABL>(s_nxt[qb], fr[f & 3], qf[qb][ks]);
+        } else {
+            const int g = f >> 1, sp = g >> 1, db = g & 1;
+            const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{p_prev[qb][4 * sp], p_prev[qb][4 * sp + 1], p_prev[qb][4 * sp + 2],
+                                                               p_prev[qb][4 * sp + 3]});
+            a2p_mfma_o<ABL>(o[qb][db], fr[f & 3], pb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    sa[1] += y0;
+    sb[1] += y1;
+    p_cur[1][7] = f5_pack2_bounded(y0, y1);
+    float psum[2] = {sa[0] + sb[0], sa[1] + sb[1]};
+    if ((ABL == 0 || ABL == 8) && __builtin_expect(__any(!(psum[0] <= SUM_LIMIT) || !(psum[1] <= SUM_LIMIT)) != 0, 0)) {
+        // wave-uniform and rare: some score of this block lies more than 14 (exp2 units) above the reference point.  Move the
+        // reference point of every row to max(old, this block's maximum): O and l shrink by alpha, -m_ref and the scores of the next
+        // block (already computed against the old point) shift by delta, the block's P is taken again.
+        asm volatile(A2P_PAD : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]));     // the last MFMAs of the half-step wrote O
+        if (HAS_QK) asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]));                           // ... issued after the S MFMAs: covered
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float tmax = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s_cur[qb][r]);
+            const float delta = fmaxf(tmax, __shfl_xor(tmax, 32, 64));       // >= 0, in exp2 units
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            l_run[qb] *= alpha;
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o[qb][0][e] *= alpha;
+                o[qb][1][e] *= alpha;
+                mneg[qb][e] -= delta;
+                if (HAS_QK) s_nxt[qb][e] -= delta;
+            }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float e0 = __builtin_amdgcn_exp2f(s_cur[qb][2 * w] - delta);
+                const float e1 = __builtin_amdgcn_exp2f(s_cur[qb][2 * w + 1] - delta);
+                s0 += e0;
+                s1 += e1;
+                p_cur[qb][w] = f5_pack2_bounded(e0, e1);
+            }
+            psum[qb] = s0 + s1;
+        }
+        // the rewritten accumulators / -m_ref are MFMA operands of the next half-step: a VALU result needs 2 states
+        asm volatile("s_nop 1" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]), "+v"(mneg[0]), "+v"(mneg[1]));
+    }
+    l_run[0] += psum[0];
+    l_run[1] += psum[1];
+}
+
+template <int ABL>
+__global__ __launch_bounds__(256, 1) void f5_attn2p_kernel(F5AttnArgs p) {
+    constexpr int TILE = 64 * 64;
+    __shared__ __attribute__((aligned(16))) op16_t smem[8 * TILE];       // K ring [4][64*64] then V^T ring [4][64*64]: 64 KB
+
+    asm volatile("" ::"s"(p.qk[0]), "s"(p.vt[0]), "s"(p.out[0]), "s"(p.kv_len), "s"(p.B), "s"(p.H), "s"(p.seq_len), "s"(p.npad), "s"(p.ldqk),
+                 "s"(p.ldo), "s"(p.dmodel), "s"(p.out8));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lq = lane & 31;
+    int bh, qblk;
+    if (!attn_block_map(p, 256, bh, qblk)) return;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qblk * 256 + wave * 64;
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.seq_len;
+    const int T = (kvlen + 63) >> 6;
+    const size_t rowbase = (size_t)b * p.seq_len;
+    const bool live = q0 < p.seq_len;                       // a wave entirely past the sequence only stages tiles and keeps the barriers
+
+    op16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = q0 + qb * 32 + lq;
+        if (qr > p.seq_len - 1) qr = p.seq_len - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[qb][ks] = *reinterpret_cast<const op16x8*>(p.qk[0] + (rowbase + qr) * p.ldqk + h * 64 + ks * 16 + hi * 8);
+    }
+    // staging: 2 16-byte chunks of K and of V^T per thread per tile (thread q_ = i * 256 + tid fills LDS chunk q_ of the tile image);
+    // source = wave-uniform tile base (SGPR pair) + a loop-invariant 32-bit lane offset
+    const char* kbase = attn_uniform_ptr(p.qk[0] + rowbase * p.ldqk + p.dmodel + h * 64);     // key 0 of this head
+    const char* vbase = attn_uniform_ptr(p.vt[0] + (size_t)bh * 64 * p.npad);                  // key 0, d 0
+    const uint32_t kstep = (uint32_t)(64 * p.ldqk) * 2u;                                      // bytes per tile
+    uint32_t koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q_ = i * 256 + tid;
+        const int srow = q_ >> 3;
+        const int schunk = (q_ & 7) ^ ((srow >> 1) & 7);
+        koff[i] = ((uint32_t)attn_kperm(srow) * (uint32_t)p.ldqk + schunk * 8) * 2u;
+        voff[i] = ((uint32_t)srow * (uint32_t)p.npad + schunk * 8) * 2u;
+    }
+    const int ldsw = wave * 64 * 8;                          // this wave's 1 KB piece of a 4 KB staging instruction (elements)
+#define A2P_ISSUE_K(t_)                          /* K tile t_ -> K ring stage t_ & 3 */                   \
+    {                                                                                                        \
+        op16_t* dst_ = smem + ((t_) & 3) * TILE + ldsw;                                                      \
+        const char* ks_ = kbase + (size_t)(t_) * kstep;                                                      \
+        const bool tail_ = ((t_) * 64 + 63) > p.seq_len - 1;                                                 \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            uint32_t ko_ = koff[i];                                                                          \
+            if (tail_) {                                     /* rows past the sequence: re-read its last key */ \
+                const int q_ = i * 256 + tid, srow_ = q_ >> 3;                                               \
+                int key_ = (t_) * 64 + attn_kperm(srow_);                                                    \
+                if (key_ > p.seq_len - 1) key_ = p.seq_len - 1;                                              \
+                ko_ = ((uint32_t)(key_ - (t_) * 64) * (uint32_t)p.ldqk + ((q_ & 7) ^ ((srow_ >> 1) & 7)) * 8) * 2u; \
+            }                                                                                                \
+            attn_glds16(reinterpret_cast<const op16_t*>(ks_ + ko_), dst_ + i * 2048);                        \
+        }                                                                                                    \
+    }
+#define A2P_ISSUE_V(t_)                          /* V^T tile t_ -> V ring stage t_ & 3 */                 \
+    {                                                                                                        \
+        op16_t* dst_ = smem + (4 + ((t_) & 3)) * TILE + ldsw;                                                \
+        const char* vs_ = vbase + (size_t)(t_) * 128;                                                        \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+            attn_glds16(reinterpret_cast<const op16_t*>(vs_ + voff[i]), dst_ + i * 2048);                    \
+    }
+    // issue group of iteration j (after its barrier): K(j+3) and V^T(j+2); the wait at the top of iteration j lets the group of
+    // iteration j-1 -- K(j+2), V^T(j+1), 2 instructions each where the tile exists -- stay in flight
+#define A2P_ISSUE_GROUP(j_)                                  \
+    {                                                        \
+        if ((j_) + 3 < T) A2P_ISSUE_K((j_) + 3);             \
+        if ((j_) + 2 < T) A2P_ISSUE_V((j_) + 2);             \
+    }
+#define A2P_WAIT_TOP(j_)                                     \
+    if ((j_) + 2 < T) {                                      \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     \
+    } else if ((j_) + 1 < T) {                               \
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     \
+    } else {                                                 \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+    }
+#define A2P_BARRIER()                              \
+    {                                              \
+        asm volatile("" ::: "memory");             \
+        __builtin_amdgcn_s_barrier();              \
+        asm volatile("" ::: "memory");             \
+    }
+    // this lane's fragment addresses inside a 64 x 64 tile image of stage 0: lane part of attn_swz; the key / d block adds 32 rows
+    const op16_t* pk[4];
+    const op16_t* pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pk[i] = smem + lq * 64 + (((i * 2 + hi) ^ ((lq >> 1) & 7)) << 3);                                  // QK^T k-step i: chunk 2 i + hi
+        pv[i] = smem + lq * 64 + (((4 * (i >> 1) + 2 * hi + (i & 1)) ^ ((lq >> 1) & 7)) << 3);             // 16-key step i of the tile
+    }
+
+    // ---- prologue: K(0), V^T(0), K(1), then the group "of iteration -1": K(2), V^T(1).  P(-1, 1) = 0 multiplies the V^T stage of
+    // "tile -1" (stage 3) in the first half-step: that stage is zeroed here (uninitialised LDS may hold NaN patterns).
+    A2P_ISSUE_K(0);
+    A2P_ISSUE_V(0);
+    if (T > 1) A2P_ISSUE_K(1);
+    if (T > 2) A2P_ISSUE_K(2);
+    if (T > 1) A2P_ISSUE_V(1);
+    {
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(smem + 7 * TILE + tid * 8) = z4;
+        *reinterpret_cast<u32x4*>(smem + 7 * TILE + 2048 + tid * 8) = z4;
+    }
+    // Q^T fragments: waited for here (a use the compiler sees, as ATTN_PIN_Q) and from here on accumulator-file values -- every
+    // MFMA takes them as "a" operands; defined as VGPR values they would be copied (4 v_accvgpr_write) in front of every use
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+a"(qf[qb][ks]));
+    // K(0) has landed (the oldest 2 of the 4 + 2 [T > 1] + 4 [T > 2: 2, else V^T(1) only] requests)
+    if (T > 2) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (T > 1) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    A2P_BARRIER();
+    if (!live) {                                             // same barriers, same staging, no arithmetic
+        for (int j = 0; j < T; ++j) {
+            A2P_WAIT_TOP(j);
+            A2P_BARRIER();
+            A2P_ISSUE_GROUP(j);
+        }
+        return;
+    }
+
+    f32x16 o[2][2], mneg[2], s_a[2], s_b[2];                 // s_a / p_a: key block 0 of a tile, s_b / p_b: key block 1
+    uint32_t p_a[2][8], p_b[2][8];
+    op16x8 fr[4];                                            // LDS fragment ring, carried across half-steps (requested three fragments ahead)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            o[qb][0][e] = 0.0f;
+            o[qb][1][e] = 0.0f;
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) p_b[qb][w] = 0u;         // P(-1, 1)
+    }
+    float l_run[2] = {0.0f, 0.0f};
+
+    // ---- the reference point: the true maximum of S(0, block 0) per row; s_a = S(0, 0) - m_ref enters the loop like every other block
+    {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const op16x8 a = *reinterpret_cast<const op16x8*>(pk[ks]);
+            if (ks == 0) {
+                a2p_mfma_first0(s_a[0], a, qf[0][ks]);
+                a2p_mfma_first0(s_a[1], a, qf[1][ks]);
+            } else {
+                a2p_mfma_s(s_a[0], a, qf[0][ks]);
+                a2p_mfma_s(s_a[1], a, qf[1][ks]);
+            }
+        }
+        asm volatile(A2P_PAD : "+v"(s_a[0]), "+v"(s_a[1]));
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, (16 * hi + r < kvlen) ? s_a[qb][r] : -INFINITY);
+            const float m0 = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                mneg[qb][e] = -m0;
+                s_a[qb][e] -= m0;
+            }
+        }
+        asm volatile("s_nop 1" : "+v"(mneg[0]), "+v"(mneg[1]));
+        // the first three fragments of half-step (0, 0): K(0) block 1 step 0, V^T(-1) [the zeroed stage 3] piece 0, K(0) block 1 step 1
+        fr[0] = *reinterpret_cast<const op16x8*>(pk[0] + 2048);
+        fr[1] = *reinterpret_cast<const op16x8*>(pv[2] + 7 * TILE);
+        fr[2] = *reinterpret_cast<const op16x8*>(pk[1] + 2048);
+        asm volatile("" : "+a"(fr[0]), "+a"(fr[1]), "+a"(fr[2]));      // accumulator-file values on every path into the loop (else: copies per half-step)
+    }
+
+    // ---- tiles.  Tile j = 4 g + PH (PH compile-time: four tiles per loop trip, a tile past the end is skipped by a scalar branch):
+    //   TOP:    K(j+1) and V^T(j) have landed (counted wait), barrier, issue K(j+3) and V^T(j+2)
+    //   (j, 0): exp of S(j, 0) in s_a -> p_a;  S(j, 1) -> s_b from K stage PH;            O += V^T(j-1, 1) p_b, V stage PH - 1
+    //   (j, 1): exp of S(j, 1) in s_b -> p_b;  S(j+1, 0) -> s_a from K stage PH + 1;      O += V^T(j, 0) p_a,   V stage PH
+    // Every tile runs the same code: keys past kvlen (last tile only) are masked under a wave-uniform branch, and the last tile's
+    // second half-step computes an S(T, 0) nobody reads (K stage PH + 1 then holds an older tile or nothing: finite or not, unused).
+    // After the loop: O += V^T(T-1, 1) p_b.
+#define A2P_STEP(PH)                                                                                                    \
+    if (j < T) {                                                                                                        \
+        if (ABL != 4) {                                                                                                 \
+            A2P_WAIT_TOP(j)                                                                                             \
+            A2P_BARRIER();                                                                                              \
+            A2P_ISSUE_GROUP(j)                                                                                          \
+        }                                                                                                               \
+        const int nv_ = kvlen - j * 64;                                                                                 \
+        attn2p_half<ABL, (PH), 1, ((PH) + 3) & 3, 1, ((PH) + 1) & 3, 0, (PH), 0>(pk, pv, qf, fr, s_a, s_b, o, mneg, p_b, p_a, l_run, hi, nv_);          \
+        attn2p_half<ABL, ((PH) + 1) & 3, 0, (PH), 0, ((PH) + 1) & 3, 1, (PH), 1>(pk, pv, qf, fr, s_b, s_a, o, mneg, p_a, p_b, l_run, hi, nv_ - 32);     \
+        ++j;                                                                                                            \
+    }
+    {
+        int j = 0;
+        for (int g = (T + 3) >> 2; g > 0; --g) {
+            A2P_STEP(0)
+            A2P_STEP(1)
+            A2P_STEP(2)
+            A2P_STEP(3)
+        }
+    }
+#undef A2P_STEP
+    // O^T += V^T(T-1, 1) P(T-1, 1): the V ring stage of the last tile is a run-time value here
+    {
+        const int stv = ((T - 1) & 3) * TILE;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const op16x8 a = *reinterpret_cast<const op16x8*>(pv[2 + sp] + 4 * TILE + stv + db * 2048);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{p_b[qb][4 * sp], p_b[qb][4 * sp + 1], p_b[qb][4 * sp + 2], p_b[qb][4 * sp + 3]});
+                    a2p_mfma_o(o[qb][db], a, pb);
+                }
+            }
+    }
+#undef A2P_BARRIER
+#undef A2P_WAIT_TOP
+#undef A2P_ISSUE_GROUP
+#undef A2P_ISSUE_V
+#undef A2P_ISSUE_K
+    asm volatile(A2P_PAD : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]));
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qr = q0 + qb * 32 + lq;
+        if (p.out8) {
+            if (qr < p.seq_len) attn_store_f8(p, o[qb], inv, rowbase + qr, h, hi);
+        } else if (qr < p.seq_len) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d = db * 32 + 8 * rg + 4 * hi;
+                    const float v0 = o[qb][db][rg * 4 + 0] * inv, v1 = o[qb][db][rg * 4 + 1] * inv;
+                    const float v2 = o[qb][db][rg * 4 + 2] * inv, v3 = o[qb][db][rg * 4 + 3] * inv;
+                    const size_t off = (rowbase + qr) * p.ldo + h * 64 + d;
+                    *reinterpret_cast<u32x2*>(p.out[0] + off) = u32x2{f5_pack2_bounded(v0, v1), f5_pack2_bounded(v2, v3)};
+                }
+        }
+    }
+}
+
 #if F5_LAB   // role-split attention (round 3): measured 7-12 % slower than v2f (profiles/r03/attention_role_split_ab.txt)
 // =================================================================================================
 // v2r (large grids, round 3): v2f's arithmetic under a ROLE-SPLIT schedule.  In v2f two waves of different workgroups share a
@@ -2083,6 +2528,7 @@ static constexpr int f5_attn_version = 2, f5_attn_variant = 0, f5_attn_ablation 
 // test hooks that choose among the SHIPPED kernels (the shape heuristics below decide otherwise)
 int f5_attn_wide = -1;     // -1 auto (>= 512 workgroups of 256 queries), 0 off, 1 force: 256-query workgroups, two query blocks per wave; lab: 2 = role-split v2r
 int f5_attn_kvsplit = -1;  // -1 auto, 1 / 2 / 4 = force the in-workgroup KV split
+int f5_attn_pipe = 0;      // process default of F5AttnArgs::pipe (-1): 1 = in-wave software-pipelined v2p (one wave per SIMD), 0 = v2f
 
 // 1-D XCD-aware grid (attn_block_map); the lab build's f5_attn_variant bit 2 asks for the plain 2-D numbering
 static dim3 attn_grid(const F5AttnArgs& a, int qrows) {
@@ -2158,7 +2604,22 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
             return 0;
         }
 #endif
-        if (a.q_prescaled) hipLaunchKernelGGL(f5_attn2f_kernel<true>, gw, dim3(256), 0, stream, a);
+        // f5_attn_pipe: 1 = the in-wave software-pipelined kernel (v2p, one wave per SIMD), 0 = v2f; q must be pre-multiplied
+        const int pipe_ = a.pipe < 0 ? f5_attn_pipe : a.pipe;
+        if (pipe_ && a.q_prescaled) {
+            switch (pipe_) {                                   // 11 .. 16: timing-only ablations of v2p (results are wrong)
+                case 11: hipLaunchKernelGGL(f5_attn2p_kernel<1>, gw, dim3(256), 0, stream, a); break;
+                case 12: hipLaunchKernelGGL(f5_attn2p_kernel<2>, gw, dim3(256), 0, stream, a); break;
+                case 13: hipLaunchKernelGGL(f5_attn2p_kernel<3>, gw, dim3(256), 0, stream, a); break;
+                case 14: hipLaunchKernelGGL(f5_attn2p_kernel<4>, gw, dim3(256), 0, stream, a); break;
+                case 15: hipLaunchKernelGGL(f5_attn2p_kernel<5>, gw, dim3(256), 0, stream, a); break;
+                case 16: hipLaunchKernelGGL(f5_attn2p_kernel<6>, gw, dim3(256), 0, stream, a); break;
+                case 17: hipLaunchKernelGGL(f5_attn2p_kernel<7>, gw, dim3(256), 0, stream, a); break;    // guards, no slow-path check
+                case 18: hipLaunchKernelGGL(f5_attn2p_kernel<8>, gw, dim3(256), 0, stream, a); break;    // slow-path check, no guards
+                default: hipLaunchKernelGGL(f5_attn2p_kernel<0>, gw, dim3(256), 0, stream, a); break;
+            }
+        }
+        else if (a.q_prescaled) hipLaunchKernelGGL(f5_attn2f_kernel<true>, gw, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(f5_attn2f_kernel<false>, gw, dim3(256), 0, stream, a);
         F5_LAUNCH_CHECK();
         return 0;

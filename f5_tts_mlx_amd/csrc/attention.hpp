@@ -25,6 +25,7 @@ struct F5AttnArgs {
     int hp;               // 0 bf16, 1 bf16x3
     float scale;
     int q_prescaled;      // 1: q was multiplied by scale * log2(e) before rounding (QKV epilogue, F5GemmArgs::q_premul): scores are in exp2 units
+    int pipe;             // large grids, q pre-scaled: -1 = the process default (f5_debug_set_attn_pipe), 1 = in-wave software-pipelined kernel (v2p), 0 = v2f
     // MX-fp8 output (bf16 kernels only): e4m3 [B*seq_len][ldo8] + E8M0 [B*seq_len][dmodel/32] (one scale per head half)
     uint8_t* out8;
     uint8_t* out8s;

@@ -79,6 +79,7 @@ struct F5Options {
     int qkv_tr = 1;       // 256x256 QKV kernel: q / k tiles accumulated transposed (pair-major rotation tables)
     int fuse_ln = 0;      // LN-modulate fused behind the small-tile residual GEMMs (measured slower, profiles/r02/ln_fusion_ab.txt)
     int gemm_flags = 0;   // F5GemmArgs::debug_flags of this engine's GEMM launches
+    int attn_pipe = -1;   // large-grid attention: -1 = process default (f5_debug_set_attn_pipe), 0 = v2f, 1 = v2p (in-wave software pipeline)
 };
 static F5Options g_default_options;
 // bumped by every process-wide launch knob change (f5_debug_set_*): part of the graph key, so a cached hipGraph captured under other
@@ -313,8 +314,9 @@ extern "C" int f5_engine_set_option(f5_engine* e, const char* name, int value) {
     else if (n == "qkv_transposed") e->opt.qkv_tr = value ? 1 : 0;
     else if (n == "ln_fusion") e->opt.fuse_ln = value ? 1 : 0;
     else if (n == "gemm_flags") e->opt.gemm_flags = value;
+    else if (n == "attn_pipe") e->opt.attn_pipe = value < 0 ? -1 : (value ? 1 : 0);
     else {
-        f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags)", name);
+        f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags, attn_pipe)", name);
         return 2;
     }
     return 0;
@@ -326,6 +328,7 @@ extern "C" int f5_engine_get_option(f5_engine* e, const char* name, int* value) 
     else if (n == "qkv_transposed") *value = e->opt.qkv_tr;
     else if (n == "ln_fusion") *value = e->opt.fuse_ln;
     else if (n == "gemm_flags") *value = e->opt.gemm_flags;
+    else if (n == "attn_pipe") *value = e->opt.attn_pipe;
     else {
         f5_set_error("unknown engine option %s", name);
         return 2;
@@ -743,6 +746,7 @@ static int run_dit(const Ctx& c, int j) {
         at.hp = 0;
         at.scale = 1.0f / sqrtf((float)cf.dim_head);
         at.q_prescaled = qpre != 0.0f;
+        at.pipe = e->opt.attn_pipe;
         RC(K.attention(at, s));
 
         F5GemmArgs go = f8args(c.p<uint8_t>(w.ao8), c.p<uint8_t>(w.ao8s), D, bw.o8, D, D, c.a<float>(bw.bo));
@@ -824,6 +828,7 @@ static int run_dit(const Ctx& c, int j) {
         at.hp = e->np == 2;
         at.scale = 1.0f / sqrtf((float)cf.dim_head);
         at.q_prescaled = qpre != 0.0f;
+        at.pipe = e->opt.attn_pipe;
         RC(K.attention(at, s));
 
         F5GemmArgs go = gemm_base(c, c.pb(w.ao, 0), c.pb(w.ao, 1), D, bw.o, M, D, D, c.a<float>(bw.bo));
@@ -1022,8 +1027,8 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, g_knob_epoch, a->workspace);
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, g_knob_epoch, a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
         // a text-to-speech service sees a new (N, nt) on almost every call and capture + instantiate of ~5000 nodes costs more
@@ -1129,6 +1134,7 @@ F5_DECL_KNOB(f5_convpos_tps)
 F5_DECL_KNOB(f5_convpos_xcd_map)
 F5_DECL_KNOB(f5_attn_wide)
 F5_DECL_KNOB(f5_attn_kvsplit)
+F5_DECL_KNOB(f5_attn_pipe)
 F5_DECL_KNOB(f5_gemm_ring_default)
 F5_DECL_KNOB(f5_gemm_order)
 F5_DECL_KNOB(f5_gemm_nband)
@@ -1175,6 +1181,11 @@ extern "C" int f5_debug_set_attn_wide(int v) {
     F5_REQUIRE(v >= -1 && v <= 1, "attention wide-workgroup switch must be -1 (auto), 0 or 1 (256-query workgroups)");
 #endif
     F5_SET_BOTH(f5_attn_wide, v);
+    return 0;
+}
+extern "C" int f5_debug_set_attn_pipe(int v) {
+    F5_REQUIRE(v == 0 || v == 1 || (v >= 11 && v <= 18), "attention pipelining switch must be 0 (v2f) or 1 (v2p: in-wave software pipeline, one wave per SIMD); 11-16 = timing ablations");
+    F5_SET_BOTH(f5_attn_pipe, v);
     return 0;
 }
 extern "C" int f5_debug_set_attn_kvsplit(int v) {
@@ -1370,6 +1381,7 @@ extern "C" int f5_op_attention(const void* qk_hi, const void* qk_lo, const void*
     at.hp = hp;
     at.scale = scale;
     at.q_prescaled = g_op_q_premul != 0.0f && hp == 0;
+    at.pipe = -1;                                     // the process default (f5_debug_set_attn_pipe)
     return g_ops.attention(at, (hipStream_t)stream);
 }
 
@@ -1440,6 +1452,12 @@ extern "C" int f5_op_convpos(const void* in_hi, const void* in_lo, const void* w
     cp.out_bf[1] = (op16_t*)out_lo;
     cp.out_f32 = out_f32;
     return g_ops.convpos(cp, (hipStream_t)stream);
+}
+
+// MFMA rate yardstick of the current operand type (f5_op_set_operand_type): see rowops.hip mfma_peak_kernel
+extern "C" int f5_op_mfma_peak(const void* operands, int blocks, int iters, float* sink, double* flops, void* stream) {
+    return g_ops.h ? f5hf::f5_launch_mfma_peak((const f5hf::op16_t*)operands, blocks, iters, sink, flops, (hipStream_t)stream)
+                   : f5bf::f5_launch_mfma_peak((const f5bf::op16_t*)operands, blocks, iters, sink, flops, (hipStream_t)stream);
 }
 
 extern "C" int f5_op_ln_modulate(const float* x, const float* scale, const float* shift, void* out_hi, void* out_lo, int rows,

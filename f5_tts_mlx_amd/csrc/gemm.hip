@@ -728,14 +728,16 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
         // QKV at batch-1-sized shapes: one round of role-split 128 x 256 tiles when they fill >= 70 % of the CUs (M = 2 x 937: 192 tiles,
         // 22.0 vs 27.3 us for the 64 x 128 register-staged tiles, sample() 78.3 -> 73.7-76.4 ms; smaller grids stay with the small
         // tiles: M = 3 x 431 22.4 vs 18.4 us).  f5_gemm_qkv_small_tile: 0 = this rule, 14 = whenever one round, 12 / 13 = lock-step ring.
-        const bool qkv14 = EPI == EPI_QKV_ROPE && sel == 0 && a.rope_cos_tk != nullptr && t128x256 <= 256 &&
+        // (the role-split QKV epilogue deals row tiles per batch element: it needs whole sequences, other shapes keep the small tiles)
+        const bool qkv_rows_ok = EPI != EPI_QKV_ROPE || (a.seq_len > 0 && a.M % a.seq_len == 0);
+        const bool qkv14 = EPI == EPI_QKV_ROPE && sel == 0 && qkv_rows_ok && a.rope_cos_tk != nullptr && t128x256 <= 256 &&
                            (f5_gemm_qkv_small_tile == 14 || (f5_gemm_qkv_small_tile == 0 && t128x256 >= 176));
         // MID sizes (batch 2 ... 16: more than one round of small tiles, too few 256 x 256 tiles to fill the chip twice): the role-split
         // 128 x 256 kernel in several rounds instead of the register-staged 128 x 128 kernel of round 1, which is where the `t128 >= 384`
         // fallback below used to send them.  sample() with it forced on every block GEMM (tile 14): batch 2 121.6 -> 110.1 ms, batch 3
         // 167.7 -> 154.5, batch 4 203.7 -> 166.5; equal to the 256 x 256 kernel at batch 8 (328.5 vs 327.4) and 16 (642.5 vs 650.6), whose
         // N = 1024 GEMMs (t256 < 512) fell to the small kernels as well (profiles/r03/mid_batch_dispatch.txt)
-        const bool mid = sel == 0 && t128 >= 384 && a.N % 256 == 0 && a.ln_counter == nullptr;
+        const bool mid = sel == 0 && t128 >= 384 && a.N % 256 == 0 && a.ln_counter == nullptr && qkv_rows_ok;
         if ((sel == 14 || qkv14 || mid) && a.N % 256 == 0 && a.ln_counter == nullptr) return f5_launch_gemm_rs128(a, EPI, stream);
         if (sel == 14) sel = 0;
     }

@@ -478,12 +478,8 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
         // the x rows (requested above, in flight during the staging writes) are waited for ONCE, here.  Their first use used to be
         // inside the `grow < M` blocks below: the compiler's `s_waitcnt vmcnt(0)` for them sat in every block and also waited for
         // the store of the previous block -- the eight 16-byte stores of a lane left one memory round trip apart
-        float kp[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            asm volatile("" : "+v"(xr[i]), "+v"(kraw[i]));
-            kp[i] = (float)kraw[i];
-        }
+        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(xr[i]), "+v"(kraw[i]));
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -493,7 +489,8 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
             if (grow < p.M) {
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = xr[i][e] + g4[e] * (v[e] * kp[i]);
+                for (int e = 0; e < 4; ++e) o[e] = xr[i][e] + g4[e] * (kraw[i] != 0u ? v[e] : 0.0f);   // a select, like gemm_epilogue: a non-finite
+                                                                                                      // accumulator of a masked row must not reach x
                 *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4) = o;
             }
         }

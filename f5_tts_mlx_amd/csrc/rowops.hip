@@ -644,6 +644,53 @@ int f5_launch_zero_vt_pad(op16_t* vt, size_t rows, int seq_len, int npad, hipStr
     return 0;
 }
 
+// MFMA rate yardstick (bench.py prints the rate it measures next to the data-sheet peak it divides by): every wave
+// streams v_mfma_f32_32x32x16 on four accumulators, no memory traffic in the loop.  operands == nullptr: lane-constant operand
+// registers (what a zero / constant-filled benchmark sees); otherwise eight A and eight B fragments per lane are loaded once from
+// `operands` (>= 16 x 64 x 8 values of workload-like data) and rotated, so consecutive MFMAs see different data like a K loop does
+// -- the delivered clock depends on how many operand bits toggle (MI355X_MICROARCH.md "DVFS give-back").
+__global__ __launch_bounds__(512) void mfma_peak_kernel(const op16_t* __restrict__ operands, int iters, float* __restrict__ sink) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+    op16x8 a[8], b[8];
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (operands) {
+            a[i] = *reinterpret_cast<const op16x8*>(operands + ((size_t)i * 64 + lane) * 8);
+            b[i] = *reinterpret_cast<const op16x8*>(operands + ((size_t)(8 + i) * 64 + lane) * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a[i][e] = static_cast<op16_t>(0.5f);
+                b[i][e] = static_cast<op16_t>(0.03125f);
+            }
+        }
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i & 3] = F5_MFMA32(a[i], b[i], acc[i & 3], 0, 0, 0);
+            acc[(i + 1) & 3] = F5_MFMA32(a[(i + 3) & 7], b[(i + 5) & 7], acc[(i + 1) & 3], 0, 0, 0);
+        }
+    }
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t += acc[i][0] + acc[i][7];
+    if (t == 123456.789f) sink[0] = t;                     // never true: keeps the accumulators alive
+}
+// returns the number of MFMA flops of the launch in *flops (blocks x 8 waves x iters x 16 MFMAs x 32 x 32 x 16 x 2)
+int f5_launch_mfma_peak(const op16_t* operands, int blocks, int iters, float* sink, double* flops, hipStream_t s) {
+    F5_REQUIRE(blocks > 0 && iters > 0 && sink, "mfma_peak: bad arguments");
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(512), 0, s, operands, iters, sink);
+    F5_LAUNCH_CHECK();
+    if (flops) *flops = (double)blocks * 8.0 * iters * 16.0 * 32768.0;
+    return 0;
+}
+
 __global__ void rowkeep_kernel(const int* __restrict__ dur, uint8_t* __restrict__ keep, int seq_len, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;

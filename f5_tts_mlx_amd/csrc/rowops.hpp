@@ -88,6 +88,8 @@ int f5_launch_splice(const float* cond, const float* y, const int* lens, float* 
 int f5_launch_stage_words(const uint32_t* host_words, size_t nwords, uint32_t* dst, hipStream_t s);
 int f5_launch_copy_words(const void* src, void* dst, size_t nwords, hipStream_t s);
 int f5_launch_zero_vt_pad(op16_t* vt, size_t rows, int seq_len, int npad, hipStream_t s);
+// MFMA rate yardstick: blocks x 512 threads, iters x 16 v_mfma_f32_32x32x16 per wave; operands nullptr = lane-constant registers
+int f5_launch_mfma_peak(const op16_t* operands, int blocks, int iters, float* sink, double* flops, hipStream_t s);
 
 // rowkeep[b*seq+n] = n < dur[b]  for 2 branches ([nb][seq])
 int f5_launch_rowkeep(const int* dur, uint8_t* keep, int nbatch, int seq_len, hipStream_t s);

@@ -62,7 +62,8 @@ int f5_engine_set_graph_cache(f5_engine* e, int max_graphs);
 int f5_engine_graph_count(f5_engine* e);
 /* Per-engine launch options (two engines of one process keep their own): "q_premul" (1: q leaves the QKV epilogue multiplied by
  * softmax_scale * log2 e), "qkv_transposed" (1: transposed q / k tiles in the 256x256 QKV kernel), "ln_fusion" (0; 1 = LN-modulate
- * fused behind small-tile residual GEMMs, measured slower), "gemm_flags" (0; F5GemmArgs debug bits of this engine's launches).
+ * fused behind small-tile residual GEMMs, measured slower), "gemm_flags" (0; F5GemmArgs debug bits of this engine's launches),
+ * "attn_pipe" (-1 = the process default of f5_debug_set_attn_pipe, 0 = large-grid attention kernel v2f, 1 = in-wave software-pipelined v2p).
  * Part of the hipGraph cache key.  New engines start from the process defaults (f5_debug_set_ln_fusion / _qkv_transposed /
  * _q_premul). */
 int f5_engine_set_option(f5_engine* e, const char* name, int value);
@@ -149,6 +150,10 @@ int f5_op_convpos(const void* in_hi, const void* in_lo, const void* w_hi, const 
 /* dit.py:270 */
 int f5_op_ln_modulate(const float* x, const float* scale, const float* shift, void* out_hi, void* out_lo, int rows, int dim,
                       void* stream);
+/* MFMA rate yardstick (no reference counterpart; BASELINE.md section 4: "print the measured MFMA micro-benchmark peak you divide by"):
+ * blocks x 8 waves x iters x 16 v_mfma_f32_32x32x16 of the current operand type on register operands -- operands NULL = lane-constant
+ * registers, else >= 16 x 64 x 8 16-bit values of workload-like data that are rotated through the MFMAs; *flops = flops of the launch */
+int f5_op_mfma_peak(const void* operands, int blocks, int iters, float* sink, double* flops, void* stream);
 /* convnext_v2.py:46-48 */
 int f5_op_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b, void* out_hi,
                     void* out_lo, int nbatch, int seq_len, int dim, void* stream);
@@ -252,6 +257,8 @@ int f5_debug_set_convpos_xcd_map(int on);   /* conv-pos kernel: 1 (default) = gr
 int f5_debug_set_attn_wide(int v);
 /* in-workgroup KV split of the attention kernel: -1 auto (by grid size), 1 none, 2 / 4 wave groups */
 int f5_debug_set_attn_kvsplit(int v);
+/* large-grid attention kernel (q pre-multiplied): 1 = in-wave software-pipelined kernel, one wave per SIMD (v2p), 0 = v2f */
+int f5_debug_set_attn_pipe(int v);
 /* process DEFAULTS of the per-engine options (f5_engine_set_option); engines that already exist keep their own values */
 int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the residual GEMMs of small-M launches (default 0: measured slower) */
 int f5_debug_set_qkv_transposed(int on);    /* 1 (default): sample() hands the pair-major rotation tables to the QKV projection (256x256 kernel: transposed q / k tiles) */

@@ -89,3 +89,50 @@ def test_two_ranks_real_engine_shards_equal_single_process_batch():
     for p in procs:
         p.join(timeout=120)
     assert res[0][0] and res[1][0], res
+
+
+def test_one_utterance_shards_keep_the_key_mask():
+    """a shard of ONE utterance (batch 6 over 6 GPUs) is padded to the global maximum by `pad_to` and must still
+    run with the key-padding mask of the unsharded call (cfm.py:333-336 builds it when batch > 1) -- the padded frames are keys
+    otherwise.  Every utterance of a ragged batch sampled alone with pad_to equals its row of the batched call (same arithmetic,
+    possibly other tile shapes: 1e-5), and NOT the unmasked single-utterance result."""
+    from f5_tts_mlx_amd.cfm import F5TTS
+    from f5_tts_mlx_amd.dit import DiT
+    from f5_tts_mlx_amd.weights import TINY, synthetic_weights
+    cfg, B, N = TINY, 6, 120
+    cond, text, durations, y0 = _inputs(cfg, B, N)
+    model = DiT.from_config(cfg, precision="bf16x3", device="cuda:0")
+    model.load_weights(synthetic_weights(cfg, seed=42))
+    f5 = F5TTS(transformer=model)
+    kw = dict(steps=5, method="midpoint", cfg_strength=2.0, sway_sampling_coef=-1.0)
+    ref, _ = f5.sample(cond, text, duration=torch.tensor(durations), y0=y0, **kw)
+    torch.cuda.synchronize()
+    worst, apart = 0.0, 0.0
+    for i in range(B):
+        sl = slice(i, i + 1)
+        out, _ = f5.sample(cond[sl], text[sl], duration=torch.tensor(durations[sl]), y0=y0[sl].contiguous(), pad_to=N, **kw)
+        d = durations[i]
+        worst = max(worst, float((out[0, :d] - ref[i, :d]).abs().max()))
+        if d < N:
+            # the same shard WITHOUT the mask (what round 3 did): engine level, use_mask=False
+            eng = model.engine
+            lens = torch.maximum((text[sl] != -1).sum(-1), torch.tensor([cond.shape[1]]))
+            condp = torch.zeros((1, N, cfg.mel_dim), device="cuda:0")
+            condp[:, :cond.shape[1]] = cond[sl].to("cuda:0")
+            from f5_tts_mlx_amd.cfm import time_grid
+            o2, _ = eng.sample(text[sl].to("cuda:0").contiguous(), condp, lens.tolist(), [d], y0[sl].to("cuda:0").contiguous(),
+                               time_grid(5, -1.0), method="midpoint", cfg_strength=2.0, use_mask=False, use_graph=False)
+            apart = max(apart, float((o2[0, :d] - ref[i, :d]).abs().max()))
+    print(f"[one-utterance shards] worst |shard - batch row| = {worst:.3e}; unmasked shard is {apart:.3e} away")
+    assert worst <= 1e-5 and apart > 1e-3
+
+
+def test_pad_to_respects_max_duration():
+    from f5_tts_mlx_amd.cfm import F5TTS
+    from f5_tts_mlx_amd.dit import DiT
+    from f5_tts_mlx_amd.weights import TINY, synthetic_weights
+    cond, text, durations, y0 = _inputs(TINY, 2, 60)
+    model = DiT.from_config(TINY, precision="f16", device="cuda:0")
+    model.load_weights(synthetic_weights(TINY, seed=42))
+    with pytest.raises(ValueError, match="exceeds max_duration"):
+        F5TTS(transformer=model).sample(cond, text, duration=torch.tensor(durations), y0=y0, steps=3, method="euler", pad_to=5000)

@@ -738,6 +738,83 @@ def test_batch32_every_utterance_parity():
     print(f"[b32 parity] worst utterance of 32: mel L1 {worst:.3e} (gate {MEL_L1_TOL})")
 
 
+def _golden_module(name):
+    import importlib.util
+    import os
+    from f5test import ROOT
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tests", "golden", name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def full_f16():
+    return _model(F5TTS_335M, synthetic_weights(F5TTS_335M, seed=42), "f16")
+
+
+@pytest.mark.parametrize("B", [2, 4, 8, 16])
+def test_fullsize_mid_batches_every_utterance_vs_oracle(full_f16, B):
+    """batch 2 ... 16 at the full 335M size run the role-split 128 x 256 GEMM IN SEVERAL ROUNDS with the RESID_GATE /
+    GELU / QKV epilogues (the `mid` rule of gemm.hip launch_epi, commit 943a2ee) -- the shipped default path of those batch sizes.
+    Here: `f16`, automatic dispatch, N = 937, 5-point Euler + sway + CFG (8 DiT forwards), EVERY utterance against the fp32 CPU
+    oracle's answer for the same utterance (tests/golden/full_b16_euler5.npz, made by make_batch_golden.py: bench.py's utterances
+    0..15; at equal durations the oracle's batch elements do not interact, so its first B rows are the batch-B answer)."""
+    import os
+    from f5test import ROOT
+    import bench
+    mg = _golden_module("make_batch_golden")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_b16_euler5.npz"))
+    cond, text, y0, _ = bench.synth_batch(B, 0, DEV)
+    out, _ = F5TTS(transformer=full_f16).sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=False, **mg.KW)
+    torch.cuda.synchronize()
+    out = out.cpu()
+    assert torch.isfinite(out).all()
+    l1 = [float((out[i] - torch.from_numpy(g["out"][i])).abs().mean()) for i in range(B)]
+    print(f"[mid batch] B={B} f16 vs fp32 oracle, mel L1 per utterance: worst {max(l1):.3e} mean {np.mean(l1):.3e}")
+    assert max(l1) <= MEL_L1_TOL, l1
+    # the captured graph replays the same launches: bit-identical
+    out2, _ = F5TTS(transformer=full_f16).sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=True, **mg.KW)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.cpu(), out)
+
+
+def test_fullsize_ragged_batch_vs_oracle(full_f16):
+    """a RAGGED full-size batch (B = 8, durations 937 ... 500, text padded by a different amount per utterance):
+    the key mask with real kv_len in the attention kernels, attention-output rows zeroed at padded positions through `rowkeep` in the
+    residual epilogue, GRN / conv-pos over the padded length (cfm.py:317-336, dit.py:160-173) -- against the fp32 oracle's BATCHED
+    answer (full_b8_ragged_euler5.npz).  The gate is asserted on each utterance's valid frames; the padded frames (which the
+    reference lets evolve through the MLP path and returns untrimmed) are compared too."""
+    import os
+    from f5test import ROOT
+    from f5_tts_mlx_amd.audio import log_mel_spectrogram
+    mg = _golden_module("make_batch_golden")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_b8_ragged_euler5.npz"))
+    waves, text, y0, dur = mg.ragged_inputs()
+    cond = log_mel_spectrogram(torch.from_numpy(waves).to(DEV))
+    f5 = F5TTS(transformer=full_f16)
+    for use_graph in (False, True):
+        out, _ = f5.sample(cond, torch.from_numpy(text), duration=torch.from_numpy(dur), y0=torch.from_numpy(y0), use_graph=use_graph, **mg.KW)
+        torch.cuda.synchronize()
+        out = out.cpu()
+        assert torch.isfinite(out).all() and tuple(out.shape) == tuple(g["out"].shape)
+        ref = torch.from_numpy(g["out"])
+        l1v = [float((out[i, :d] - ref[i, :d]).abs().mean()) for i, d in enumerate(dur.tolist())]
+        l1p = [float((out[i, d:] - ref[i, d:]).abs().mean()) for i, d in enumerate(dur.tolist()) if d < out.shape[1]]
+        print(f"[ragged full size] graph={use_graph} f16 vs fp32 oracle: valid frames worst {max(l1v):.3e}, padded frames worst {max(l1p):.3e}")
+        assert max(l1v) <= MEL_L1_TOL, l1v
+        assert max(l1p) <= 5e-3, l1p
+    # the same batch as two shards padded to the global maximum (pad_to): rows equal the unsharded call
+    o_a, _ = f5.sample(cond[:1], torch.from_numpy(text[:1]), duration=torch.from_numpy(dur[:1]), y0=torch.from_numpy(y0[:1]), use_graph=False, **mg.KW)
+    o_b, _ = f5.sample(cond[5:], torch.from_numpy(text[5:]), duration=torch.from_numpy(dur[5:]), y0=torch.from_numpy(y0[5:]).contiguous(),
+                       use_graph=False, pad_to=mg.N_FRAMES, **mg.KW)
+    torch.cuda.synchronize()
+    d0 = float((o_a.cpu()[0] - out[0]).abs().max())
+    d5 = max(float((o_b.cpu()[k, :dur[5 + k]] - out[5 + k, :dur[5 + k]]).abs().max()) for k in range(3))
+    print(f"[ragged full size] shard of 1 (longest, no pad_to needed) vs batch row: {d0:.3e}; shard of 3 with pad_to vs batch rows: {d5:.3e}")
+    assert d5 <= 2e-2 and d0 <= 2e-2      # other tile shapes at M = 2 x 937 / 6 x 937: f16 rounding-level, not mask-level, differences
+
+
 def test_f16_range_stress_outlier_weights():
     """The range hazard of IEEE-half operands (+-65 504), tested instead of argued: trained DiTs carry activation outliers the
     seeded-random weights do not, so a few adaLN scale rows, FF1 rows and q / k rows of the 335M weights are scaled by 1e2 ... 1e3
@@ -935,3 +1012,46 @@ def test_golden_cfm_loss_on_the_engine(tiny_weights, tiny_x3):
         want = float(g["loss_" + name])
         print(f"golden cfm loss [{name}]: engine {got:.6f} golden {want:.6f}")
         assert abs(got - want) <= 2e-4 * want
+
+
+def test_real_checkpoint_tooling_on_a_synthetic_directory(tmp_path):
+    """the real-weights entry points, runnable without a real checkpoint.  A synthetic 335M checkpoint directory
+    with UPSTREAM key names (ema_model. prefix, PyTorch conv layout: what cfm.py:477-508 converts) goes through
+    (1) tools/real_checkpoint_parity.py: oracle vs engine in f16 / bf16x3 on the fixture WAV + the per-producer operand maxima,
+    (2) `bench.py --weights DIR` (= $F5_WEIGHTS): the bench line on that checkpoint."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from safetensors.numpy import save_file
+    from f5test import ROOT
+    vocab_text = open(str(E.library_path().parent.parent / "assets" / "vocab.txt")).read()
+    import dataclasses
+    cfg = dataclasses.replace(F5TTS_335M, text_num_embeds=len(vocab_text.split("\n")) - 1)
+    w = synthetic_weights(cfg, seed=9)
+    up = {}
+    for k, v in w.items():                                  # MLX-layout names -> upstream names (the inverse of cfm.py:479-504)
+        n = k.replace(".to_out.layers.", ".to_out.").replace(".text_blocks.layers.", ".text_blocks.").replace(".ff.ff.layers.0.layers.0", ".ff.ff.0.0")
+        n = n.replace(".ff.ff.layers.2", ".ff.ff.2").replace(".time_mlp.layers.", ".time_mlp.").replace(".conv1d.layers.", ".conv1d.")
+        if v.ndim == 3 and ("conv1d" in k or "dwconv" in k):
+            v = np.ascontiguousarray(np.swapaxes(v, 1, 2))
+        up["ema_model." + n] = v.astype(np.float32)
+    mdir = tmp_path / "ckpt"
+    mdir.mkdir()
+    (mdir / "vocab.txt").write_text(vocab_text)
+    save_file(up, str(mdir / "model_v1.safetensors"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import real_checkpoint_parity as RP
+    wl, _ = RP.load_checkpoint(str(mdir))
+    assert set(wl) >= {k for k in w if "inv_freq" not in k} and all(np.array_equal(wl[k], w[k]) for k in w if k in wl)
+    res = RP.run(str(mdir), steps=3, seconds=1.0, precisions=("f16", "bf16x3"))
+    print(json.dumps({k: v for k, v in res.items() if k != "operand_peaks"}), "\n", json.dumps(res["operand_peaks"], indent=0)[:1500])
+    assert res["mel_l1"]["bf16x3"] <= 1e-4 and res["mel_l1"]["f16"] <= MEL_L1_TOL and all(res["finite"].values())
+    assert res["largest_operand"] < 65504.0 / 8 and any("attention q" in k for k in res["operand_peaks"]) and any("ff.ff.layers.2" in k for k in res["operand_peaks"])
+    env = dict(os.environ, F5_WEIGHTS=str(mdir))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--ode-points", "3", "--no-sub", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["data"].startswith("REAL checkpoint") and "parity_l1" not in line and line["value"] > 0
+    assert line["roofline"]["peak_measured_tflops"] > 500 and 0 < line["roofline"]["frac_of_measured"] < 1

@@ -62,6 +62,19 @@ def test_attention_softmax_spike_f16(lib):
     T.test_attention_softmax_spike(lib, hp=0)
 
 
+@pytest.mark.parametrize("N", [1, 33, 64, 65, 130, 257, 320, 499, 937])
+def test_attention_pipelined_v2p_shapes_f16(lib, N):
+    T.test_attention_pipelined_v2p_shapes(lib, N)
+
+
+def test_attention_pipelined_v2p_ragged_and_spikes_f16(lib):
+    T.test_attention_pipelined_v2p_ragged_and_spikes(lib)
+
+
+def test_attention_pipelined_v2p_large_grid_f16(lib):
+    T.test_attention_pipelined_v2p_large_grid_matches_v2f(lib)
+
+
 @pytest.mark.lab
 @pytest.mark.parametrize("N", [1, 64, 130, 937])
 def test_attention_pipelined_kernel_f16(lib, N):
@@ -120,3 +133,8 @@ def test_fp16_producers_saturate(lib):
     E.check(lib.f5_op_ln_modulate(P(xd), P(scd), P(shd), P(hi), P(None), rows, dim, stream()))
     torch.cuda.synchronize()
     assert torch.isfinite(hi).all() and float(hi.abs().max()) == 65504.0
+
+
+@pytest.mark.parametrize("tile", [0, 14])
+def test_gemm_rs128_several_rounds_all_epilogues_f16(lib, tile):
+    T.test_gemm_rs128_several_rounds_all_epilogues(lib, tile)

@@ -32,7 +32,7 @@ def models():
     cfg = DiTConfig(**json.loads(str(g["cfg"])))
     w = synthetic_weights(cfg, seed=int(g["weights_seed"]))
     out = {}
-    for prec in ("bf16x3", "bf16"):
+    for prec in ("bf16x3", "bf16", "f16"):
         m = DiT.from_config(cfg, precision=prec, device=DEV)
         m.load_weights(w)
         out[prec] = m
@@ -177,3 +177,44 @@ def test_sample_duration_clamps_vs_reference_code(models):
     _, l1, _ = report("sample[bf16x3] clamps final mel vs reference code", out.cpu(), torch.from_numpy(g["out"]))
     _, l1t, _ = report("sample[bf16x3] clamps trajectory vs reference code", traj.cpu(), torch.from_numpy(g["traj"]))
     assert l1 <= MEL_L1_TOL and l1t <= MEL_L1_TOL
+
+
+def test_benched_f16_mode_vs_reference_code(models):
+    """the mode bench.py times (`f16`: IEEE-half MFMA operands) against the vectors the REFERENCE's own code
+    produced -- one hop, not engine -> oracle -> reference: DiT forwards (cond / null, masked / unmasked), the ragged batch-2
+    sample() for the three solvers, batch 1 without CFG, and the duration clamps.  Gate: mel L1 <= 1e-3 on final mels and
+    trajectories (the forward gets the relative bound the bf16 mode has, tightened by the three extra significand bits)."""
+    cfg, ms = models
+    m = ms["f16"]
+    g = load("ref_dit_forward.npz")
+    x, cond, text, time, mask = (torch.from_numpy(g[k]) for k in ("x", "cond", "text", "time", "mask"))
+    for tag, (drop, mk) in dict(cond=(False, None), null=(True, None), cond_masked=(False, mask), null_masked=(True, mask)).items():
+        got = m(x=x, cond=cond, text=text, time=time, drop_audio_cond=drop, drop_text=drop, mask=mk)
+        _, mean, refm = report(f"dit[f16] {tag} vs reference code", got.cpu(), torch.from_numpy(g["out_" + tag]))
+        assert mean <= 4e-3 * max(1.0, refm), tag
+    g = load("ref_sample.npz")
+    durations = torch.from_numpy(g["durations"])
+    y0 = torch.zeros((2, int(durations.max()), cfg.mel_dim))
+    for i, z in enumerate((g["z0"], g["z1"])):
+        y0[i, :z.shape[1]] = torch.from_numpy(z.T)
+    f5 = F5TTS(transformer=m)
+    for method in ("euler", "midpoint", "rk4"):
+        kw = dict(duration=durations, lens=torch.from_numpy(g["lens"]), steps=int(g[f"steps_{method}"]), method=method, cfg_strength=2.0,
+                  sway_sampling_coef=-1.0, y0=y0)
+        out, traj = f5.sample(torch.from_numpy(g["cond"]), torch.from_numpy(g["text"]), **kw)
+        _, l1, _ = report(f"sample[f16] {method} final mel vs reference code", out.cpu(), torch.from_numpy(g[f"out_{method}"]))
+        _, l1t, _ = report(f"sample[f16] {method} trajectory vs reference code", traj.cpu(), torch.from_numpy(g[f"traj_{method}"]))
+        assert l1 <= MEL_L1_TOL and l1t <= MEL_L1_TOL, method
+    out, traj = f5.sample(torch.from_numpy(g["cond"][:1]), torch.from_numpy(g["text"][:1]), duration=int(g["durations"][0]), steps=4,
+                          method="euler", cfg_strength=0.0, sway_sampling_coef=None, y0=torch.from_numpy(g["z0"].T.copy())[None])
+    _, l1, _ = report("sample[f16] B1 no-cfg vs reference code", out.cpu(), torch.from_numpy(g["out_b1_nocfg"]))
+    assert l1 <= MEL_L1_TOL
+    g = load("ref_sample_clamps.npz")
+    nmax = int(g["max_duration"])
+    y0 = torch.zeros((2, nmax, cfg.mel_dim))
+    for i, z in enumerate((g["z0"], g["z1"])):
+        y0[i, :z.shape[1]] = torch.from_numpy(z.T)
+    out, _ = f5.sample(torch.from_numpy(g["cond"]), torch.from_numpy(g["text"]), duration=torch.from_numpy(g["durations"]),
+                       lens=torch.from_numpy(g["lens"]), steps=3, method="euler", y0=y0, max_duration=nmax)
+    _, l1, _ = report("sample[f16] clamps final mel vs reference code", out.cpu(), torch.from_numpy(g["out"]))
+    assert l1 <= MEL_L1_TOL

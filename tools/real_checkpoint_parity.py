@@ -1,0 +1,132 @@
+"""Parity and operand range of a REAL F5-TTS checkpoint (reference path cfm.py:404-520).
+
+Every drift figure in this repo (f16 2.4e-4, bf16 1.9e-3) and the argument that IEEE-half operands are safe rest on seeded synthetic
+weights -- no checkpoint is reachable offline.  Where one is, this tool answers the two open questions for it:
+
+  1. mel L1 of the engine (f16 / bf16 / bf16x3) against the fp32 CPU oracle on the fixture WAV + its caption, short solve;
+  2. the largest |value| that reaches each MFMA operand producer in the fp32 oracle run (LN-modulated activations into QKV / FF1,
+     RoPE'd q and k, v, attention output into the out-projection, GELU output into FF2, conv-pos input, text-path pwconv inputs) --
+     the f16 mode saturates at +-65 504 (op16.hpp f5_sat); anything within ~2x of that means: run this checkpoint in bf16x3 / bf16.
+
+    python tools/real_checkpoint_parity.py /path/to/F5-TTS-dir [--steps 5] [--seconds 6.0] [--precisions f16,bf16,bf16x3]
+
+The directory is what F5TTS.from_pretrained reads: model_v1.safetensors (upstream or MLX key names) + vocab.txt.  The oracle is test
+infrastructure: this tool is a checker, nothing on the product path imports it.  tests/test_model_gpu.py runs it on a synthetic
+checkpoint directory.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+F16_MAX = 65504.0
+
+
+def load_checkpoint(path: str):
+    """-> (reference-named fp32 weights, vocab char map), the way F5TTS.from_pretrained reads a directory (cfm.py:411-421, 477-508)"""
+    from safetensors.numpy import load_file
+    from f5_tts_mlx_amd.weights import convert_upstream_weights
+    vocab = {v: i for i, v in enumerate(open(os.path.join(path, "vocab.txt"), encoding="utf-8").read().split("\n"))}
+    w = load_file(os.path.join(path, "model_v1.safetensors"))
+    if any(k.startswith("ema_model.") for k in w):
+        w = convert_upstream_weights(w)
+    return {k: np.asarray(v, np.float32) for k, v in w.items()}, vocab
+
+
+def recording_oracle(cfg, weights):
+    """fp32 oracle that records max |x| per MFMA operand producer (keyed by site, block index stripped)"""
+    from oracle import f5_oracle as O   # checker only
+
+    class Rec(O.DiTOracle):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.peaks, self._pending = {}, 0
+
+        def _note(self, site, x):
+            v = float(x.abs().max())
+            self.peaks[site] = max(self.peaks.get(site, 0.0), v)
+
+        def _A(self, x):
+            if self._pending:                               # the three calls of attention(): q, k (after RoPE), v
+                self._note(("attention q (RoPE'd, before the scale)", "attention k (RoPE'd)", "attention v")[3 - self._pending], x)
+                self._pending -= 1
+            return super()._A(x)
+
+        def linear(self, x, name, lowp=True):
+            if lowp:
+                self._note("A operand of " + re.sub(r"\.\d+\.", ".N.", name), x)
+            y = super().linear(x, name, lowp)
+            if name.endswith(".attn.to_v"):
+                self._pending = 3
+            return y
+
+        def conv1d_cl(self, x, name, groups, padding, lowp):
+            if lowp:
+                self._note("conv input of " + name, x)
+            return super().conv1d_cl(x, name, groups, padding, lowp)
+
+    return Rec(cfg, weights)
+
+
+def run(path: str, steps: int = 5, seconds: float = 6.0, precisions=("f16", "bf16", "bf16x3"), device: str = "cuda:0", wav: str | None = None,
+        text: str = "Some call me nature, others call me mother nature.") -> dict:
+    import dataclasses
+    from oracle import f5_oracle as O   # checker only
+    from f5_tts_mlx_amd.cfm import F5TTS
+    from f5_tts_mlx_amd.dit import DiT
+    from f5_tts_mlx_amd.generate import read_wav
+    from f5_tts_mlx_amd.utils import convert_char_to_pinyin
+    from f5_tts_mlx_amd.weights import F5TTS_335M
+    weights, vocab = load_checkpoint(path)
+    cfg = dataclasses.replace(F5TTS_335M, text_num_embeds=len(vocab) - 1)
+    wav = wav or os.path.join(ROOT, "f5_tts_mlx_amd", "assets", "test_en_1_ref_short.wav")
+    audio, sr = read_wav(wav)
+    assert sr == 24000, "the reference audio must be 24 kHz (generate.py:147-148)"
+    audio = np.asarray(audio, np.float32)
+    n_ref = audio.shape[0] // 256
+    duration = n_ref + int(seconds * 93.75)
+    chars = convert_char_to_pinyin(["Some call me nature, others call me mother nature. " + text])
+    r = np.random.default_rng(0)
+    y0 = torch.from_numpy(np.ascontiguousarray(r.standard_normal((100, duration)).astype(np.float32).T))[None]
+    kw = dict(steps=steps, method="euler", cfg_strength=2.0, sway_sampling_coef=-1.0)
+    orc = recording_oracle(cfg, weights)
+    cond = torch.from_numpy(np.asarray(O.log_mel_spectrogram(audio), np.float32).reshape(1, -1, 100))
+    ref, _ = O.sample(orc, cond, chars, duration, y0=y0, vocab_char_map=vocab, **kw)
+    res = dict(checkpoint=os.path.abspath(path), frames=int(duration), ref_frames=int(n_ref), ode_points=steps, forwards=2 * (steps - 1),
+               oracle_mel_abs_mean=float(ref.abs().mean()), mel_l1={}, operand_peaks={k: round(v, 3) for k, v in sorted(orc.peaks.items())})
+    worst = max(orc.peaks.values())
+    res["largest_operand"] = worst
+    res["f16_headroom"] = F16_MAX / worst
+    res["verdict"] = ("f16 operands have >= 8x headroom on this input" if worst * 8 <= F16_MAX else
+                      ("f16 operands are within 8x of saturation: compare the f16 and bf16x3 lines below" if worst <= F16_MAX else
+                       "values beyond +-65504 reach MFMA operands: f16 saturates, use bf16x3 (or bf16)"))
+    for prec in precisions:
+        m = DiT.from_config(cfg, precision=prec, device=device)
+        m.load_weights(weights)
+        out, _ = F5TTS(transformer=m, vocab_char_map=vocab).sample(cond, chars, duration=duration, y0=y0, use_graph=False, **kw)
+        torch.cuda.synchronize()
+        res["mel_l1"][prec] = float((out.cpu() - ref).abs().mean())
+        res.setdefault("finite", {})[prec] = bool(torch.isfinite(out).all())
+        del m
+        torch.cuda.empty_cache()
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("path")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--seconds", type=float, default=6.0)
+    ap.add_argument("--precisions", default="f16,bf16,bf16x3")
+    ap.add_argument("--wav", default=None)
+    a = ap.parse_args()
+    print(json.dumps(run(a.path, a.steps, a.seconds, tuple(a.precisions.split(",")), wav=a.wav), indent=1))
