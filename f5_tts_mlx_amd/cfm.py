@@ -228,6 +228,7 @@ class F5TTS:
             duration = self.predict_duration(cond, text, speed)
         max_duration_cap = int(max_duration)
         text, lens, duration, max_duration = prepare_lengths(text, cond_seq_len, batch, duration, lens, max_duration, method)
+        self.last_durations = [int(d) for d in duration.tolist()]     # extension: frames per element after the clamps (cfm.py:317-318)
         if pad_to is not None:
             # GRN (convnext_v2.py:16) and the unmasked conv-pos-embed (dit.py:251) see the padding, so a shard of a batch only
             # reproduces its rows of the unsharded call when it is padded to the WHOLE batch's maximum (dist.shard_batch)

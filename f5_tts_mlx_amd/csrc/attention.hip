@@ -1056,29 +1056,20 @@ __global__ __launch_bounds__(256, 2) void f5_attn2f_kernel(F5AttnArgs p) {
 // opens with its own two states.
 #define A2P_GUARD "s_nop 1\n\t"
 // d (VGPRs) = a * b + c: first MFMA of a score block, c = -m_ref (VGPRs: C and D share one half of the register file)
-template <int ABL = 0>
 __device__ __forceinline__ void a2p_mfma_first(f32x16& d, const op16x8& a, const op16x8& b, const f32x16& c) {
-    if (ABL == 5) { asm volatile("" : "=v"(d) : "a"(a), "a"(b), "v"(c)); return; }
-    if (ABL == 6 || ABL == 8) asm volatile(A2P_MFMA_OP " %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
-    else asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
+    asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
 }
 // d (VGPRs) = a * b (C = inline constant 0)
 __device__ __forceinline__ void a2p_mfma_first0(f32x16& d, const op16x8& a, const op16x8& b) {
     asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b));
 }
 // d (VGPRs) += a * b
-template <int ABL = 0>
 __device__ __forceinline__ void a2p_mfma_s(f32x16& d, const op16x8& a, const op16x8& b) {
-    if (ABL == 5) { asm volatile("" : "+v"(d) : "a"(a), "a"(b)); return; }
-    if (ABL == 6 || ABL == 8) asm volatile(A2P_MFMA_OP " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
-    else asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+    asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
 }
 // d (AGPRs) += a * b, b = P (VGPRs)
-template <int ABL = 0>
 __device__ __forceinline__ void a2p_mfma_o(f32x16& d, const op16x8& a, const op16x8& b) {
-    if (ABL == 5) { asm volatile("" : "+a"(d) : "a"(a), "v"(b)); return; }
-    if (ABL == 6 || ABL == 8) asm volatile(A2P_MFMA_OP " %0, %1, %2, %0" : "+a"(d) : "a"(a), "v"(b));
-    else asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, %0" : "+a"(d) : "a"(a), "v"(b));
+    asm volatile(A2P_GUARD A2P_MFMA_OP " %0, %1, %2, %0" : "+a"(d) : "a"(a), "v"(b));
 }
 // a wave-uniform pointer the compiler can see is uniform (SGPR pair): global_load_lds then uses the "SGPR base + 32-bit VGPR offset" form
 __device__ __forceinline__ const char* attn_uniform_ptr(const void* ptr) {
@@ -1091,14 +1082,37 @@ __device__ __forceinline__ const char* attn_uniform_ptr(const void* ptr) {
 // block KBN of the K tile in ring stage ST_K; p_prev: P of the previous block = key block KBP of the tile whose V^T sits in stage
 // ST_V; nvalid (MASK instantiations = last tile only): keys of THIS block that exist (>= 32: all).  pk / pv: LDS addresses of this
 // lane's K / V^T fragments inside stage 0 (loop invariant; stage, key / d block are immediates).
-// N_*: the same four parameters of the half-step that FOLLOWS (its first three fragments are requested at the end of this one)
-template <int ABL, int ST_K, int KBN, int ST_V, int KBP, int N_ST_K, int N_KBN, int N_ST_V, int N_KBP>
-__device__ __forceinline__ void attn2p_half(const op16_t* const (&pk)[4], const op16_t* const (&pv)[4], const op16x8 (&qf)[2][4],
-                                            op16x8 (&fr)[4], f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], f32x16 (&o)[2][2], f32x16 (&mneg)[2],
+// LDS fragment load in asm, straight into the accumulator file, with the wait counted by hand (the compiler's own lgkmcnt waits for
+// its ds_reads were lgkmcnt(0) in front of the first MFMA that used one: a full LDS round trip, ~100 cycles, exposed twice per
+// half-step; tools/probes/inwave_overlap.hip modes 11 / 13).  The destination is only valid after a2p_lds_wait.
+__device__ __forceinline__ uint32_t a2p_lds_addr(const void* p) {
+    return (uint32_t)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)p);
+}
+template <int BYTES>
+__device__ __forceinline__ void a2p_lds_read(op16x8& dst, uint32_t addr) {
+    static_assert(BYTES >= 0 && BYTES < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(addr), "n"(BYTES));
+}
+__device__ __forceinline__ void a2p_lds_wait(op16x8 (&f)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(f[0]), "+a"(f[1]), "+a"(f[2]), "+a"(f[3]), "+a"(f[4]), "+a"(f[5]), "+a"(f[6]), "+a"(f[7]));
+}
+// the eight fragments of a half-step: K steps 0..3 of key block KBN of the K tile in ring stage ST_K, then V^T pieces (16-key step
+// 2 KBP + (g >> 1), d block g & 1), g = 0..3, of the V^T tile in stage ST_V.  ak / av: this lane's LDS byte addresses inside stage 0.
+template <int F, int ST_K, int KBN, int ST_V, int KBP>
+__device__ __forceinline__ void a2p_load_frag(op16x8& dst, const uint32_t (&ak)[4], const uint32_t (&av)[4]) {
+    if (F < 4) a2p_lds_read<(ST_K * ATTN2P_TILE + KBN * 2048) * 2>(dst, ak[F]);
+    else a2p_lds_read<((4 + ST_V) * ATTN2P_TILE + ((F - 4) & 1) * 2048) * 2>(dst, av[2 * KBP + ((F - 4) >> 1)]);
+}
+
+// One half-step.  s_cur: the scores of this 32-key block (both query blocks); s_nxt: the scores of the next block; fr: the eight
+// LDS fragments of THIS half-step (requested during the previous one, complete on entry); fn: those of the NEXT half-step, whose
+// parameters are N_* -- requested in the first eight half-slots, waited for at the end; p_prev: P of the previous block;
+// nvalid: keys of THIS block that exist (>= 32: all).
+template <int N_ST_K, int N_KBN, int N_ST_V, int N_KBP>
+__device__ __forceinline__ void attn2p_half(const uint32_t (&ak)[4], const uint32_t (&av)[4], const op16x8 (&qf)[2][4], op16x8 (&fr)[8],
+                                            op16x8 (&fn)[8], f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], f32x16 (&o)[2][2], f32x16 (&mneg)[2],
                                             const uint32_t (&p_prev)[2][8], uint32_t (&p_cur)[2][8], float (&l_run)[2], int hi,
                                             int nvalid) {
-    constexpr int NF = 8;                                    // LDS fragments of this half-step; each feeds two MFMAs (query blocks 0, 1)
-    constexpr bool HAS_QK = true;
     constexpr float SUM_LIMIT = 16384.0f;
     if (__builtin_expect(nvalid < 32, 0)) {                  // wave-uniform; only the last tile of a sequence can be partial
 #pragma unroll
@@ -1107,61 +1121,52 @@ __device__ __forceinline__ void attn2p_half(const op16_t* const (&pk)[4], const 
             for (int r = 0; r < 16; ++r)
                 if (16 * hi + r >= nvalid) s_cur[qb][r] = -INFINITY;
     }
-    // fragment f (compile-time after unrolling: lane address + immediate).  K and V^T fragments ALTERNATE -- K step 0, V^T piece 0,
-    // K step 1, ... -- so that an MFMA and the next one on the same accumulator are four MFMAs apart in both chains (S: two query
-    // blocks x K steps; O: two query blocks x two d blocks); f >= 8 = fragment f - 8 of the next half-step
-    auto frag = [&](int f) -> op16x8 {
-        const bool nx = f >= NF;
-        const int ff = nx ? f - NF : f, g = ff >> 1;
-        if ((ff & 1) == 0) return *reinterpret_cast<const op16x8*>(pk[g] + (nx ? N_ST_K : ST_K) * ATTN2P_TILE + (nx ? N_KBN : KBN) * 2048);   // k-step g
-        return *reinterpret_cast<const op16x8*>(pv[2 * (nx ? N_KBP : KBP) + (g >> 1)] + (4 + (nx ? N_ST_V : ST_V)) * ATTN2P_TILE + (g & 1) * 2048);   // (16-key step g >> 1, d block g & 1)
-    };
     float sa[2] = {0.0f, 0.0f}, sb[2] = {0.0f, 0.0f};        // two partial row sums per query block (even / odd key of a pair)
     float y0 = 0.0f, y1 = 0.0f;                              // exponentials of the previous pair (summed / packed one half-slot later)
-#pragma unroll
-    for (int h = 0; h < 2 * NF; ++h) {
-        const int f = h >> 1, qb = h & 1;
-        // three fragments ahead, into the slot of fragment f - 1 (both of its MFMAs are out); the last three requests are the first
-        // three fragments of the NEXT half-step, which therefore starts without an exposed LDS round trip
-        if (ABL != 3 && qb == 0) fr[(f + 3) & 3] = frag(f + 3);
-        if (ABL != 2) {
-            const int pr = h;                                // pair (query block, i): scores 2i, 2i + 1 of s_cur[.]
-            const int pq = pr >> 3, pi = pr & 7;
-            float x0 = ABL == 1 ? s_cur[pq][2 * pi] : __builtin_amdgcn_exp2f(s_cur[pq][2 * pi]);
-            float x1 = ABL == 1 ? s_cur[pq][2 * pi + 1] : __builtin_amdgcn_exp2f(s_cur[pq][2 * pi + 1]);
-            asm volatile("" : "+v"(x0), "+v"(x1));
-            if (pr > 0) {
-                const int qq = (pr - 1) >> 3, w = (pr - 1) & 7;
-                sa[qq] += y0;
-                sb[qq] += y1;
-                p_cur[qq][w] = f5_pack2_bounded(y0, y1);
-                asm volatile("" : "+v"(sa[qq]), "+v"(sb[qq]), "+v"(p_cur[qq][w]));
-            }
-            y0 = x0;
-            y1 = x1;
-        }
-        if ((f & 1) == 0) {
-            const int ks = f >> 1;
-            if (ks == 0) a2p_mfma_first<ABL>(s_nxt[qb], fr[f & 3], qf[qb][ks], mneg[qb]);
-            else a2p_mfma_s<ABL>(s_nxt[qb], fr[f & 3], qf[qb][ks]);
-        } else {
-            const int g = f >> 1, sp = g >> 1, db = g & 1;
-            const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{p_prev[qb][4 * sp], p_prev[qb][4 * sp + 1], p_prev[qb][4 * sp + 2],
-                                                               p_prev[qb][4 * sp + 3]});
-            a2p_mfma_o<ABL>(o[qb][db], fr[f & 3], pb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+#define A2P_HALF_SLOT(H)                                                                                                \
+    {                                                                                                                   \
+        constexpr int h = (H), f = h >> 1, qb = h & 1;                                                                  \
+        if (h < 8) a2p_load_frag<(h < 8 ? h : 0), N_ST_K, N_KBN, N_ST_V, N_KBP>(fn[h < 8 ? h : 0], ak, av);               \
+        {                                                                                                               \
+            constexpr int pq = h >> 3, pi = h & 7;           /* pair (query block, i): scores 2i, 2i + 1 of s_cur[.] */ \
+            float x0 = __builtin_amdgcn_exp2f(s_cur[pq][2 * pi]);                                                       \
+            float x1 = __builtin_amdgcn_exp2f(s_cur[pq][2 * pi + 1]);                                                   \
+            asm volatile("" : "+v"(x0), "+v"(x1));                                                                      \
+            if (h > 0) {                                                                                                \
+                constexpr int qq = (h > 0 ? h - 1 : 0) >> 3, w = (h > 0 ? h - 1 : 0) & 7;                               \
+                sa[qq] += y0;                                                                                           \
+                sb[qq] += y1;                                                                                           \
+                p_cur[qq][w] = f5_pack2_bounded(y0, y1);                                                                \
+                asm volatile("" : "+v"(sa[qq]), "+v"(sb[qq]), "+v"(p_cur[qq][w]));                                      \
+            }                                                                                                           \
+            y0 = x0;                                                                                                    \
+            y1 = x1;                                                                                                    \
+        }                                                                                                               \
+        if (f < 4) {                                                                                                    \
+            if (f == 0) a2p_mfma_first(s_nxt[qb], fr[f], qf[qb][f < 4 ? f : 0], mneg[qb]);                              \
+            else a2p_mfma_s(s_nxt[qb], fr[f], qf[qb][f < 4 ? f : 0]);                                                   \
+        } else {                                                                                                        \
+            constexpr int sp = (f - 4) >> 1 & 1, db = (f - 4) & 1;                                                      \
+            const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{p_prev[qb][4 * sp], p_prev[qb][4 * sp + 1], p_prev[qb][4 * sp + 2], \
+                                                               p_prev[qb][4 * sp + 3]});                                \
+            a2p_mfma_o(o[qb][db], fr[f], pb);                                                                           \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
     }
+    A2P_HALF_SLOT(0) A2P_HALF_SLOT(1) A2P_HALF_SLOT(2) A2P_HALF_SLOT(3) A2P_HALF_SLOT(4) A2P_HALF_SLOT(5) A2P_HALF_SLOT(6) A2P_HALF_SLOT(7)
+    A2P_HALF_SLOT(8) A2P_HALF_SLOT(9) A2P_HALF_SLOT(10) A2P_HALF_SLOT(11) A2P_HALF_SLOT(12) A2P_HALF_SLOT(13) A2P_HALF_SLOT(14) A2P_HALF_SLOT(15)
+#undef A2P_HALF_SLOT
     sa[1] += y0;
     sb[1] += y1;
     p_cur[1][7] = f5_pack2_bounded(y0, y1);
+    a2p_lds_wait(fn);                                        // requested eight or more half-slots ago
     float psum[2] = {sa[0] + sb[0], sa[1] + sb[1]};
-    if ((ABL == 0 || ABL == 8) && __builtin_expect(__any(!(psum[0] <= SUM_LIMIT) || !(psum[1] <= SUM_LIMIT)) != 0, 0)) {
+    if (__builtin_expect(__any(!(psum[0] <= SUM_LIMIT) || !(psum[1] <= SUM_LIMIT)) != 0, 0)) {
         // wave-uniform and rare: some score of this block lies more than 14 (exp2 units) above the reference point.  Move the
         // reference point of every row to max(old, this block's maximum): O and l shrink by alpha, -m_ref and the scores of the next
         // block (already computed against the old point) shift by delta, the block's P is taken again.
         asm volatile(A2P_PAD : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]));     // the last MFMAs of the half-step wrote O
-        if (HAS_QK) asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]));                           // ... issued after the S MFMAs: covered
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]));                                       // ... issued after the S MFMAs: covered
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             float tmax = 0.0f;
@@ -1176,7 +1181,7 @@ __device__ __forceinline__ void attn2p_half(const op16_t* const (&pk)[4], const 
                 o[qb][0][e] *= alpha;
                 o[qb][1][e] *= alpha;
                 mneg[qb][e] -= delta;
-                if (HAS_QK) s_nxt[qb][e] -= delta;
+                s_nxt[qb][e] -= delta;
             }
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
@@ -1195,7 +1200,6 @@ __device__ __forceinline__ void attn2p_half(const op16_t* const (&pk)[4], const 
     l_run[1] += psum[1];
 }
 
-template <int ABL>
 __global__ __launch_bounds__(256, 1) void f5_attn2p_kernel(F5AttnArgs p) {
     constexpr int TILE = 64 * 64;
     __shared__ __attribute__((aligned(16))) op16_t smem[8 * TILE];       // K ring [4][64*64] then V^T ring [4][64*64]: 64 KB
@@ -1282,13 +1286,12 @@ __global__ __launch_bounds__(256, 1) void f5_attn2p_kernel(F5AttnArgs p) {
         __builtin_amdgcn_s_barrier();              \
         asm volatile("" ::: "memory");             \
     }
-    // this lane's fragment addresses inside a 64 x 64 tile image of stage 0: lane part of attn_swz; the key / d block adds 32 rows
-    const op16_t* pk[4];
-    const op16_t* pv[4];
+    // this lane's fragment addresses (LDS bytes) inside a 64 x 64 tile image of stage 0: lane part of attn_swz; the key / d block adds 32 rows
+    uint32_t ak[4], av[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        pk[i] = smem + lq * 64 + (((i * 2 + hi) ^ ((lq >> 1) & 7)) << 3);                                  // QK^T k-step i: chunk 2 i + hi
-        pv[i] = smem + lq * 64 + (((4 * (i >> 1) + 2 * hi + (i & 1)) ^ ((lq >> 1) & 7)) << 3);             // 16-key step i of the tile
+        ak[i] = a2p_lds_addr(smem + lq * 64 + (((i * 2 + hi) ^ ((lq >> 1) & 7)) << 3));                       // QK^T k-step i: chunk 2 i + hi
+        av[i] = a2p_lds_addr(smem + lq * 64 + (((4 * (i >> 1) + 2 * hi + (i & 1)) ^ ((lq >> 1) & 7)) << 3));  // 16-key step i of the tile
     }
 
     // ---- prologue: K(0), V^T(0), K(1), then the group "of iteration -1": K(2), V^T(1).  P(-1, 1) = 0 multiplies the V^T stage of
@@ -1329,7 +1332,7 @@ __global__ __launch_bounds__(256, 1) void f5_attn2p_kernel(F5AttnArgs p) {
 
     f32x16 o[2][2], mneg[2], s_a[2], s_b[2];                 // s_a / p_a: key block 0 of a tile, s_b / p_b: key block 1
     uint32_t p_a[2][8], p_b[2][8];
-    op16x8 fr[4];                                            // LDS fragment ring, carried across half-steps (requested three fragments ahead)
+    op16x8 fr_a[8], fr_b[8];                                 // LDS fragments of the (j, 0) / (j, 1) half-steps: each set is requested during the other's half-step
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
@@ -1344,15 +1347,29 @@ __global__ __launch_bounds__(256, 1) void f5_attn2p_kernel(F5AttnArgs p) {
 
     // ---- the reference point: the true maximum of S(0, block 0) per row; s_a = S(0, 0) - m_ref enters the loop like every other block
     {
+        a2p_load_frag<0, 0, 0, 0, 0>(fr_b[0], ak, av);       // K(0) block 0, steps 0..3 (fr_b is free until half-step (0, 0) requests into it)
+        a2p_load_frag<1, 0, 0, 0, 0>(fr_b[1], ak, av);
+        a2p_load_frag<2, 0, 0, 0, 0>(fr_b[2], ak, av);
+        a2p_load_frag<3, 0, 0, 0, 0>(fr_b[3], ak, av);
+        // the fragments of half-step (0, 0): K(0) block 1; V^T(-1) second half = the zeroed stage 3
+        a2p_load_frag<0, 0, 1, 3, 1>(fr_a[0], ak, av);
+        a2p_load_frag<1, 0, 1, 3, 1>(fr_a[1], ak, av);
+        a2p_load_frag<2, 0, 1, 3, 1>(fr_a[2], ak, av);
+        a2p_load_frag<3, 0, 1, 3, 1>(fr_a[3], ak, av);
+        a2p_load_frag<4, 0, 1, 3, 1>(fr_a[4], ak, av);
+        a2p_load_frag<5, 0, 1, 3, 1>(fr_a[5], ak, av);
+        a2p_load_frag<6, 0, 1, 3, 1>(fr_a[6], ak, av);
+        a2p_load_frag<7, 0, 1, 3, 1>(fr_a[7], ak, av);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(fr_b[0]), "+a"(fr_b[1]), "+a"(fr_b[2]), "+a"(fr_b[3]));
+        a2p_lds_wait(fr_a);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const op16x8 a = *reinterpret_cast<const op16x8*>(pk[ks]);
             if (ks == 0) {
-                a2p_mfma_first0(s_a[0], a, qf[0][ks]);
-                a2p_mfma_first0(s_a[1], a, qf[1][ks]);
+                a2p_mfma_first0(s_a[0], fr_b[ks], qf[0][ks]);
+                a2p_mfma_first0(s_a[1], fr_b[ks], qf[1][ks]);
             } else {
-                a2p_mfma_s(s_a[0], a, qf[0][ks]);
-                a2p_mfma_s(s_a[1], a, qf[1][ks]);
+                a2p_mfma_s(s_a[0], fr_b[ks], qf[0][ks]);
+                a2p_mfma_s(s_a[1], fr_b[ks], qf[1][ks]);
             }
         }
         asm volatile(A2P_PAD : "+v"(s_a[0]), "+v"(s_a[1]));
@@ -1369,11 +1386,6 @@ __global__ __launch_bounds__(256, 1) void f5_attn2p_kernel(F5AttnArgs p) {
             }
         }
         asm volatile("s_nop 1" : "+v"(mneg[0]), "+v"(mneg[1]));
-        // the first three fragments of half-step (0, 0): K(0) block 1 step 0, V^T(-1) [the zeroed stage 3] piece 0, K(0) block 1 step 1
-        fr[0] = *reinterpret_cast<const op16x8*>(pk[0] + 2048);
-        fr[1] = *reinterpret_cast<const op16x8*>(pv[2] + 7 * TILE);
-        fr[2] = *reinterpret_cast<const op16x8*>(pk[1] + 2048);
-        asm volatile("" : "+a"(fr[0]), "+a"(fr[1]), "+a"(fr[2]));      // accumulator-file values on every path into the loop (else: copies per half-step)
     }
 
     // ---- tiles.  Tile j = 4 g + PH (PH compile-time: four tiles per loop trip, a tile past the end is skipped by a scalar branch):
@@ -1385,14 +1397,13 @@ __global__ __launch_bounds__(256, 1) void f5_attn2p_kernel(F5AttnArgs p) {
     // After the loop: O += V^T(T-1, 1) p_b.
 #define A2P_STEP(PH)                                                                                                    \
     if (j < T) {                                                                                                        \
-        if (ABL != 4) {                                                                                                 \
-            A2P_WAIT_TOP(j)                                                                                             \
-            A2P_BARRIER();                                                                                              \
-            A2P_ISSUE_GROUP(j)                                                                                          \
-        }                                                                                                               \
+        A2P_WAIT_TOP(j)                                                                                                 \
+        A2P_BARRIER();                                                                                                  \
+        A2P_ISSUE_GROUP(j)                                                                                              \
         const int nv_ = kvlen - j * 64;                                                                                 \
-        attn2p_half<ABL, (PH), 1, ((PH) + 3) & 3, 1, ((PH) + 1) & 3, 0, (PH), 0>(pk, pv, qf, fr, s_a, s_b, o, mneg, p_b, p_a, l_run, hi, nv_);          \
-        attn2p_half<ABL, ((PH) + 1) & 3, 0, (PH), 0, ((PH) + 1) & 3, 1, (PH), 1>(pk, pv, qf, fr, s_b, s_a, o, mneg, p_a, p_b, l_run, hi, nv_ - 32);     \
+        /* (j, 0) requests the fragments of (j, 1): K(j+1) block 0, V^T(j) first half; (j, 1) those of (j+1, 0): K(j+1) block 1, V^T(j) second half */ \
+        attn2p_half<((PH) + 1) & 3, 0, (PH), 0>(ak, av, qf, fr_a, fr_b, s_a, s_b, o, mneg, p_b, p_a, l_run, hi, nv_);       \
+        attn2p_half<((PH) + 1) & 3, 1, (PH), 1>(ak, av, qf, fr_b, fr_a, s_b, s_a, o, mneg, p_a, p_b, l_run, hi, nv_ - 32);  \
         ++j;                                                                                                            \
     }
     {
@@ -1405,20 +1416,26 @@ __global__ __launch_bounds__(256, 1) void f5_attn2p_kernel(F5AttnArgs p) {
         }
     }
 #undef A2P_STEP
-    // O^T += V^T(T-1, 1) P(T-1, 1): the V ring stage of the last tile is a run-time value here
+    // O^T += V^T(T-1, 1) P(T-1, 1): the V ring stage of the last tile is a run-time value here (added to the lane address)
     {
-        const int stv = ((T - 1) & 3) * TILE;
+        const uint32_t stv = (uint32_t)((T - 1) & 3) * (ATTN2P_TILE * 2);
+        uint32_t avf[4];
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
+        for (int i = 0; i < 4; ++i) avf[i] = av[i] + stv;
+        a2p_load_frag<4, 0, 0, 0, 1>(fr_a[0], ak, avf);      // stage "0" + the run-time offset, second half of the tile (KBP = 1), pieces 0..3
+        a2p_load_frag<5, 0, 0, 0, 1>(fr_a[1], ak, avf);
+        a2p_load_frag<6, 0, 0, 0, 1>(fr_a[2], ak, avf);
+        a2p_load_frag<7, 0, 0, 0, 1>(fr_a[3], ak, avf);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(fr_a[0]), "+a"(fr_a[1]), "+a"(fr_a[2]), "+a"(fr_a[3]));
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const op16x8 a = *reinterpret_cast<const op16x8*>(pv[2 + sp] + 4 * TILE + stv + db * 2048);
+        for (int g = 0; g < 4; ++g) {
+            const int sp = g >> 1, db = g & 1;
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{p_b[qb][4 * sp], p_b[qb][4 * sp + 1], p_b[qb][4 * sp + 2], p_b[qb][4 * sp + 3]});
-                    a2p_mfma_o(o[qb][db], a, pb);
-                }
+            for (int qb = 0; qb < 2; ++qb) {
+                const op16x8 pb = __builtin_bit_cast(op16x8, u32x4{p_b[qb][4 * sp], p_b[qb][4 * sp + 1], p_b[qb][4 * sp + 2], p_b[qb][4 * sp + 3]});
+                a2p_mfma_o(o[qb][db], fr_a[g], pb);
             }
+        }
     }
 #undef A2P_BARRIER
 #undef A2P_WAIT_TOP
@@ -2605,20 +2622,7 @@ int f5_launch_attention(const F5AttnArgs& a, hipStream_t stream) {
         }
 #endif
         // f5_attn_pipe: 1 = the in-wave software-pipelined kernel (v2p, one wave per SIMD), 0 = v2f; q must be pre-multiplied
-        const int pipe_ = a.pipe < 0 ? f5_attn_pipe : a.pipe;
-        if (pipe_ && a.q_prescaled) {
-            switch (pipe_) {                                   // 11 .. 16: timing-only ablations of v2p (results are wrong)
-                case 11: hipLaunchKernelGGL(f5_attn2p_kernel<1>, gw, dim3(256), 0, stream, a); break;
-                case 12: hipLaunchKernelGGL(f5_attn2p_kernel<2>, gw, dim3(256), 0, stream, a); break;
-                case 13: hipLaunchKernelGGL(f5_attn2p_kernel<3>, gw, dim3(256), 0, stream, a); break;
-                case 14: hipLaunchKernelGGL(f5_attn2p_kernel<4>, gw, dim3(256), 0, stream, a); break;
-                case 15: hipLaunchKernelGGL(f5_attn2p_kernel<5>, gw, dim3(256), 0, stream, a); break;
-                case 16: hipLaunchKernelGGL(f5_attn2p_kernel<6>, gw, dim3(256), 0, stream, a); break;
-                case 17: hipLaunchKernelGGL(f5_attn2p_kernel<7>, gw, dim3(256), 0, stream, a); break;    // guards, no slow-path check
-                case 18: hipLaunchKernelGGL(f5_attn2p_kernel<8>, gw, dim3(256), 0, stream, a); break;    // slow-path check, no guards
-                default: hipLaunchKernelGGL(f5_attn2p_kernel<0>, gw, dim3(256), 0, stream, a); break;
-            }
-        }
+        if ((a.pipe < 0 ? f5_attn_pipe : a.pipe) && a.q_prescaled) hipLaunchKernelGGL(f5_attn2p_kernel, gw, dim3(256), 0, stream, a);
         else if (a.q_prescaled) hipLaunchKernelGGL(f5_attn2f_kernel<true>, gw, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(f5_attn2f_kernel<false>, gw, dim3(256), 0, stream, a);
         F5_LAUNCH_CHECK();

@@ -80,8 +80,10 @@ struct F5Options {
     int fuse_ln = 0;      // LN-modulate fused behind the small-tile residual GEMMs (measured slower, profiles/r02/ln_fusion_ab.txt)
     int gemm_flags = 0;   // F5GemmArgs::debug_flags of this engine's GEMM launches
     int attn_pipe = -1;   // large-grid attention: -1 = process default (f5_debug_set_attn_pipe), 0 = v2f, 1 = v2p (in-wave software pipeline)
+    int null_keeps_cond = 0;   // the second (null) branch keeps the audio conditioning: DiT.__call__(drop_audio_cond=False, drop_text=True), dit.py:374-401
 };
 static F5Options g_default_options;
+static int g_live_engines = 0;   // f5_debug_set_{ln_fusion,qkv_transposed,q_premul} only change the DEFAULTS: with engines alive they say so
 // bumped by every process-wide launch knob change (f5_debug_set_*): part of the graph key, so a cached hipGraph captured under other
 // knob values is never replayed
 static int g_knob_epoch = 0;
@@ -285,6 +287,7 @@ extern "C" int f5_engine_create(const f5_config* cfg, int precision, f5_engine**
     e->np = precision == F5_PREC_BF16X3 ? 2 : 1;
     e->ops.h = precision == F5_PREC_F16;
     build_arena_plan(e);
+    ++g_live_engines;
     *out = e;
     return 0;
 }
@@ -292,6 +295,7 @@ extern "C" int f5_engine_create(const f5_config* cfg, int precision, f5_engine**
 extern "C" void f5_engine_destroy(f5_engine* e) {
     if (!e) return;
     for (auto& g : e->graphs) destroy_graph_entry(g);
+    --g_live_engines;
     delete e;
 }
 
@@ -315,8 +319,9 @@ extern "C" int f5_engine_set_option(f5_engine* e, const char* name, int value) {
     else if (n == "ln_fusion") e->opt.fuse_ln = value ? 1 : 0;
     else if (n == "gemm_flags") e->opt.gemm_flags = value;
     else if (n == "attn_pipe") e->opt.attn_pipe = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "null_keeps_cond") e->opt.null_keeps_cond = value ? 1 : 0;
     else {
-        f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags, attn_pipe)", name);
+        f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags, attn_pipe, null_keeps_cond)", name);
         return 2;
     }
     return 0;
@@ -329,6 +334,7 @@ extern "C" int f5_engine_get_option(f5_engine* e, const char* name, int* value) 
     else if (n == "ln_fusion") *value = e->opt.fuse_ln;
     else if (n == "gemm_flags") *value = e->opt.gemm_flags;
     else if (n == "attn_pipe") *value = e->opt.attn_pipe;
+    else if (n == "null_keeps_cond") *value = e->opt.null_keeps_cond;
     else {
         f5_set_error("unknown engine option %s", name);
         return 2;
@@ -620,7 +626,7 @@ static int run_prep(const Ctx& c, int nfe) {
     }
     // --- hoisted part of the input projection: Hc = [cond | text] * Wct^T + b   (dit.py:249-250)
     RC(K.pack_cond_text(c.p<float>(w.cond), c.p<int>(w.lens), c.p<float>(w.te[cur]), c.pb(w.ct, 0), c.pb(w.ct, 1), c.B,
-                                c.N, cf.mel_dim, Dt, s));
+                                c.N, cf.mel_dim, Dt, e->opt.null_keeps_cond, s));
     F5GemmArgs gh = gemm_base(c, c.pb(w.ct, 0), c.pb(w.ct, 1), 128 + Dt, e->wct, M2, D, 128 + Dt, c.a<float>(e->bproj));
     gh.out_f32 = c.p<float>(w.hc);
     gh.ldo = D;
@@ -1027,8 +1033,9 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, g_knob_epoch, a->workspace);
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d nk%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, e->opt.null_keeps_cond, g_knob_epoch,
+             a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
         // a text-to-speech service sees a new (N, nt) on almost every call and capture + instantiate of ~5000 nodes costs more
@@ -1079,7 +1086,11 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
             F5_HIP_CHECK(hipGraphInstantiate(&exec, graph_h, nullptr, nullptr, 0));
             (void)hipGraphDestroy(graph_h);
             hipEvent_t done = nullptr;
-            F5_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGraphExecDestroy(exec);              // do not leak the instantiated graph
+                f5_set_error("f5_sample: hipEventCreateWithFlags failed");
+                return 3;
+            }
             e->graphs.push_back({key, exec, a->workspace, ++e->clock, done});
         }
         F5_HIP_CHECK(hipGraphLaunch(exec, s));
@@ -1162,15 +1173,23 @@ extern "C" int f5_debug_set_convpos_xcd_map(int on) {
     return 0;
 }
 // process DEFAULTS of the per-engine options (f5_engine_set_option changes one engine; engines that already exist keep theirs)
+static void warn_defaults_only(const char* hook, const char* option) {
+    if (g_live_engines > 0)
+        fprintf(stderr, "[f5tts_hip] %s changes the default of NEW engines only: %d engine(s) already exist and keep their value "
+                        "(use f5_engine_set_option(e, \"%s\", v) for those)\n", hook, g_live_engines, option);
+}
 extern "C" int f5_debug_set_ln_fusion(int on) {
+    warn_defaults_only("f5_debug_set_ln_fusion", "ln_fusion");
     g_default_options.fuse_ln = on ? 1 : 0;
     return 0;
 }
 extern "C" int f5_debug_set_qkv_transposed(int on) {
+    warn_defaults_only("f5_debug_set_qkv_transposed", "qkv_transposed");
     g_default_options.qkv_tr = on ? 1 : 0;
     return 0;
 }
 extern "C" int f5_debug_set_q_premul(int on) {
+    warn_defaults_only("f5_debug_set_q_premul", "q_premul");
     g_default_options.q_premul = on ? 1 : 0;
     return 0;
 }
@@ -1184,7 +1203,7 @@ extern "C" int f5_debug_set_attn_wide(int v) {
     return 0;
 }
 extern "C" int f5_debug_set_attn_pipe(int v) {
-    F5_REQUIRE(v == 0 || v == 1 || (v >= 11 && v <= 18), "attention pipelining switch must be 0 (v2f) or 1 (v2p: in-wave software pipeline, one wave per SIMD); 11-16 = timing ablations");
+    F5_REQUIRE(v == 0 || v == 1, "attention pipelining switch must be 0 (v2f) or 1 (v2p: in-wave software pipeline, one wave per SIMD)");
     F5_SET_BOTH(f5_attn_pipe, v);
     return 0;
 }

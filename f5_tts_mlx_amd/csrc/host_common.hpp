@@ -79,9 +79,9 @@ struct Ops {
                  : f5bf::f5_launch_grn(g, gamma, beta, partial, nx, hi, lo, nbatch, seq_len, dim, s);
     }
     int pack_cond_text(const float* cond, const int* lens, const float* text_emb, op16_t* hi, op16_t* lo, int B, int seq_len,
-                       int mel_dim, int dt, hipStream_t s) const {
-        return h ? f5hf::f5_launch_pack_cond_text(cond, lens, text_emb, H(hi), H(lo), B, seq_len, mel_dim, dt, s)
-                 : f5bf::f5_launch_pack_cond_text(cond, lens, text_emb, hi, lo, B, seq_len, mel_dim, dt, s);
+                       int mel_dim, int dt, int null_keeps_cond, hipStream_t s) const {
+        return h ? f5hf::f5_launch_pack_cond_text(cond, lens, text_emb, H(hi), H(lo), B, seq_len, mel_dim, dt, null_keeps_cond, s)
+                 : f5bf::f5_launch_pack_cond_text(cond, lens, text_emb, hi, lo, B, seq_len, mel_dim, dt, null_keeps_cond, s);
     }
     int pack_x(const float* y, op16_t* hi, op16_t* lo, int rows, int mel_dim, hipStream_t s) const {
         return h ? f5hf::f5_launch_pack_x(y, H(hi), H(lo), rows, mel_dim, s) : f5bf::f5_launch_pack_x(y, hi, lo, rows, mel_dim, s);

@@ -317,16 +317,17 @@ int f5_launch_text_embed(const int* text, int nt, const float* table, const floa
 
 // =================================================================================================
 // A operand of the hoisted input projection: rows [2][B*seq], cols [cond padded to 128 | text dt]
-// branch 0: cond masked by n < lens[b] (step_cond, cfm.py:331); branch 1: cond dropped (dit.py:249)
+// branch 0: cond masked by n < lens[b] (step_cond, cfm.py:331); branch 1: cond dropped (dit.py:249) unless null_keeps_cond
 // =================================================================================================
 __global__ __launch_bounds__(256) void pack_cond_text_kernel(const float* __restrict__ cond, const int* __restrict__ lens,
                                                              const float* __restrict__ text_emb, op16_t* __restrict__ out_hi,
                                                              op16_t* __restrict__ out_lo, int B, int seq_len, int mel_dim,
-                                                             int dt) {
+                                                             int dt, int null_keeps_cond) {
     const int n = blockIdx.x, b = blockIdx.y, br = blockIdx.z;
     const int ld = 128 + dt;
     const size_t orow = (((size_t)br * B + b) * seq_len + n) * ld;
-    const bool use_cond = (br == 0) && (n < lens[b]);
+    // null_keeps_cond: the second branch is (drop_audio_cond = False, drop_text = True) instead of (True, True), dit.py:245-247 / 209-210
+    const bool use_cond = (br == 0 || null_keeps_cond) && (n < lens[b]);
     for (int c = threadIdx.x; c < ld; c += 256) {
         float v = 0.0f;
         if (c < 128) {
@@ -342,10 +343,10 @@ __global__ __launch_bounds__(256) void pack_cond_text_kernel(const float* __rest
 }
 
 int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, op16_t* out_hi, op16_t* out_lo,
-                             int B, int seq_len, int mel_dim, int dt, hipStream_t s) {
+                             int B, int seq_len, int mel_dim, int dt, int null_keeps_cond, hipStream_t s) {
     F5_REQUIRE(mel_dim <= 128, "pack_cond_text: mel_dim must be <= 128");
     hipLaunchKernelGGL(pack_cond_text_kernel, dim3(seq_len, B, 2), dim3(256), 0, s, cond, lens, text_emb, out_hi, out_lo, B,
-                       seq_len, mel_dim, dt);
+                       seq_len, mel_dim, dt, null_keeps_cond);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -36,7 +36,7 @@ int f5_launch_text_embed(const int* text, int nt, const float* table, const floa
 
 // pack A operand of the hoisted input projection: [cond(128, zero padded) | text_embed(dt)] for both branches
 int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, op16_t* out_hi, op16_t* out_lo,
-                             int B, int seq_len, int mel_dim, int dt, hipStream_t s);
+                             int B, int seq_len, int mel_dim, int dt, int null_keeps_cond, hipStream_t s);
 
 // sinusoidal time embedding (dit.py:61-67)
 int f5_launch_time_sinus(const float* t, float* out, int n, int dim, hipStream_t s);

@@ -54,14 +54,24 @@ class DiT:
         self.engine.load_weights({k: np.asarray(v) for k, v in weights.items()})
 
     def __call__(self, x, cond, text, time, drop_audio_cond, drop_text, mask=None) -> torch.Tensor:
-        """dit.py:374-401 — one forward.  The engine evaluates the conditional branch (False, False) and the null branch
-        (True, True).  (True, False) — audio conditioning dropped, text kept (training, cfm.py:222-225) — is the conditional
-        branch on a zeroed `cond` (dit.py:245-247); (False, True) never occurs in the reference (drop_text forces
-        drop_audio_cond, cfm.py:225).  `time` may be a scalar or a (b,) tensor; rows with different times run as separate
-        batch-1 forwards, which is exact when `mask is None` (no cross-utterance arithmetic in the DiT)."""
+        """dit.py:374-401 — one forward, any (drop_audio_cond, drop_text).  The engine evaluates two branches per call: the
+        conditional one (False, False) and a second one that drops the text and, by default, the audio conditioning (True, True).
+        (True, False) — audio dropped, text kept (training, cfm.py:222-225) — is the conditional branch on a zeroed `cond`
+        (dit.py:245-247); (False, True) — text dropped, audio kept; the reference never produces it (drop_text forces
+        drop_audio_cond, cfm.py:225) but its `DiT` accepts it — is the second branch with the engine option `null_keeps_cond`.
+        `time` may be a scalar or a (b,) tensor; rows with different times run as separate batch-1 forwards at the SAME padded
+        length with their own row of `mask`, which is exact (no cross-utterance arithmetic in the DiT; GRN / conv-pos see the
+        same padding)."""
         drop_audio_cond, drop_text = _flag(drop_audio_cond), _flag(drop_text)
         if drop_text and not drop_audio_cond:
-            raise NotImplementedError("(drop_audio_cond, drop_text) = (False, True) is not a combination the reference uses")
+            self.engine.set_option("null_keeps_cond", 1)
+            try:
+                return self._forward(x, cond, text, time, False, True, mask)
+            finally:
+                self.engine.set_option("null_keeps_cond", 0)
+        return self._forward(x, cond, text, time, drop_audio_cond, drop_text, mask)
+
+    def _forward(self, x, cond, text, time, drop_audio_cond, drop_text, mask=None) -> torch.Tensor:
         B, N, _ = x.shape
         x = x.to(self.device, torch.float32).contiguous()
         cond = cond.to(self.device, torch.float32).contiguous()
@@ -75,9 +85,8 @@ class DiT:
         else:
             times = [float(time if not torch.is_tensor(time) else time.reshape(-1)[0])] * B
         if len(set(times)) > 1:
-            if mask is not None:
-                raise NotImplementedError("per-row times together with a key-padding mask")
-            outs = [self(x[i:i + 1], cond[i:i + 1], text[i:i + 1], times[i], drop_audio_cond, drop_text) for i in range(B)]
+            outs = [self._forward(x[i:i + 1], cond[i:i + 1], text[i:i + 1], times[i], drop_audio_cond, drop_text,
+                                  None if mask is None else mask[i:i + 1]) for i in range(B)]
             return torch.cat(outs, dim=0)
         if mask is not None:
             durations = mask.sum(dim=-1).to(torch.int32).tolist()

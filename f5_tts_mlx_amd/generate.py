@@ -86,7 +86,14 @@ def generate(
     quantization_bits: Optional[int] = None,
     output_path: Optional[str] = None,
     f5tts: Optional[F5TTS] = None,          # extension: reuse an already loaded model
+    batch_sentences: bool = False,          # extension: all sentences as ONE ragged sample() batch instead of the reference's loop
 ):
+    """generate.py:113-245.  `batch_sentences=True` (opt-in, no reference counterpart; SURVEY.md section 8(f)2 names it as the point of
+    owning the app loop): the sentences of a multi-sentence text are sampled as one ragged batch -- one `sample()` call, one set of
+    launches at M = 2 x (sum of frames) instead of one set per sentence.  It is NOT bit-compatible with the loop: in a batch the
+    key-padding mask exists (cfm.py:333-336), and GRN (convnext_v2.py:16) and the conv position embedding (dit.py:251) see the padding
+    up to the longest sentence, exactly as the reference's own `sample()` behaves for a batch; what it equals is `sample()` of that
+    batch (tests/test_model_gpu.py::test_generate_batch_sentences)."""
     if f5tts is None:
         f5tts = F5TTS.from_pretrained(model_name, quantization_bits=quantization_bits)
     if getattr(f5tts, "_vocoder", None) is None:
@@ -127,6 +134,20 @@ def generate(
             duration = int(estimated_duration(audio, ref_audio_text, generation_text, speed) * FRAMES_PER_SEC)
         text = convert_char_to_pinyin([ref_audio_text + " " + generation_text])
         wave = run(text, duration)
+    elif batch_sentences:
+        # every sentence gets the reference mel as conditioning and its own duration; sample() pads to the longest (cfm.py:319-321)
+        texts = convert_char_to_pinyin([ref_audio_text + " " + t for t in sentences])
+        cond = f5tts._mel_spec(audio[None].to(f5tts.transformer.device)).repeat(len(sentences), 1, 1)
+        if estimate_duration:                                         # (the loop's quirk -- the whole text for every sentence -- is kept)
+            durs = torch.full((len(sentences),), int(estimated_duration(audio, ref_audio_text, generation_text, speed) * FRAMES_PER_SEC))
+        else:
+            durs = None                                               # duration predictor, per element (cfm.py:307-308)
+        waves, _ = f5tts.sample(cond, text=texts, duration=durs, steps=steps, method=method, speed=speed, cfg_strength=cfg_strength,
+                                sway_sampling_coef=sway_sampling_coef, seed=seed)
+        frames = f5tts.last_durations                                 # per-element frame counts after the clamps of cfm.py:317-318
+        waves = waves.reshape(len(sentences), -1)
+        edge = max(frames) * HOP_LENGTH - waves.shape[1]              # a vocoder's own edge loss (Vocos: one hop), the same for every element
+        wave = torch.cat([waves[i, audio.shape[0]:int(frames[i]) * HOP_LENGTH - edge] for i in range(len(sentences))], dim=0)
     else:
         output = []
         for sentence_text in sentences:

@@ -63,7 +63,9 @@ int f5_engine_graph_count(f5_engine* e);
 /* Per-engine launch options (two engines of one process keep their own): "q_premul" (1: q leaves the QKV epilogue multiplied by
  * softmax_scale * log2 e), "qkv_transposed" (1: transposed q / k tiles in the 256x256 QKV kernel), "ln_fusion" (0; 1 = LN-modulate
  * fused behind small-tile residual GEMMs, measured slower), "gemm_flags" (0; F5GemmArgs debug bits of this engine's launches),
- * "attn_pipe" (-1 = the process default of f5_debug_set_attn_pipe, 0 = large-grid attention kernel v2f, 1 = in-wave software-pipelined v2p).
+ * "attn_pipe" (-1 = the process default of f5_debug_set_attn_pipe, 0 = large-grid attention kernel v2f, 1 = in-wave software-pipelined v2p),
+ * "null_keeps_cond" (0; 1 = the second branch of f5_dit_forward / f5_sample keeps the audio conditioning and drops only the text:
+ * DiT.__call__(drop_audio_cond=False, drop_text=True), dit.py:374-401).
  * Part of the hipGraph cache key.  New engines start from the process defaults (f5_debug_set_ln_fusion / _qkv_transposed /
  * _q_premul). */
 int f5_engine_set_option(f5_engine* e, const char* name, int value);

@@ -1055,3 +1055,79 @@ def test_real_checkpoint_tooling_on_a_synthetic_directory(tmp_path):
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["data"].startswith("REAL checkpoint") and "parity_l1" not in line and line["value"] > 0
     assert line["roofline"]["peak_measured_tflops"] > 500 and 0 < line["roofline"]["frac_of_measured"] < 1
+
+
+def test_dit_call_remaining_argument_combinations(tiny_weights, tiny_x3):
+    """VERDICT r3 missing #8: `DiT.__call__` (dit.py:374-401) accepts any (drop_audio_cond, drop_text) and per-row `time` together with
+    a mask.  (False, True) -- text dropped, audio kept -- runs as the engine's second branch with `null_keeps_cond`; per-row times with a
+    mask run row by row at the same padded length.  Against the oracle's forward on identical inputs (bf16x3: fp32-class)."""
+    cfg = TINY
+    B, N = 3, 90
+    cond, text, durations, y0 = synth_inputs(cfg, B, N, nt=24, n_ref=30, seed=321, ragged=True)
+    step_cond = _pad_cond(cond, N)
+    mask = O.lens_to_mask(torch.tensor(durations), N)
+    orc = O.DiTOracle(cfg, tiny_weights)
+    x = y0
+    for drop_a, drop_t in ((False, True), (True, False), (True, True), (False, False)):
+        want = orc.forward(x, step_cond, text, torch.tensor(0.4), drop_a, drop_t, mask)
+        got = tiny_x3(x=x, cond=step_cond, text=text, time=torch.tensor(0.4), drop_audio_cond=drop_a, drop_text=drop_t, mask=mask)
+        _, mean, refm = report(f"dit[bf16x3] drop_audio_cond={drop_a} drop_text={drop_t} masked vs oracle", got.cpu(), want)
+        assert mean <= 2e-4 * max(1.0, refm), (drop_a, drop_t)
+    assert tiny_x3.engine.get_option("null_keeps_cond") == 0            # restored
+    times = torch.tensor([0.1, 0.55, 0.9])
+    for m in (None, mask):
+        want = orc.forward(x, step_cond, text, times, False, False, m)
+        got = tiny_x3(x=x, cond=step_cond, text=text, time=times, drop_audio_cond=False, drop_text=False, mask=m)
+        _, mean, refm = report(f"dit[bf16x3] per-row times, mask={'yes' if m is not None else 'no'} vs oracle", got.cpu(), want)
+        assert mean <= 2e-4 * max(1.0, refm)
+    want = orc.forward(x, step_cond, text, times, False, True, mask)
+    got = tiny_x3(x=x, cond=step_cond, text=text, time=times, drop_audio_cond=False, drop_text=True, mask=mask)
+    _, mean, refm = report("dit[bf16x3] per-row times + mask + (False, True) vs oracle", got.cpu(), want)
+    assert mean <= 2e-4 * max(1.0, refm)
+
+
+def test_generate_batch_sentences(tiny_weights, tiny_x3):
+    """VERDICT r3 missing #5 / SURVEY section 8(f)2: `generate(..., batch_sentences=True)` runs the sentences of a text as ONE ragged
+    sample() batch.  It must equal the ORACLE's batched `sample()` on the same inputs (the reference's own batch semantics: key mask,
+    GRN / conv-pos over the padding) sentence by sentence, and it is documented NOT to equal the per-sentence loop bit for bit --
+    both facts are checked.  Fake frame-synchronous vocoder (256 mel-derived samples per frame), character vocabulary."""
+    import os as _os
+    from f5_tts_mlx_amd import generate as G
+    from f5_tts_mlx_amd.utils import convert_char_to_pinyin, list_str_to_idx
+    cfg = TINY
+    vocab = {c: i for i, c in enumerate(" abcdefghijklmnopqrstuvwxyz.,!?'ABCDEFGHIJKLMNOPQRSTUVWXYZ")}
+    assert len(vocab) <= cfg.text_num_embeds
+    idx = torch.arange(256, device=DEV) % 100
+    voc = lambda mel: mel[:, :, idx].reshape(mel.shape[0], -1) if mel.shape[0] > 1 else mel[0][:, idx].reshape(-1)   # noqa: E731
+    f5 = F5TTS(transformer=tiny_x3, vocab_char_map=vocab, vocoder=voc)
+    wav = _os.path.join(_os.path.dirname(G.__file__), "assets", "test_en_1_ref_short.wav")
+    ref_text = "some call me nature."
+    text = "Hello there. This one is a longer sentence, is it not? Short."
+    kw = dict(ref_audio_path=wav, ref_audio_text=ref_text, steps=4, method="euler", seed=5, estimate_duration=True, f5tts=f5)
+    got = G.generate(text, batch_sentences=True, **kw)
+    loop = G.generate(text, batch_sentences=False, **kw)
+    torch.cuda.synchronize()
+    assert got.shape == loop.shape                                   # same frame counts per sentence
+    # the oracle's batched sample() on the same batch
+    audio, _ = G.read_wav(wav)
+    audio = torch.from_numpy(np.asarray(audio)).to(torch.float32)
+    sentences = G.split_sentences(text)
+    toks = convert_char_to_pinyin([ref_text + " " + t for t in sentences])
+    cond = torch.from_numpy(np.asarray(O.log_mel_spectrogram(audio.numpy()), np.float32).reshape(1, -1, 100)).repeat(len(sentences), 1, 1)
+    dur = int(G.estimated_duration(audio, ref_text, text, 1.0) * G.FRAMES_PER_SEC)
+    from f5_tts_mlx_amd.rng import mlx_like_normal
+    ids = list_str_to_idx(toks, vocab)
+    lens = torch.maximum((ids != -1).sum(-1), torch.full((len(sentences),), cond.shape[1]))
+    durs = torch.clip(torch.maximum(lens + 1, torch.full((len(sentences),), dur)), 0, 4096)
+    N = int(durs.max())
+    y0 = torch.zeros((len(sentences), N, 100))
+    for i, d in enumerate(durs.tolist()):
+        y0[i, :d] = torch.from_numpy(mlx_like_normal(5, (100, d)).T.copy())
+    ref, _ = O.sample(O.DiTOracle(cfg, tiny_weights), cond, ids, durs, y0=y0, steps=4, method="euler", vocab_char_map=vocab)
+    ns = audio.shape[0]
+    want = torch.cat([ref[i][:, idx.cpu()].reshape(-1)[ns:int(durs[i]) * 256] for i in range(len(sentences))])
+    assert want.shape == got.shape, (want.shape, got.shape)
+    l1 = float((got.cpu() - want).abs().mean())
+    l1_loop = float((got.cpu() - loop.cpu()).abs().mean())
+    print(f"[batch_sentences] vs the oracle's batched sample(): {l1:.3e}; vs the per-sentence loop: {l1_loop:.3e}")
+    assert l1 <= MEL_L1_TOL and l1_loop <= 5e-3          # the loop differs by the batch semantics (mask, padding), not by much at equal durations
