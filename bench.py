@@ -526,7 +526,7 @@ def main():
         else:
             kernels, sym = kernel_rooflines(args.precision, device, B)
         dominant = max(kernels, key=lambda k: k.get("share_of_block", 1.0))
-        if sym.get("f5_gemm*_kernel<EPI_RESID_GATE>", 0.0) >= max(sym.values(), default=0.0):
+        if sym and sym.get("f5_gemm*_kernel<EPI_RESID_GATE>", 0.0) >= max(sym.values(), default=0.0):
             # the residual-update GEMM symbol (out-proj + FF2 launches) leads the rocprof CSV: report its heavier instance
             dominant = max((k for k in kernels if k["key"] in ("out_proj_gemm", "ff2_gemm")), key=lambda k: k["share_of_block"])
         rec = {

@@ -138,7 +138,9 @@ def generate(
         # every sentence gets the reference mel as conditioning and its own duration; sample() pads to the longest (cfm.py:319-321)
         texts = convert_char_to_pinyin([ref_audio_text + " " + t for t in sentences])
         cond = f5tts._mel_spec(audio[None].to(f5tts.transformer.device)).repeat(len(sentences), 1, 1)
-        if estimate_duration:                                         # (the loop's quirk -- the whole text for every sentence -- is kept)
+        # (the whole text for every sentence, like the loop's first sentence; the loop's carried-over `duration` -- frames x 93.75
+        # again from the second sentence on, generate.py:203-208 -- is a quirk of the loop and is not reproduced here)
+        if estimate_duration:
             durs = torch.full((len(sentences),), int(estimated_duration(audio, ref_audio_text, generation_text, speed) * FRAMES_PER_SEC))
         else:
             durs = None                                               # duration predictor, per element (cfm.py:307-308)

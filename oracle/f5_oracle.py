@@ -218,10 +218,16 @@ class DiTOracle:
     """
 
     def __init__(self, cfg, weights: Dict[str, np.ndarray], dtype=torch.float32, emulate_bf16: bool = False,
-                 emulate_mxfp8: bool = False, emulate_f16: bool = False):
+                 emulate_mxfp8: bool = False, emulate_f16: bool = False, ln_fold: bool = False):
         """emulate_bf16: GEMM / attention operands rounded to bf16 like the engine's `bf16` mode.  emulate_mxfp8: the engine's
         `mxfp8` mode (BASELINE configs[4], no reference counterpart): as bf16, except that both operands of the four
         per-block linears (to_q/k/v, to_out, ff.0, ff.2) are MX-fp8 (oracle/mx_oracle.py), weights from their bf16 copies."""
+        # ln_fold (numerics STUDY of a fusion the engine does not ship, DESIGN.md section 12): the two LayerNorm-modulate steps of a
+        # block are folded algebraically into the GEMM that consumes them -- the GEMM's A operand is the residual stream x itself
+        # rounded to 16 bits, its weight is W (1 + scale) rounded to 16 bits, and the normalisation arrives in the epilogue:
+        #   LN(x) (1 + s) + b) W^T  =  rstd (x W'^T) - rstd mu c1 + c2,   W' = W (1 + s),  c1 = W' 1,  c2 = W b + bias
+        # (mean / rstd from the fp32 x).  Only meaningful together with an emulate_* operand rounding.
+        self.ln_fold = ln_fold
         self.cfg = cfg
         self.dtype = dtype
         self.emu = emulate_bf16 or emulate_mxfp8 or emulate_f16
@@ -339,14 +345,29 @@ class DiTOracle:
         x = self.linear(torch.cat((x, cond, text_emb), dim=-1), "transformer.input_embed.proj")
         return self.conv_pos_embed(x) + x
 
-    def attention(self, x: Tensor, i: int, mask: Optional[Tensor], rope: Tensor) -> Tensor:
-        """Attention (dit.py:127-175)."""
+    def folded_linear(self, x: Tensor, scale: Tensor, shift: Tensor, name: str, eps: float = 1e-6) -> Tensor:
+        """(LN(x) (1 + scale) + shift) W^T + bias with the modulation folded into the weight (ln_fold, see __init__): x (b, n, d) fp32
+        residual stream, scale / shift (b, d)."""
+        w, bias = self.w[name + ".weight"], self.w[name + ".bias"]
+        mu = x.mean(dim=-1, keepdim=True)
+        rstd = torch.rsqrt(((x - mu) ** 2).mean(dim=-1, keepdim=True) + eps)
+        wp = self._r(w[None] * (1 + scale)[:, None, :])                        # (b, out, in), rounded like a weight operand
+        acc = torch.einsum("bnk,bok->bno", self._r(x), wp)                     # A operand = the rounded residual stream
+        c1 = wp.sum(dim=-1)                                                    # (b, out)
+        c2 = shift @ w.T + bias                                                # (b, out), fp32
+        return rstd * acc - (rstd * mu) * c1[:, None, :] + c2[:, None, :]
+
+    def attention(self, x: Tensor, i: int, mask: Optional[Tensor], rope: Tensor, fold=None) -> Tensor:
+        """Attention (dit.py:127-175).  fold = (x_residual, scale, shift): ln_fold study, `x` is then unused for q / k / v."""
         p = f"transformer.transformer_blocks.{i}.attn."
         b, n, _ = x.shape
         H = self.cfg.heads
-        q = self.linear(x, p + "to_q").reshape(b, n, H, -1).transpose(1, 2)
-        k = self.linear(x, p + "to_k").reshape(b, n, H, -1).transpose(1, 2)
-        v = self.linear(x, p + "to_v").reshape(b, n, H, -1).transpose(1, 2)
+        if fold is not None:
+            q, k, v = (self.folded_linear(fold[0], fold[1], fold[2], p + nm).reshape(b, n, H, -1).transpose(1, 2) for nm in ("to_q", "to_k", "to_v"))
+        else:
+            q = self.linear(x, p + "to_q").reshape(b, n, H, -1).transpose(1, 2)
+            k = self.linear(x, p + "to_k").reshape(b, n, H, -1).transpose(1, 2)
+            v = self.linear(x, p + "to_v").reshape(b, n, H, -1).transpose(1, 2)
         q = apply_rotary_pos_emb(q, rope)
         k = apply_rotary_pos_emb(k, rope)
         scale = 1.0 / math.sqrt(self.cfg.dim_head)
@@ -372,6 +393,11 @@ class DiTOracle:
         p = f"transformer.transformer_blocks.{i}."
         emb = self.linear(F.silu(t), p + "attn_norm.linear", lowp=False)
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = emb.chunk(6, dim=1)
+        if self.ln_fold and self.emu:
+            x = x + gate_msa[:, None] * self.attention(x, i, mask, rope, fold=(x, scale_msa, shift_msa))
+            h = _gelu_tanh(self.folded_linear(x, scale_mlp, shift_mlp, p + "ff.ff.layers.0.layers.0"))
+            ff = self.linear(h, p + "ff.ff.layers.2")
+            return x + gate_mlp[:, None] * ff
         norm = self.layer_norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
         x = x + gate_msa[:, None] * self.attention(norm, i, mask, rope)
         norm = self.layer_norm(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]

@@ -43,6 +43,7 @@ def inputs(i: int = 0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--emulate", default=None, choices=[None, "bf16", "f16"], help="report operand-rounding drift instead of writing")
+    ap.add_argument("--ln-fold", action="store_true", help="numerics study: LN-modulate folded algebraically into the consumer GEMMs (oracle ln_fold)")
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     ns = ap.parse_args()
     torch.set_num_threads(ns.threads)
@@ -51,6 +52,8 @@ def main():
     assert cond.shape == (REF_SAMPLES // 256, 100)
     w = synthetic_weights(F5TTS_335M, seed=42)
     kw = {} if ns.emulate is None else {f"emulate_{ns.emulate}": True}
+    if ns.ln_fold:
+        kw["ln_fold"] = True
     orc = O.DiTOracle(F5TTS_335M, w, **kw)
     t0 = time.time()
     out, traj = O.sample(orc, torch.from_numpy(cond)[None], torch.from_numpy(text)[None], N_FRAMES, y0=torch.from_numpy(y0)[None],
@@ -64,7 +67,7 @@ def main():
     else:
         g = np.load(OUT)
         for k, v in (("out", out[0]), ("traj_8", traj[8, 0]), ("traj_16", traj[16, 0]), ("traj_24", traj[24, 0])):
-            print(f"[{ns.emulate}] mel L1 vs fp32 oracle, {k}: {float(np.abs(v.numpy() - g[k]).mean()):.3e}")
+            print(f"[{ns.emulate}{' + ln_fold' if ns.ln_fold else ''}] mel L1 vs fp32 oracle, {k}: {float(np.abs(v.numpy() - g[k]).mean()):.3e}")
 
 
 if __name__ == "__main__":

@@ -92,8 +92,9 @@ def test_dit_call_signature(tiny_bf16, tiny_weights):
     a = tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=True, drop_text=False)
     b = tiny_bf16(x=y0, cond=torch.zeros_like(sc), text=text, time=torch.tensor(0.5), drop_audio_cond=False, drop_text=False)
     assert torch.equal(a, b) and float((a - out).abs().mean()) > 1e-4
-    with pytest.raises(NotImplementedError):
-        tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=False, drop_text=True)
+    # text dropped, audio kept: accepted since round 4 (test_dit_call_remaining_argument_combinations checks it against the oracle)
+    c = tiny_bf16(x=y0, cond=sc, text=text, time=torch.tensor(0.5), drop_audio_cond=False, drop_text=True)
+    assert c.shape == out.shape and float((c - out).abs().mean()) > 1e-4 and float((c - null).abs().mean()) > 1e-4
 
 
 @pytest.mark.parametrize("method,steps", [("euler", 8), ("midpoint", 5), ("rk4", 4)])
@@ -1107,7 +1108,9 @@ def test_generate_batch_sentences(tiny_weights, tiny_x3):
     got = G.generate(text, batch_sentences=True, **kw)
     loop = G.generate(text, batch_sentences=False, **kw)
     torch.cuda.synchronize()
-    assert got.shape == loop.shape                                   # same frame counts per sentence
+    # the loop keeps the reference's carried-over `duration` (generate.py:203-208: from the second sentence on the FRAME count of the
+    # previous one is multiplied by 93.75 again and clipped to 4096); the batch gives every sentence the estimate itself, so only the
+    # first sentence has the same length in both
     # the oracle's batched sample() on the same batch
     audio, _ = G.read_wav(wav)
     audio = torch.from_numpy(np.asarray(audio)).to(torch.float32)
@@ -1128,6 +1131,7 @@ def test_generate_batch_sentences(tiny_weights, tiny_x3):
     want = torch.cat([ref[i][:, idx.cpu()].reshape(-1)[ns:int(durs[i]) * 256] for i in range(len(sentences))])
     assert want.shape == got.shape, (want.shape, got.shape)
     l1 = float((got.cpu() - want).abs().mean())
-    l1_loop = float((got.cpu() - loop.cpu()).abs().mean())
-    print(f"[batch_sentences] vs the oracle's batched sample(): {l1:.3e}; vs the per-sentence loop: {l1_loop:.3e}")
-    assert l1 <= MEL_L1_TOL and l1_loop <= 5e-3          # the loop differs by the batch semantics (mask, padding), not by much at equal durations
+    n1 = int(durs[0]) * 256 - ns
+    l1_loop = float((got.cpu()[:n1] - loop.cpu()[:n1]).abs().mean())
+    print(f"[batch_sentences] vs the oracle's batched sample(): {l1:.3e}; first sentence vs the per-sentence loop's: {l1_loop:.3e}")
+    assert l1 <= MEL_L1_TOL and l1_loop <= 5e-3          # batch semantics (mask, padding) vs a batch-1 call: close, not identical
