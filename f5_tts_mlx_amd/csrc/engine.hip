@@ -60,6 +60,8 @@ struct Workspace {
     size_t hc, x;
     size_t xb[2], c1[2], h[2], qk[2], vt[2], ao[2], ffh[2];
     size_t h8, h8s, ao8, ao8s, ffh8, ffh8s;   // precision mxfp8: block-GEMM A operands as e4m3 + E8M0
+    size_t lnstats;                // LN fold: per row and 64-column slice (sum, sum of squares) of the residual stream, [M2][D / 64][2] floats
+    size_t foldc[2];               // LN fold: c1, c2 tables, [nfe][L][3 D + FF] floats each
     size_t vt_bytes;
 };
 
@@ -80,6 +82,8 @@ struct F5Options {
     int fuse_ln = 0;      // LN-modulate fused behind the small-tile residual GEMMs (measured slower, profiles/r02/ln_fusion_ab.txt)
     int gemm_flags = 0;   // F5GemmArgs::debug_flags of this engine's GEMM launches
     int attn_pipe = -1;   // large-grid attention: -1 = process default (f5_debug_set_attn_pipe), 0 = v2f, 1 = v2p (in-wave software pipeline)
+    int ln_fold = 0;      // LN-modulate folded into the GEMMs around it (gemm.hpp fold_*): -1 = wherever the four block GEMMs run on the staged
+                          // kernels (one-pass operand modes, batch >= 4), 0 = never, 1 = required (fails loudly where it cannot run)
     int null_keeps_cond = 0;   // the second (null) branch keeps the audio conditioning: DiT.__call__(drop_audio_cond=False, drop_text=True), dit.py:374-401
 };
 static F5Options g_default_options;
@@ -320,8 +324,9 @@ extern "C" int f5_engine_set_option(f5_engine* e, const char* name, int value) {
     else if (n == "gemm_flags") e->opt.gemm_flags = value;
     else if (n == "attn_pipe") e->opt.attn_pipe = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "null_keeps_cond") e->opt.null_keeps_cond = value ? 1 : 0;
+    else if (n == "ln_fold") e->opt.ln_fold = value < 0 ? -1 : (value ? 1 : 0);
     else {
-        f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags, attn_pipe, null_keeps_cond)", name);
+        f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags, attn_pipe, null_keeps_cond, ln_fold)", name);
         return 2;
     }
     return 0;
@@ -335,6 +340,7 @@ extern "C" int f5_engine_get_option(f5_engine* e, const char* name, int* value) 
     else if (n == "gemm_flags") *value = e->opt.gemm_flags;
     else if (n == "attn_pipe") *value = e->opt.attn_pipe;
     else if (n == "null_keeps_cond") *value = e->opt.null_keeps_cond;
+    else if (n == "ln_fold") *value = e->opt.ln_fold;
     else {
         f5_set_error("unknown engine option %s", name);
         return 2;
@@ -498,6 +504,8 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
         w.ao[p] = p < np ? b.take(M2 * D * 2) : 0;
         w.ffh[p] = p < np ? b.take(M2 * FF * 2) : 0;
     }
+    w.lnstats = b.take(M2 * (size_t)((D + 63) / 64) * 2 * 4);
+    for (int p = 0; p < 2; ++p) w.foldc[p] = b.take(nfe1 * L * (size_t)(3 * D + FF) * 4);
     w.h8 = w.h8s = w.ao8 = w.ao8s = w.ffh8 = w.ffh8s = 0;
     if (e->prec == F5_PREC_MXFP8) {
         w.h8 = b.take(M2 * D);
@@ -569,6 +577,37 @@ static F5GemmArgs gemm_base(const Ctx& c, const op16_t* a_hi, const op16_t* a_lo
     return g;
 }
 
+// LN fold (gemm.hpp fold_*): 44 of the 46 LN-modulate launches of a forward disappear into the epilogues of the GEMMs around them
+// (the first LN of block 0 follows conv-pos and the final one feeds a small-tile GEMM: both keep the LN kernel).  Only where all
+// four block GEMMs of this shape run on the staged kernels, in the one-pass operand modes, with the transposed q / k tiles.
+// -> 0 = off, 1 = on, -1 = required by the option but impossible here (error set)
+static int ln_fold_state(const Ctx& c) {
+    const f5_engine* e = c.e;
+    const f5_config& cf = e->cfg;
+    if (e->opt.ln_fold == 0) return 0;
+    const int D = cf.dim, FF = cf.ff_dim, M = c.nb * c.B * c.N;
+    bool ok = e->np == 1 && e->prec != F5_PREC_MXFP8 && e->opt.qkv_tr && !e->opt.fuse_ln && D % 256 == 0 && D <= 2048 && FF % 256 == 0 &&
+              (e->opt.gemm_flags & 16384) == 0 && cf.depth >= 1;
+    if (ok) {
+        F5GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.M = M;
+        g.seq_len = c.N;
+        const int shapes[4][3] = {{3 * D, D, EPI_QKV_ROPE}, {D, D, EPI_RESID_GATE}, {FF, D, EPI_GELU_TANH}, {D, FF, EPI_RESID_GATE}};
+        for (const auto& sh : shapes) {
+            g.N = sh[0];
+            g.K = sh[1];
+            ok = ok && c.ops.gemm_runs_staged(g, sh[2]);
+        }
+    }
+    if (!ok && e->opt.ln_fold == 1) {
+        f5_set_error("ln_fold = 1: this shape / precision cannot run the folded LN (needs f16 or bf16, qkv_transposed, no ln_fusion, dim %% 256 "
+                     "== 0, and all four block GEMMs on the 256x256 / role-split 128x256 kernels: batch >= 4 at the 335M shape)");
+        return -1;
+    }
+    return ok ? 1 : 0;
+}
+
 // loop-invariant preparation: time/adaLN tables, text path, hoisted input projection, masks, rope
 static int run_prep(const Ctx& c, int nfe) {
     const f5_engine* e = c.e;
@@ -588,6 +627,23 @@ static int run_prep(const Ctx& c, int nfe) {
                                  0, 0, s));
         RC(f5_launch_skinny_gemm(c.p<float>(w.temb), c.a<float>(e->ada_w), c.a<float>(e->ada_b), c.p<float>(w.mod), nfe,
                                  (6 * L + 2) * D, D, 1, 0, s));
+    }
+    const int fold = ln_fold_state(c);
+    if (fold < 0) return 2;
+    if (fold && nfe > 0) {
+        // c1 = W (1 + scale), c2 = W shift + bias for every evaluation and block: QKV against (scale_msa, shift_msa), FF1 against
+        // (scale_mlp, shift_mlp); mod rows are [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] (dit.py:53-58)
+        const int FF = cf.ff_dim;
+        const size_t vstride = (size_t)(6 * L + 2) * D, ostride = (size_t)L * (3 * D + FF);
+        for (int i = 0; i < L; ++i) {
+            const BlockW& bw = e->blocks[i];
+            const float* m6 = c.p<float>(w.mod) + (size_t)i * 6 * D;
+            float* c1 = c.p<float>(w.foldc[0]) + (size_t)i * (3 * D + FF);
+            float* c2 = c.p<float>(w.foldc[1]) + (size_t)i * (3 * D + FF);
+            RC(K.fold_consts(c.wm(bw.qkv, 0), bw.qkv.ld, c.a<float>(bw.bqkv), m6 + D, m6, vstride, nfe, c1, c2, ostride, 3 * D, D, s));
+            RC(K.fold_consts(c.wm(bw.ff1, 0), bw.ff1.ld, c.a<float>(bw.bff1), m6 + 4 * D, m6 + 3 * D, vstride, nfe, c1 + 3 * D, c2 + 3 * D,
+                             ostride, FF, D, s));
+        }
     }
     RC(f5_launch_rope_table(c.p<float>(w.rope_cos), c.p<float>(w.rope_sin), c.N, cf.dim_head, s));
     {
@@ -788,11 +844,33 @@ static int run_dit(const Ctx& c, int j) {
         g.ln_eps = 1e-6f;
         return true;
     };
+    // LN fold: the residual GEMMs leave x (1 + scale) in the operand type in `h` and the row sums in `lnstats`; QKV / FF1 finish the
+    // LN in their epilogues with the constants of this evaluation (run_prep)
+    const int fold_state = ln_fold_state(c);
+    if (fold_state < 0) return 2;
+    const bool fold = fold_state == 1;
+    const float* fc1 = c.p<float>(w.foldc[0]) + (size_t)j * L * (3 * D + FF);
+    const float* fc2 = c.p<float>(w.foldc[1]) + (size_t)j * L * (3 * D + FF);
+    auto fold_consumer = [&](F5GemmArgs& g, int block, int col0) {
+        g.fold_stats = c.p<float>(w.lnstats);
+        g.fold_nslice = D / 64;
+        g.fold_c1 = fc1 + (size_t)block * (3 * D + FF) + col0;
+        g.fold_c2 = fc2 + (size_t)block * (3 * D + FF) + col0;
+        g.fold_eps = 1e-6f;
+    };
+    auto fold_producer = [&](F5GemmArgs& g, const float* next_scale) {
+        g.x16_out = c.pb(w.h, 0);
+        g.ldx16 = D;
+        g.x16_scale = next_scale;
+        g.stats_out = c.p<float>(w.lnstats);
+    };
+    bool h_folded = false;                       // `h` holds x (1 + scale) + row sums (fold) instead of the finished LN-modulate
     for (int i = 0; i < L && e->prec != F5_PREC_MXFP8; ++i) {
         const BlockW& bw = e->blocks[i];
         const float* m6 = mod + (size_t)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         if (!h_ready) RC(K.ln_modulate(c.p<float>(w.x), m6 + D, m6, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
         F5GemmArgs gq = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.qkv, M, 3 * D, D, c.a<float>(bw.bqkv));
+        if (h_folded) fold_consumer(gq, i, 0);
         gq.out_bf[0] = c.pb(w.qk, 0);
         gq.out_bf[1] = c.pb(w.qk, 1);
         gq.ldob = 2 * D;
@@ -843,10 +921,12 @@ static int run_dit(const Ctx& c, int j) {
         go.gate = m6 + 2 * D;
         go.rowkeep = rowkeep;
         const bool fused_mlp_ln = fuse_ln(go, m6 + 4 * D, m6 + 3 * D);     // h = LN(x) (1 + scale_mlp) + shift_mlp in the same launch
+        if (fold) fold_producer(go, m6 + 4 * D);
         RC(K.gemm(go, EPI_RESID_GATE, s));
 
-        if (!fused_mlp_ln) RC(K.ln_modulate(c.p<float>(w.x), m6 + 4 * D, m6 + 3 * D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+        if (!fused_mlp_ln && !fold) RC(K.ln_modulate(c.p<float>(w.x), m6 + 4 * D, m6 + 3 * D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
         F5GemmArgs g1 = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.ff1, M, FF, D, c.a<float>(bw.bff1));
+        if (fold) fold_consumer(g1, i, 3 * D);
         g1.out_bf[0] = c.pb(w.ffh, 0);
         g1.out_bf[1] = c.pb(w.ffh, 1);
         g1.ldob = FF;
@@ -858,6 +938,11 @@ static int run_dit(const Ctx& c, int j) {
         // the LN that follows FF2: the next block's attention LN (scale_msa, shift_msa), or the final one (dit.py:287: scale, shift)
         const float* m6n = m6 + 6 * D;
         h_ready = (i + 1 < L) ? fuse_ln(g2, m6n + D, m6n) : fuse_ln(g2, mf, mf + D);
+        h_folded = fold && i + 1 < L;            // (the final LN feeds the small mel projection: it keeps the LN kernel)
+        if (h_folded) {
+            fold_producer(g2, m6n + D);
+            h_ready = true;
+        }
         RC(K.gemm(g2, EPI_RESID_GATE, s));
     }
     if (!h_ready) RC(K.ln_modulate(c.p<float>(w.x), mf, mf + D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
@@ -1033,8 +1118,8 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d nk%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, e->opt.null_keeps_cond, g_knob_epoch,
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d nk%d lf%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, e->opt.null_keeps_cond, e->opt.ln_fold, g_knob_epoch,
              a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
@@ -1299,6 +1384,41 @@ extern "C" int f5_debug_set_gemm_v3_prio(int v) {
 }
 #endif  // F5_LAB
 
+// op-level twins of the LN fold (gemm.hpp fold_*): what run_dit sets on its block GEMMs, for the per-op entry points
+static struct {
+    const float* next_scale = nullptr;       // producer: f5_op_gemm_resid_gate
+    op16_t* x16 = nullptr;
+    float* stats_out = nullptr;
+    const float* stats = nullptr;            // consumer: f5_op_gemm (epi 2), f5_op_qkv_rope
+    int nslice = 0;
+    const float* c1 = nullptr;
+    const float* c2 = nullptr;
+} g_op_fold;
+extern "C" int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float* stats_out) {
+    g_op_fold.next_scale = next_scale;
+    g_op_fold.x16 = (op16_t*)x16_out;
+    g_op_fold.stats_out = stats_out;
+    return 0;
+}
+extern "C" int f5_debug_set_op_fold_consumer(const float* stats, int nslice, const float* c1, const float* c2) {
+    g_op_fold.stats = stats;
+    g_op_fold.nslice = nslice;
+    g_op_fold.c1 = c1;
+    g_op_fold.c2 = c2;
+    return 0;
+}
+static void op_fold_consumer(F5GemmArgs& g) {
+    g.fold_stats = g_op_fold.stats;
+    g.fold_nslice = g_op_fold.nslice;
+    g.fold_c1 = g_op_fold.c1;
+    g.fold_c2 = g_op_fold.c2;
+    g.fold_eps = 1e-6f;
+}
+extern "C" int f5_op_fold_consts(const void* w_hi, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride,
+                                 int nvec, float* c1, float* c2, size_t out_stride, int N, int K, void* stream) {
+    return g_ops.fold_consts((const op16_t*)w_hi, ldw, bias, scale, shift, vec_stride, nvec, c1, c2, out_stride, N, K, (hipStream_t)stream);
+}
+
 extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                           float* out_f32, void* out_bf_hi, void* out_bf_lo, int M, int N, int K, int lda, int ldw, int ldo,
                           int nseg, int epi, void* stream) {
@@ -1322,6 +1442,7 @@ extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, 
     g.out_bf[0] = (op16_t*)out_bf_hi;
     g.out_bf[1] = (op16_t*)out_bf_lo;
     g.ldob = ldo;
+    if (epi == EPI_GELU_TANH && g_op_fold.stats != nullptr) op_fold_consumer(g);
     return g_ops.gemm(g, epi, (hipStream_t)stream);
 }
 
@@ -1437,6 +1558,7 @@ extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_
     g.rope_ldt = seq_len;
     g.vt[0] = (op16_t*)vt_hi;
     g.vt[1] = (op16_t*)vt_lo;
+    if (g_op_fold.stats != nullptr) op_fold_consumer(g);
     return g_ops.gemm(g, EPI_QKV_ROPE, (hipStream_t)stream);
 }
 
@@ -1592,6 +1714,12 @@ extern "C" int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const v
     g.out_f32 = x;
     g.ldo = ldx;
     F5_REQUIRE(gate != nullptr && x != nullptr, "gemm_resid_gate: null gate / x");
+    if (g_op_fold.x16 != nullptr) {
+        g.x16_out = g_op_fold.x16;
+        g.ldx16 = N;
+        g.x16_scale = g_op_fold.next_scale;
+        g.stats_out = g_op_fold.stats_out;
+    }
     return g_ops.gemm(g, EPI_RESID_GATE, (hipStream_t)stream);
 }
 // the same with the LN-modulate of the next sub-layer fused behind it (small-tile shapes only, see gemm.hpp ln_counter):

@@ -688,6 +688,96 @@ bool f5_gemm_resid_ln_fusable(const F5GemmArgs& a) {
     return !gemm_uses_big_kernel(a) && a.N % 256 == 0 && a.N >= 256 && a.N <= 1024 && a.ldo == a.N && a.M <= 64 * 65536;
 }
 
+// mirrors launch_epi's two staged routes (a drift makes f5_launch_gemm fail loudly, never compute something else)
+bool f5_gemm_runs_staged(const F5GemmArgs& a, int epi) {
+    if (!(epi == EPI_RESID_GATE || epi == EPI_QKV_ROPE || epi == EPI_GELU_TANH) || a.ln_counter != nullptr || a.N % 256 != 0) return false;
+    const int sel = f5_gemm_tile_override;
+#if F5_LAB
+    if (sel == 7 || f5_gemm_big_kernel != 2 || f5_gemm_streamk) return false;
+#endif
+    const long t256 = (long)f5_cdiv(a.M, 256) * (a.N / 256);
+    const long t128 = (long)f5_cdiv(a.M, 128) * f5_cdiv(a.N, 128);
+    if (sel == 4 || (sel == 0 && a.M >= 256 && t256 >= 512)) return a.M >= 256;
+    const bool qkv_rows_ok = epi != EPI_QKV_ROPE || (a.seq_len > 0 && a.M % a.seq_len == 0);
+    return qkv_rows_ok && (sel == 14 || (sel == 0 && t128 >= 384));
+}
+
+// ---- constants of the LN fold (gemm.hpp): one wave holds FC_ROWS weight rows in registers as fp32 and streams every modulation
+// vector past them (the vectors are L2-resident: nvec x 2 x K floats)
+constexpr int FC_ROWS = 4, FC_MAXC = 8;
+__global__ __launch_bounds__(256) void f5_fold_consts_kernel(const op16_t* __restrict__ w, int ldw, const float* __restrict__ bias,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, size_t vec_stride,
+                                                             int nvec, float* __restrict__ c1, float* __restrict__ c2, size_t out_stride, int N,
+                                                             int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * FC_ROWS;
+    if (n0 >= N) return;
+    const int nchunk = K >> 8;                       // 256 columns per chunk, 4 per lane
+    float wv[FC_ROWS][FC_MAXC][4];
+#pragma unroll
+    for (int r = 0; r < FC_ROWS; ++r) {
+        const int n = n0 + r < N ? n0 + r : N - 1;
+#pragma unroll
+        for (int c = 0; c < FC_MAXC; ++c) {
+            if (c < nchunk) {
+                const op16x4 t = *reinterpret_cast<const op16x4*>(w + (size_t)n * ldw + c * 256 + lane * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wv[r][c][e] = f5_op2f(t[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wv[r][c][e] = 0.0f;
+            }
+        }
+    }
+    for (int v = 0; v < nvec; ++v) {
+        const float* sv = scale + (size_t)v * vec_stride;
+        const float* bv = shift + (size_t)v * vec_stride;
+        float a1[FC_ROWS], a2[FC_ROWS];
+#pragma unroll
+        for (int r = 0; r < FC_ROWS; ++r) a1[r] = a2[r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < FC_MAXC; ++c) {
+            if (c < nchunk) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sv + c * 256 + lane * 4);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bv + c * 256 + lane * 4);
+#pragma unroll
+                for (int r = 0; r < FC_ROWS; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a1[r] += wv[r][c][e] * (1.0f + s4[e]);
+                        a2[r] += wv[r][c][e] * b4[e];
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FC_ROWS; ++r) {
+            a1[r] = f5_wave_sum(a1[r]);
+            a2[r] = f5_wave_sum(a2[r]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < FC_ROWS; ++r)
+                if (n0 + r < N) {
+                    c1[(size_t)v * out_stride + n0 + r] = a1[r];
+                    c2[(size_t)v * out_stride + n0 + r] = a2[r] + (bias ? bias[n0 + r] : 0.0f);
+                }
+        }
+    }
+}
+
+int f5_launch_fold_consts(const op16_t* w, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,
+                          float* c1, float* c2, size_t out_stride, int N, int K, hipStream_t stream) {
+    F5_REQUIRE(w && scale && shift && c1 && c2 && N > 0 && nvec > 0, "fold_consts: null argument");
+    F5_REQUIRE(K % 256 == 0 && K <= 256 * FC_MAXC && ldw % 4 == 0 && vec_stride % 4 == 0, "fold_consts: K must be a multiple of 256, <= %d",
+               256 * FC_MAXC);
+    F5_REQUIRE(((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0,
+               "fold_consts: unaligned operand");
+    hipLaunchKernelGGL(f5_fold_consts_kernel, dim3(f5_cdiv(N, 4 * FC_ROWS)), dim3(256), 0, stream, w, ldw, bias, scale, shift, vec_stride, nvec,
+                       c1, c2, out_stride, N, K);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int EPI>
 static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     if (a.ln_counter) {
@@ -708,6 +798,8 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     if (sel == 4 || (sel == 0 && v2ok && t256 >= 512)) {
         F5_REQUIRE(v2ok, "gemm: the 256x256 kernel needs N %% 256 == 0 and M >= 256");
 #if F5_LAB
+        F5_REQUIRE((a.x16_out == nullptr && a.fold_stats == nullptr) || (f5_gemm_big_kernel == 2 && !f5_gemm_streamk),
+                   "gemm: the LN fold needs the product 256x256 kernel");
         if (f5_gemm_big_kernel == 4 || f5_gemm_streamk) return f5_launch_gemm_lab_v2(a, EPI, stream);      // lock-step predecessor (A/B)
         if constexpr (EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_RESID_GATE || EPI == EPI_QKV_ROPE) {
             if (f5_gemm_big_kernel == 5) return f5_launch_gemm128(a, EPI, stream);              // 128x256, two workgroups per CU
@@ -741,6 +833,8 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
         if ((sel == 14 || qkv14 || mid) && a.N % 256 == 0 && a.ln_counter == nullptr) return f5_launch_gemm_rs128(a, EPI, stream);
         if (sel == 14) sel = 0;
     }
+    F5_REQUIRE(a.x16_out == nullptr && a.fold_stats == nullptr,
+               "gemm: the LN fold (x16_out / fold_stats) needs a launch on the 256x256 or the role-split 128x256 kernel (f5_gemm_runs_staged)");
     if constexpr (EPI == EPI_QKV_ROPE) {
         // batch-1-sized QKV projection with pair-major tables: one round of 8-wave 128 x 256 tiles with transposed q / k wave tiles
         // (f5_gemm_qkv_small_tile = 13 / 12) instead of 64 x 128 register-staged tiles (0)
@@ -798,6 +892,22 @@ int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
     F5_REQUIRE((size_t)(a.a_row_mod > 0 ? a.a_row_mod : a.M) * a.lda < (1ull << 31) && (size_t)(a.N + 256) * a.ldw < (1ull << 31),
                "gemm: operands must stay below 4 GiB (the kernels use 32-bit byte offsets)");
     F5_REQUIRE(epi != EPI_RESID_GATE || (size_t)a.M * a.ldo * 4 < (1ull << 32), "gemm(resid): the residual stream must stay below 4 GiB");
+    if (a.x16_out != nullptr || a.stats_out != nullptr) {
+        F5_REQUIRE(epi == EPI_RESID_GATE && a.x16_out && a.stats_out && a.x16_scale && a.N % 64 == 0 && a.ldx16 % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.x16_scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.x16_out) & 7) == 0,
+                   "gemm: LN-fold producer needs EPI_RESID_GATE, x16_out + stats_out + x16_scale (16-byte aligned), N %% 64 == 0");
+    }
+    if (a.fold_stats != nullptr) {
+        F5_REQUIRE((epi == EPI_QKV_ROPE || epi == EPI_GELU_TANH) && a.nseg == 1 && a.out_bf[1] == nullptr && a.fold_c1 && a.fold_c2 &&
+                       a.fold_nslice >= 2 && a.fold_nslice % 2 == 0 && a.fold_nslice * 64 == a.K &&
+                       ((reinterpret_cast<uintptr_t>(a.fold_c1) | reinterpret_cast<uintptr_t>(a.fold_c2) |
+                         reinterpret_cast<uintptr_t>(a.fold_stats)) & 15) == 0 &&
+                       (a.debug_flags & 16384) == 0,
+                   "gemm: LN-fold consumer needs EPI_QKV_ROPE / EPI_GELU_TANH, one-pass operands, aligned fold_c1 / fold_c2 / fold_stats, "
+                   "fold_nslice == K / 64");
+        F5_REQUIRE(epi != EPI_QKV_ROPE || (a.rope_cos_tk && a.dmodel % 256 == 0), "gemm(qkv): the LN fold needs the transposed q / k tiles");
+        a.bias = nullptr;                             // inside fold_c2
+    }
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(a, stream);
         case EPI_BF16: return launch_epi<EPI_BF16>(a, stream);

@@ -61,6 +61,21 @@ struct F5GemmArgs {
     const float* ln_shift;    // [N]
     op16_t* ln_out[2];        // hi, lo (lo may be null): [M][N]
     float ln_eps;
+    // ---- LN-modulate folded into the GEMMs around it (round 4; 256x256 and role-split 128x256 kernels, one-pass operand modes):
+    //   (LN(x) (1 + s) + b) W^T + bias  =  rstd ((x (1 + s)) W^T) - rstd mu c1 + c2,    c1 = W (1 + s),  c2 = W b + bias
+    // PRODUCER (EPI_RESID_GATE): besides x it writes x (1 + s) in the 16-bit operand type (the next GEMM's A operand; s = the scale of
+    // the LN that follows, x16_scale) and, per row and 64-column slice, the partial sums (sum x, sum x^2) of the new x.  CONSUMER
+    // (EPI_QKV_ROPE with transposed q / k tiles, EPI_GELU_TANH): A = that operand, W unchanged, and the epilogue applies the row
+    // factors from the partial sums before everything else; `bias` is ignored (it is inside fold_c2, f5_launch_fold_consts).
+    op16_t* x16_out;          // [M][ldx16] or null
+    int ldx16;
+    const float* x16_scale;   // [N]: s (the kernel adds the 1)
+    float* stats_out;         // [M][N / 64][2] (sum, sum of squares) or null; both or neither
+    const float* fold_stats;  // [M][fold_nslice][2] or null = plain GEMM
+    int fold_nslice;          // slices per row (LN width / 64)
+    const float* fold_c1;     // [N], 16-byte aligned
+    const float* fold_c2;     // [N], 16-byte aligned
+    float fold_eps;
     // ---- MX-fp8 path (f5_launch_gemm_f8): e4m3 operands with one E8M0 scale per 32 consecutive K elements
     const uint8_t* A8;        // [a_rows][lda8] bytes
     const uint8_t* W8;        // [>=ceil256(N)][ldw8] bytes
@@ -73,6 +88,14 @@ struct F5GemmArgs {
 };
 
 int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
+// true when f5_launch_gemm runs this launch on a kernel with the LDS-staged epilogues (256x256 / role-split 128x256): the only ones
+// that implement the x16_out / stats_out / fold_* fields (f5_launch_gemm fails loudly for the others)
+bool f5_gemm_runs_staged(const F5GemmArgs& a, int epi);
+// Constants of the fold for `nvec` modulation vectors at once: c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k]
+// shift_v[k] + bias[n], fp32 sums over the operand-typed weights the GEMM multiplies by.  scale_v = scale + v * vec_stride (floats),
+// likewise shift_v; c1 / c2 rows are out_stride floats apart.  K % 256 == 0, K <= 2048.
+int f5_launch_fold_consts(const op16_t* w, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,
+                          float* c1, float* c2, size_t out_stride, int N, int K, hipStream_t stream);
 // the large-shape kernel (gemm256.hip: 256 x 256 tiles, one workgroup per CU); f5_launch_gemm routes N % 256 == 0, >= 512-tile shapes here
 int f5_launch_gemm256(const F5GemmArgs& a, int epi, hipStream_t stream);
 // batch-1-sized shapes: role-split 128 x 256 tiles, one round of 8-wave workgroups (gemm_rs128.hip)

@@ -245,6 +245,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     }
 
     op16_t* stage = smem + wave * 8192;                 // this wave's private 16 KB of epilogue staging
+    float* fl = reinterpret_cast<float*>(stage + 6144); // its last 4 KB: row factors of a folded LN-modulate (the staged tiles use <= 9 KB)
+    const bool fold = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH) && p.fold_stats != nullptr;
     const int row0 = m0 + wm * 128, col0 = n0 + wn * 64;
     // 16-bit row-major outputs: the tile is accumulated TRANSPOSED (operands swapped in every MFMA) for staged_epilogue_tr.  Both
     // loop copies end in their own epilogue: no join with 128 live accumulator registers.
@@ -256,6 +258,11 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         }
         if (wm == 0) G256_BARRIER();                    // group 0 waits for group 1's last MATRIX segment: the ring is dead
         if ((p.debug_flags & 1) || !act_lo) return;     // flag 1 = timing experiment: main loop only
+        if (fold) {                                     // LN-modulate folded into this GEMM (F5GemmArgs::fold_*; workgroup-uniform)
+            if (QT) staged_epilogue_tr_rope<4, 2, true>(p, acc, stage, row0, col0, lane, fl);
+            else staged_epilogue_tr<EPI, 4, 2, true>(p, acc, stage, row0, col0, lane, fl);
+            return;
+        }
         if (QT) staged_epilogue_tr_rope<4, 2>(p, acc, stage, row0, col0, lane);
         else staged_epilogue_tr<EPI, 4, 2>(p, acc, stage, row0, col0, lane);
         return;
@@ -274,7 +281,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     }
     if (!act_lo) return;
     if (QT) {                                                               // (the q / k tiles finished above)
-        staged_epilogue_bf16<EPI, 4, 2, true>(p, acc, stage, row0, col0, lane);
+        if (fold) staged_epilogue_bf16<EPI, 4, 2, true, true>(p, acc, stage, row0, col0, lane, fl);
+        else staged_epilogue_bf16<EPI, 4, 2, true>(p, acc, stage, row0, col0, lane);
     } else if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
         staged_epilogue_bf16<EPI, 4, 2>(p, acc, stage, row0, col0, lane);
     } else if (EPI == EPI_RESID_GATE) {

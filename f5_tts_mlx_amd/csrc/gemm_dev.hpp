@@ -167,24 +167,64 @@ __device__ __forceinline__ void glds16(const op16_t* gptr, op16_t* lds_wave_base
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
 
+// ---- LN-modulate folded into the consumer GEMM (F5GemmArgs::fold_*): the row factors rstd and rstd * mean of the wave's ROWS rows,
+// from the per-slice partial sums the producing residual GEMM left in fold_stats, into the wave's private LDS scratch fl[ROWS][2].
+// Lane l finalises row l (+ 64): nslice (sum, sum of squares) pairs = nslice / 2 16-byte loads, summed in slice order (deterministic).
+template <int ROWS>
+__device__ __forceinline__ void fold_rows_to_lds(const F5GemmArgs& p, float* fl, int row0, int lane) {
+    const float inv_n = 1.0f / (64.0f * (float)p.fold_nslice);
+#pragma unroll
+    for (int base = 0; base < ROWS; base += 64) {
+        const int r = base + lane;
+        int grow = row0 + r;
+        if (grow > p.M - 1) grow = p.M - 1;
+        const f32x4* sp = reinterpret_cast<const f32x4*>(p.fold_stats + (size_t)grow * p.fold_nslice * 2);
+        float s = 0.0f, q = 0.0f;
+        for (int i = 0; i < (p.fold_nslice >> 1); ++i) {
+            const f32x4 t = sp[i];
+            s += t[0];
+            q += t[1];
+            s += t[2];
+            q += t[3];
+        }
+        const float mean = s * inv_n;
+        const float var = fmaxf(q * inv_n - mean * mean, 0.0f);
+        const float rstd = rsqrtf(var + p.fold_eps);
+        if (r < ROWS) *reinterpret_cast<f5_f32x2*>(&fl[2 * r]) = f5_f32x2{rstd, rstd * mean};
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---- LDS-staged epilogues (used by the 256x256 and the 128x256 kernels).  A wave owns a (32*MBW) x (32*NBW) tile
 // and a private LDS region; the MFMA C layout (lane = column, registers = rows) is turned into 16-byte global accesses
 // in full row segments.  bf16 row-major outputs (FF1 / q / k / plain bf16): 32-row passes, [32][W+8] hi (+ lo).
 // V (QKV columns >= 2*dmodel) is written TRANSPOSED, Vt[(b*H+h)*64+d][n]: staged [d][64 tokens (+8)] and stored along
 // the token axis; those 16-byte stores may be only 2-byte aligned (legal on gfx950, tools/probes/unaligned.hip) and
 // are split element-wise where a chunk crosses a batch-element boundary.
-template <int EPI, int MBW, int NBW, bool VONLY = false>
+// FOLD (V tiles only): the LN-modulate fold of F5GemmArgs::fold_* -- value = rstd * acc - rstd * mean * c1[col] + c2[col], the row
+// factors from the wave's LDS scratch `fl` (fold_rows_to_lds).
+template <int EPI, int MBW, int NBW, bool VONLY = false, bool FOLD = false>
 __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
-                                                     int colbase, int lane) {
+                                                     int colbase, int lane, float* fl = nullptr) {
+    static_assert(!FOLD || VONLY, "the straight q / k / FF1 tiles have no folded form");
     constexpr int W = 32 * NBW;
     constexpr int LD = W + 8;
     constexpr int CPR = W / 8;             // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;          // rows per store instruction
     const int hi = lane >> 5, lcol = lane & 31;
     const bool two = p.out_bf[1] != nullptr;
-    float bcol[NBW];
+    float bcol[NBW], c1col[NBW];
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
+    for (int nb = 0; nb < NBW; ++nb) {
+        if (FOLD) {
+            bcol[nb] = p.fold_c2[colbase + nb * 32 + lcol];
+            c1col[nb] = p.fold_c1[colbase + nb * 32 + lcol];
+        } else {
+            bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
+            c1col[nb] = 0.0f;
+        }
+    }
+    if (FOLD) fold_rows_to_lds<32 * MBW>(p, fl, row0, lane);
     const bool is_v = VONLY || ((EPI == EPI_QKV_ROPE) && (colbase >= 2 * p.dmodel));   // VONLY: the q / k tiles went elsewhere
 
     if (!is_v) {
@@ -274,8 +314,20 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
                             float v[4];
+                            if (FOLD) {
+                                // rows (mq*MP + mb)*32 + rg*8 + 4*hi + [0, 4): their (rstd, rstd*mean) pairs are 32 contiguous bytes
+                                const float* fr = fl + 2 * ((mq * MP + mb) * 32 + rg * 8 + 4 * hi);
+                                const f32x4 f01 = *reinterpret_cast<const f32x4*>(fr);
+                                const f32x4 f23 = *reinterpret_cast<const f32x4*>(fr + 4);
+                                const float d = bcol[nb], c = c1col[nb];
+                                v[0] = f01[0] * acc[mq * MP + mb][nb][rg * 4 + 0] + (d - f01[1] * c);
+                                v[1] = f01[2] * acc[mq * MP + mb][nb][rg * 4 + 1] + (d - f01[3] * c);
+                                v[2] = f23[0] * acc[mq * MP + mb][nb][rg * 4 + 2] + (d - f23[1] * c);
+                                v[3] = f23[2] * acc[mq * MP + mb][nb][rg * 4 + 3] + (d - f23[3] * c);
+                            } else {
 #pragma unroll
-                            for (int ri = 0; ri < 4; ++ri) v[ri] = acc[mq * MP + mb][nb][rg * 4 + ri] + bcol[nb];
+                                for (int ri = 0; ri < 4; ++ri) v[ri] = acc[mq * MP + mb][nb][rg * 4 + ri] + bcol[nb];
+                            }
                             const u32x2 pk = part == 0 ? u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])}
                                                        : u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
                             const int tok = mb * 32 + rg * 8 + 4 * hi;
@@ -320,9 +372,10 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
 // into the same [32 tokens][W + 8] image, and the read-back / 16-byte global stores in full row segments are unchanged: 8x
 // fewer LDS write instructions per tile, bias lane-uniform.  The wave picks the layout by the operand order of its MFMAs
 // (f5_gemm256_kernel, V2_MM).
-template <int EPI, int MBW, int NBW>
+// FOLD: the LN-modulate fold of F5GemmArgs::fold_* (lane = token: its two row factors are one 8-byte LDS read per 32-token block).
+template <int EPI, int MBW, int NBW, bool FOLD = false>
 __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0, int colbase,
-                                                   int lane) {
+                                                   int lane, float* fl = nullptr) {
     constexpr int W = 32 * NBW;
     constexpr int LD = W + 8;
     constexpr int CPR = W / 8;             // 16-byte chunks per row
@@ -336,18 +389,24 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
-            b4[nb][rg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colbase + nb * 32 + rg * 8 + hi * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            b4[nb][rg] = FOLD ? *reinterpret_cast<const f32x4*>(p.fold_c2 + colbase + nb * 32 + rg * 8 + hi * 4)
+                              : (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colbase + nb * 32 + rg * 8 + hi * 4) : f32x4{0.f, 0.f, 0.f, 0.f});
+    if (FOLD) fold_rows_to_lds<32 * MBW>(p, fl, row0, lane);
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
         const int rowblk = row0 + mb * 32;
+        f5_f32x2 rr = {1.0f, 0.0f};
+        if (FOLD) rr = *reinterpret_cast<const f5_f32x2*>(&fl[2 * (mb * 32 + lcol)]);
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 float v[4];
+                f32x4 c1q = {0.f, 0.f, 0.f, 0.f};
+                if (FOLD) c1q = *reinterpret_cast<const f32x4*>(p.fold_c1 + colbase + nb * 32 + rg * 8 + hi * 4);   // (L1-resident after block 0)
 #pragma unroll
                 for (int ri = 0; ri < 4; ++ri) {
-                    v[ri] = acc[mb][nb][rg * 4 + ri] + b4[nb][rg][ri];
+                    v[ri] = FOLD ? rr[0] * acc[mb][nb][rg * 4 + ri] + (b4[nb][rg][ri] - rr[1] * c1q[ri]) : acc[mb][nb][rg * 4 + ri] + b4[nb][rg][ri];
                     if (EPI == EPI_GELU_TANH) v[ri] = f5_gelu_tanh(v[ri]);
                     if (EPI == EPI_GELU_ERF_BF16) v[ri] = f5_gelu_erf(v[ri]);
                 }
@@ -375,9 +434,9 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
 // tables ([dim_head/2][positions]: the 32 lanes of a half wave hold 32 consecutive tokens and read 128 contiguous bytes per
 // factor; the straight tile reads a token-major table with 2 lines per load but needs 64 loads and 32 lane swaps per 32 x 64
 // block).  q_premul is folded into the q tables by the host.  dit.py:136-158.
-template <int MBW, int NBW>
+template <int MBW, int NBW, bool FOLD = false>
 __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
-                                                        int colbase, int lane) {
+                                                        int colbase, int lane, float* fl = nullptr) {
     constexpr int W = 32 * NBW;
     constexpr int LD = W + 8;
     constexpr int CPR = W / 8;
@@ -389,12 +448,15 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
     const float* st = isq ? p.rope_sin_tq : p.rope_sin_tk;
     op16_t* rh = reg;
     op16_t* rl = reg + 32 * LD;
+    if (FOLD) fold_rows_to_lds<32 * MBW>(p, fl, row0, lane);
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
         const int rowblk = row0 + mb * 32;
         int row = rowblk + lcol;
         if (row > p.M - 1) row = p.M - 1;                    // rows past the end compute a valid rotation and are never stored
         const int n = row % p.seq_len;
+        f5_f32x2 rr = {1.0f, 0.0f};
+        if (FOLD) rr = *reinterpret_cast<const f5_f32x2*>(&fl[2 * (mb * 32 + lcol)]);
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
             // one batch of loads per 32-feature block: 16 rotation factors + 4 bias quads (the accumulators leave ~90 free VGPRs)
@@ -408,12 +470,28 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
                 c1[rg] = ct[(size_t)(j0 + 1) * p.rope_ldt + n];
                 s0[rg] = st[(size_t)j0 * p.rope_ldt + n];
                 s1[rg] = st[(size_t)(j0 + 1) * p.rope_ldt + n];
-                b4[rg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (FOLD) {
+                    const f32x4 c1q = *reinterpret_cast<const f32x4*>(p.fold_c1 + c), c2q = *reinterpret_cast<const f32x4*>(p.fold_c2 + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b4[rg][e] = c2q[e] - rr[1] * c1q[e];
+                } else {
+                    b4[rg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
+            const float rs_ = FOLD ? rr[0] : 1.0f;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float a0 = acc[mb][nb][rg * 4 + 0] + b4[rg][0], a1 = acc[mb][nb][rg * 4 + 1] + b4[rg][1];
-                const float a2 = acc[mb][nb][rg * 4 + 2] + b4[rg][2], a3 = acc[mb][nb][rg * 4 + 3] + b4[rg][3];
+                float a0 = acc[mb][nb][rg * 4 + 0], a1 = acc[mb][nb][rg * 4 + 1], a2 = acc[mb][nb][rg * 4 + 2], a3 = acc[mb][nb][rg * 4 + 3];
+                if (FOLD) {
+                    a0 *= rs_;
+                    a1 *= rs_;
+                    a2 *= rs_;
+                    a3 *= rs_;
+                }
+                a0 += b4[rg][0];
+                a1 += b4[rg][1];
+                a2 += b4[rg][2];
+                a3 += b4[rg][3];
                 // same expressions as the straight tile: even column v*c - partner*s, odd column v*c + partner*s
                 const float o0 = a0 * c0[rg] - a1 * s0[rg], o1 = a1 * c0[rg] + a0 * s0[rg];
                 const float o2 = a2 * c1[rg] - a3 * s1[rg], o3 = a3 * c1[rg] + a2 * s1[rg];
@@ -454,6 +532,12 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
     const int chunk = lane % CPR;
     f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gate + colbase + chunk * 4);
     asm volatile("" : "+v"(g4));
+    f32x4 sc4 = {1.0f, 1.0f, 1.0f, 1.0f};               // LN fold: 1 + the scale of the LN that follows (F5GemmArgs::x16_scale)
+    if (p.x16_out != nullptr) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.x16_scale + colbase + chunk * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc4[e] += t[e];
+    }
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
         const int rowblk = row0 + mb * 32;
@@ -486,12 +570,30 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
             const int lrow = i * RPI + lane / CPR;
             const int grow = rowblk + lrow;
             const f32x4 v = *reinterpret_cast<const f32x4*>(&reg[lrow * LD + chunk * 4]);
-            if (grow < p.M) {
-                f32x4 o;
+            f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = xr[i][e] + g4[e] * (kraw[i] != 0u ? v[e] : 0.0f);   // a select, like gemm_epilogue: a non-finite
-                                                                                                      // accumulator of a masked row must not reach x
-                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4) = o;
+            for (int e = 0; e < 4; ++e) o[e] = xr[i][e] + g4[e] * (kraw[i] != 0u ? v[e] : 0.0f);   // a select, like gemm_epilogue: a non-finite
+                                                                                                  // accumulator of a masked row must not reach x
+            if (grow < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4) = o;
+            if (CPR == 16 && p.x16_out != nullptr) {          // (64-column wave tiles only: the launcher refuses the others)
+                // LN fold (F5GemmArgs): x (1 + s) in the operand type is the next GEMM's A operand; the row's partial sums over this
+                // wave's 64 columns come from a 16-lane DPP reduction (the 16 lanes of a DPP row hold one row segment)
+                float ps = grow < p.M ? (o[0] + o[1]) + (o[2] + o[3]) : 0.0f;
+                float pq = grow < p.M ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.0f;
+                ps += f5_dpp_row<0x128>(ps);
+                pq += f5_dpp_row<0x128>(pq);
+                ps += f5_dpp_row<0x124>(ps);
+                pq += f5_dpp_row<0x124>(pq);
+                ps += f5_dpp_row<0x122>(ps);
+                pq += f5_dpp_row<0x122>(pq);
+                ps += f5_dpp_row<0x121>(ps);
+                pq += f5_dpp_row<0x121>(pq);
+                if (grow < p.M) {
+                    *reinterpret_cast<u32x2*>(p.x16_out + (size_t)grow * p.ldx16 + colbase + chunk * 4) =
+                        u32x2{f5_pack2(o[0] * sc4[0], o[1] * sc4[1]), f5_pack2(o[2] * sc4[2], o[3] * sc4[3])};
+                    if (chunk == 0)
+                        *reinterpret_cast<f5_f32x2*>(p.stats_out + ((size_t)grow * (p.N >> 6) + (colbase >> 6)) * 2) = f5_f32x2{ps, pq};
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -221,6 +221,8 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
     }
 
     op16_t* stage = smem + wave * 4608;                 // 9 KB of private epilogue staging per wave (32 x (64 + 8) hi + lo)
+    float* fl = reinterpret_cast<float*>(smem + 8 * 4608) + wave * 128;     // behind the eight stages: row factors of a folded LN-modulate
+    const bool fold = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH) && p.fold_stats != nullptr;
     const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
     constexpr bool TR_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
     if ((TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel)) {       // workgroup-uniform
@@ -228,6 +230,11 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
         if (wm == 0) RS_BARRIER();                      // group 0 waits for group 1's last MATRIX segment: the ring is dead
         if ((p.debug_flags & 1) || !active) return;
         // (requesting the rotation factors before the K loop -- 64 more live registers -- was measured neutral: 25.3 vs 25.6 us)
+        if (fold) {                                     // LN-modulate folded into this GEMM (F5GemmArgs::fold_*; workgroup-uniform)
+            if (QT) staged_epilogue_tr_rope<2, 2, true>(p, acc, stage, row0, col0, lane, fl);
+            else staged_epilogue_tr<EPI, 2, 2, true>(p, acc, stage, row0, col0, lane, fl);
+            return;
+        }
         if (QT) staged_epilogue_tr_rope<2, 2>(p, acc, stage, row0, col0, lane);
         else staged_epilogue_tr<EPI, 2, 2>(p, acc, stage, row0, col0, lane);
         return;
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
     }
     if (!active) return;
     if (QT) {
-        staged_epilogue_bf16<EPI, 2, 2, true>(p, acc, stage, row0, col0, lane);
+        if (fold) staged_epilogue_bf16<EPI, 2, 2, true, true>(p, acc, stage, row0, col0, lane, fl);
+        else staged_epilogue_bf16<EPI, 2, 2, true>(p, acc, stage, row0, col0, lane);
     } else if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
         staged_epilogue_bf16<EPI, 2, 2>(p, acc, stage, row0, col0, lane);
     } else if (EPI == EPI_RESID_GATE) {

@@ -54,6 +54,15 @@ struct Ops {
     bool gemm_resid_ln_fusable(const F5GemmArgs& a) const {
         return h ? f5hf::f5_gemm_resid_ln_fusable(reinterpret_cast<const f5hf::F5GemmArgs&>(a)) : f5bf::f5_gemm_resid_ln_fusable(a);
     }
+    bool gemm_runs_staged(const F5GemmArgs& a, int epi) const {
+        return h ? f5hf::f5_gemm_runs_staged(reinterpret_cast<const f5hf::F5GemmArgs&>(a), epi) : f5bf::f5_gemm_runs_staged(a, epi);
+    }
+    int fold_consts(const op16_t* w, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec, float* c1,
+                    float* c2, size_t out_stride, int N, int K, hipStream_t s) const {
+        return h ? f5hf::f5_launch_fold_consts(reinterpret_cast<const f5hf::op16_t*>(w), ldw, bias, scale, shift, vec_stride, nvec, c1, c2,
+                                               out_stride, N, K, s)
+                 : f5bf::f5_launch_fold_consts(w, ldw, bias, scale, shift, vec_stride, nvec, c1, c2, out_stride, N, K, s);
+    }
     int attention(const F5AttnArgs& a, hipStream_t s) const {
         return h ? f5hf::f5_launch_attention(reinterpret_cast<const f5hf::F5AttnArgs&>(a), s) : f5bf::f5_launch_attention(a, s);
     }

@@ -217,7 +217,7 @@ class Engine:
         return int(self.lib.f5_engine_graph_count(self._h))
 
     def set_option(self, name: str, value: int) -> None:
-        """Per-engine launch option ("q_premul", "qkv_transposed", "ln_fusion", "gemm_flags", "attn_pipe"; include/f5tts_hip.h): other engines of
+        """Per-engine launch option ("q_premul", "qkv_transposed", "ln_fusion", "gemm_flags", "attn_pipe", "null_keeps_cond", "ln_fold"; include/f5tts_hip.h): other engines of
         the process keep their own values, cached hipGraphs are keyed on them."""
         check(self.lib.f5_engine_set_option(self._h, name.encode(), int(value)), f"f5_engine_set_option({name})")
 

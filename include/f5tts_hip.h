@@ -65,7 +65,9 @@ int f5_engine_graph_count(f5_engine* e);
  * fused behind small-tile residual GEMMs, measured slower), "gemm_flags" (0; F5GemmArgs debug bits of this engine's launches),
  * "attn_pipe" (-1 = the process default of f5_debug_set_attn_pipe, 0 = large-grid attention kernel v2f, 1 = in-wave software-pipelined v2p),
  * "null_keeps_cond" (0; 1 = the second branch of f5_dit_forward / f5_sample keeps the audio conditioning and drops only the text:
- * DiT.__call__(drop_audio_cond=False, drop_text=True), dit.py:374-401).
+ * DiT.__call__(drop_audio_cond=False, drop_text=True), dit.py:374-401), "ln_fold" (LN-modulate folded into the epilogues of the block
+ * GEMMs around it, see f5_debug_set_op_fold_producer: -1 = wherever the four block GEMMs run on the 256x256 / role-split 128x256
+ * kernels in the f16 / bf16 modes (batch >= 4 at the 335M shape), 0 = never, 1 = required: f5_sample fails where it cannot run).
  * Part of the hipGraph cache key.  New engines start from the process defaults (f5_debug_set_ln_fusion / _qkv_transposed /
  * _q_premul). */
 int f5_engine_set_option(f5_engine* e, const char* name, int value);
@@ -265,6 +267,17 @@ int f5_debug_set_attn_pipe(int v);
 int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the residual GEMMs of small-M launches (default 0: measured slower) */
 int f5_debug_set_qkv_transposed(int on);    /* 1 (default): sample() hands the pair-major rotation tables to the QKV projection (256x256 kernel: transposed q / k tiles) */
 int f5_debug_set_q_premul(int on);          /* 1 (default): sample() multiplies q by softmax_scale * log2(e) in the QKV epilogue (single-segment operand modes) */
+/* LN-modulate folded into the GEMMs around it (dit.py:270 / :321 between the residual updates :319 / :323 and the projections;
+ * csrc/gemm.hpp fold_*; engine option "ln_fold"):  (LN(x)(1 + s) + b) W^T + bias = rstd ((x (1 + s)) W^T) - rstd mean c1 + c2.
+ * Op-level twins: with a producer set, f5_op_gemm_resid_gate also writes x (1 + next_scale) as [M][N] 16-bit operands and the row sums
+ * [M][N / 64][2]; with a consumer set, f5_op_gemm (epi 2) and f5_op_qkv_rope take those as A operand / stats and finish the LN in
+ * their epilogues (bias ignored: it is inside c2).  Shapes must run on the 256x256 / role-split 128x256 kernels.  NULLs = off. */
+int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float* stats_out);
+int f5_debug_set_op_fold_consumer(const float* stats, int nslice, const float* c1, const float* c2);
+/* c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k] shift_v[k] + bias[n] for nvec modulation vectors (vec_stride
+ * floats apart; result rows out_stride floats apart); K % 256 == 0, K <= 2048 */
+int f5_op_fold_consts(const void* w_hi, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,
+                      float* c1, float* c2, size_t out_stride, int N, int K, void* stream);
 /* op-level twins for f5_op_qkv_rope / f5_op_attention */
 int f5_debug_set_op_rope_tables_t(const float* cos_tq, const float* sin_tq, const float* cos_tk, const float* sin_tk); /* NULLs = off */
 int f5_debug_set_op_q_premul(float factor); /* f5_op_qkv_rope scales q by factor, f5_op_attention expects q pre-scaled; 0 = off (default) */

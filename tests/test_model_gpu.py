@@ -780,6 +780,73 @@ def test_fullsize_mid_batches_every_utterance_vs_oracle(full_f16, B):
     assert torch.equal(out2.cpu(), out)
 
 
+@pytest.mark.parametrize("B", [4, 8, 16])
+def test_fullsize_ln_fold_every_utterance_vs_oracle(full_f16, B):
+    """LN fold (engine option "ln_fold", csrc/gemm.hpp fold_*): 44 of the 46 LN-modulate launches of a forward folded into the epilogues
+    of the GEMMs around them.  B = 4: all four block GEMMs on the role-split 128 x 256 kernel; B = 8 / 16: QKV (and FF1) on the 256 x 256
+    kernel, the residual GEMMs role-split.  Same gate and same oracle answers as the test above; the result must differ from the unfolded
+    path (it is a different rounding sequence -- identical bits would mean the option did nothing) and replay bit-identically from a graph."""
+    import os
+    from f5test import ROOT
+    import bench
+    mg = _golden_module("make_batch_golden")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_b16_euler5.npz"))
+    cond, text, y0, _ = bench.synth_batch(B, 0, DEV)
+    f5 = F5TTS(transformer=full_f16)
+    base, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=False, **mg.KW)
+    full_f16.engine.set_option("ln_fold", 1)
+    try:
+        out, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=False, **mg.KW)
+        out2, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=True, **mg.KW)
+        torch.cuda.synchronize()
+    finally:
+        full_f16.engine.set_option("ln_fold", 0)
+    out, base = out.cpu(), base.cpu()
+    assert torch.isfinite(out).all() and torch.equal(out2.cpu(), out)
+    l1 = [float((out[i] - torch.from_numpy(g["out"][i])).abs().mean()) for i in range(B)]
+    l1b = [float((base[i] - torch.from_numpy(g["out"][i])).abs().mean()) for i in range(B)]
+    print(f"[ln_fold] B={B} f16 vs fp32 oracle, mel L1 per utterance: worst {max(l1):.3e} mean {np.mean(l1):.3e} "
+          f"(unfolded: worst {max(l1b):.3e} mean {np.mean(l1b):.3e}); folded vs unfolded {float((out - base).abs().mean()):.3e}")
+    assert max(l1) <= MEL_L1_TOL, l1
+    assert not torch.equal(out, base)
+
+
+def test_ln_fold_ragged_batch_and_where_it_cannot_run(full_f16):
+    """ln_fold on the RAGGED full-size batch (masked residual rows keep x: their x16 / row sums must still be written), and the option's
+    three values: 1 fails loudly at batch 1 (small-tile GEMMs), -1 silently keeps the LN kernels there, 0 is the default."""
+    import os
+    from f5test import ROOT
+    import bench
+    from f5_tts_mlx_amd.audio import log_mel_spectrogram
+    mg = _golden_module("make_batch_golden")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_b8_ragged_euler5.npz"))
+    waves, text, y0, dur = mg.ragged_inputs()
+    cond = log_mel_spectrogram(torch.from_numpy(waves).to(DEV))
+    f5 = F5TTS(transformer=full_f16)
+    eng = full_f16.engine
+    assert eng.get_option("ln_fold") == 0
+    eng.set_option("ln_fold", 1)
+    try:
+        out, _ = f5.sample(cond, torch.from_numpy(text), duration=torch.from_numpy(dur), y0=torch.from_numpy(y0), use_graph=False, **mg.KW)
+        torch.cuda.synchronize()
+        out, ref = out.cpu(), torch.from_numpy(g["out"])
+        l1v = [float((out[i, :d] - ref[i, :d]).abs().mean()) for i, d in enumerate(dur.tolist())]
+        print(f"[ln_fold ragged] mel L1 on the valid frames: worst {max(l1v):.3e}")
+        assert torch.isfinite(out).all() and max(l1v) <= MEL_L1_TOL, l1v
+        c1, t1, y1, _ = bench.synth_batch(1, 0, DEV)
+        with pytest.raises(RuntimeError, match="ln_fold"):
+            f5.sample(c1, t1, duration=mg.N_FRAMES, y0=y1, use_graph=False, **mg.KW)
+        eng.set_option("ln_fold", -1)
+        assert eng.get_option("ln_fold") == -1
+        a, _ = f5.sample(c1, t1, duration=mg.N_FRAMES, y0=y1, use_graph=False, **mg.KW)
+        eng.set_option("ln_fold", 0)
+        b, _ = f5.sample(c1, t1, duration=mg.N_FRAMES, y0=y1, use_graph=False, **mg.KW)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+    finally:
+        eng.set_option("ln_fold", 0)
+
+
 def test_fullsize_ragged_batch_vs_oracle(full_f16):
     """a RAGGED full-size batch (B = 8, durations 937 ... 500, text padded by a different amount per utterance):
     the key mask with real kv_len in the attention kernels, attention-output rows zeroed at padded positions through `rowkeep` in the

@@ -138,3 +138,8 @@ def test_fp16_producers_saturate(lib):
 @pytest.mark.parametrize("tile", [0, 14])
 def test_gemm_rs128_several_rounds_all_epilogues_f16(lib, tile):
     T.test_gemm_rs128_several_rounds_all_epilogues(lib, tile)
+
+
+@pytest.mark.parametrize("tile", [4, 14])
+def test_ln_modulate_folded_into_the_gemms_around_it_f16(lib, tile):
+    T.test_ln_modulate_folded_into_the_gemms_around_it(lib, tile)

@@ -867,6 +867,152 @@ def test_gemm_rs128_several_rounds_all_epilogues(lib, tile):
         E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+@pytest.mark.parametrize("tile", [4, 14])
+def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
+    """LN fold (csrc/gemm.hpp fold_*; dit.py:319-321 and :323 -> :270 -> :136): the residual GEMM leaves x (1 + s) as 16-bit operands
+    plus per-row partial sums, the QKV / FF1 GEMM finishes the LN in its epilogue:
+        (LN(x)(1 + s) + b) W^T + bias = rstd ((x (1 + s)) W^T) - rstd mean c1 + c2,   c1 = W (1 + s),  c2 = W b + bias.
+    Both staged kernels (tile 4 = 256x256, 14 = role-split 128x256), ragged last row tile, masked rows.  Checked piece by piece:
+    x bit-identical to the plain launch, x16 the exact rounding of x (1 + s), the row sums and the constants against fp64, and the
+    consumer outputs against an fp64 evaluation of the folded formula on the SAME operands (sharp: one 16-bit rounding) as well as
+    against the exact LN-modulate + GEMM (the precision claim)."""
+    r = rng(4100 + tile)
+    Bq, Nq, H, D, FF = 8, 937, 16, 1024, 2048
+    M = Bq * Nq
+    eps_op = 2.0 ** -8 if op_dtype() == torch.bfloat16 else 2.0 ** -11
+    a = randn(r, M, D)
+    wo, bo, gate, x0 = randn(r, D, D, scale=D ** -0.5), randn(r, D, scale=0.1), randn(r, D), randn(r, M, D)
+    x0 += 0.5 * randn(r, M, 1) + 0.3 * randn(r, 1, D)                      # row means and column offsets: the cancellation the fold must survive
+    keep = torch.from_numpy((r.random(M) > 0.3).astype(np.uint8))
+    sv = torch.stack([randn(r, D, scale=0.3), randn(r, D, scale=0.3)])     # two modulation vectors: the second one is used (strides)
+    bv = torch.stack([randn(r, D, scale=0.3), randn(r, D, scale=0.3)])
+    a_hi, _ = split_bf16(a.to(DEV))
+    wo_hi, _ = split_bf16(wo.to(DEV))
+    bo_d, gate_d, keep_d, sv_d, bv_d = bo.to(DEV), gate.to(DEV), keep.to(DEV), sv.to(DEV), bv.to(DEV)
+    x_plain, x = x0.to(DEV).clone(), x0.to(DEV).clone()
+    x16 = torch.zeros((M, D), dtype=op_dtype(), device=DEV)
+    stats = torch.full((M, D // 64, 2), float("nan"), device=DEV)
+    s1, b1 = sv[1], bv[1]
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(wo_hi), P(None), P(bo_d), P(gate_d), P(keep_d), P(x_plain), M, D, D, D, D, D, 1,
+                                          stream()), "resid_gate plain")
+        E.check(lib.f5_debug_set_op_fold_producer(P(sv_d[1]), P(x16), P(stats)))
+        try:
+            E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(wo_hi), P(None), P(bo_d), P(gate_d), P(keep_d), P(x), M, D, D, D, D, D, 1,
+                                              stream()), "resid_gate fold producer")
+        finally:
+            E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None)))
+        sync()
+        assert torch.equal(x, x_plain), "the fold producer changed the residual stream"
+        xc = x.cpu()
+        want16 = (xc * (1.0 + s1)).to(op_dtype())
+        assert torch.equal(x16.cpu(), want16), "x16 is not the rounding of x (1 + s)"
+        xs = xc.double().reshape(M, D // 64, 64)
+        st = stats.cpu().double()
+        assert float((st[..., 0] - xs.sum(-1)).abs().max()) <= 1e-5 * float(xs.abs().sum(-1).max())
+        assert float((st[..., 1] - (xs * xs).sum(-1)).abs().max()) <= 1e-5 * float((xs * xs).sum(-1).max())
+        # --- constants, for both consumers
+        w1, bias1 = randn(r, FF, D, scale=D ** -0.5), randn(r, FF, scale=0.1)
+        wq, biasq = randn(r, 3 * D, D, scale=D ** -0.5), randn(r, 3 * D, scale=0.1)
+        w1_hi, _ = split_bf16(w1.to(DEV))
+        wq_hi, _ = split_bf16(wq.to(DEV))
+        bias1_d, biasq_d = bias1.to(DEV), biasq.to(DEV)
+        consts = {}
+        for nm, w_hi, wf, bias_d, bias, Nn in (("ff1", w1_hi, w1, bias1_d, bias1, FF), ("qkv", wq_hi, wq, biasq_d, biasq, 3 * D)):
+            c1 = torch.full((2, Nn + 64), float("nan"), device=DEV)
+            c2 = torch.full((2, Nn + 64), float("nan"), device=DEV)
+            E.check(lib.f5_op_fold_consts(P(w_hi), D, P(bias_d), P(sv_d), P(bv_d), C.c_size_t(D), 2, P(c1), P(c2), C.c_size_t(Nn + 64), Nn, D,
+                                          stream()), "fold_consts")
+            sync()
+            w64 = bf16r(wf).double()
+            for v in range(2):
+                r1, r2 = w64 @ (1.0 + sv[v].double()), w64 @ bv[v].double() + bias.double()
+                assert float((c1[v, :Nn].cpu().double() - r1).abs().max()) <= 2e-5 * float(r1.abs().max()), nm
+                assert float((c2[v, :Nn].cpu().double() - r2).abs().max()) <= 2e-5 * max(1.0, float(r2.abs().max())), nm
+            assert bool(torch.isnan(c1[:, Nn:]).all()) and bool(torch.isnan(c2[:, Nn:]).all())
+            consts[nm] = (c1, c2, w64)
+        # --- the folded formula in fp64 on the operands the consumers see, and the exact LN-modulate + projection
+        x64 = xc.double()
+        mean, var = x64.mean(-1, keepdim=True), x64.var(-1, unbiased=False, keepdim=True)
+        rstd = (var + 1e-6).rsqrt()
+        h_exact = (x64 - mean) * rstd * (1.0 + s1.double()) + b1.double()
+
+        def folded(nm, bias):
+            c1, c2, w64 = consts[nm]
+            return rstd * (want16.double() @ w64.T) - rstd * mean * c1[1, :w64.shape[0]].cpu().double() + c2[1, :w64.shape[0]].cpu().double()
+
+        # FF1 + GELU-tanh
+        out16 = torch.zeros((M, FF), dtype=op_dtype(), device=DEV)
+        c1, c2, w64 = consts["ff1"]
+        E.check(lib.f5_debug_set_op_fold_consumer(P(stats), D // 64, P(c1[1]), P(c2[1])))
+        try:
+            E.check(lib.f5_op_gemm(P(x16), P(None), P(w1_hi), P(None), P(None), P(None), P(out16), P(None), M, FF, D, D, D, FF, 1, 2, stream()),
+                    "gemm gelu folded")
+            sync()
+            sharp = F.gelu(folded("ff1", bias1), approximate="tanh")
+            exact = F.gelu(h_exact @ w64.T + bias1.double(), approximate="tanh")
+            mx, _, _ = report(f"LN fold FF1 tile={tile}: vs the folded formula in fp64", out16.float().cpu(), sharp)
+            assert mx <= 2.5 * eps_op * max(1.0, float(sharp.abs().max()))
+            mx, _, l1 = report(f"LN fold FF1 tile={tile}: vs exact LN-modulate + GEMM", out16.float().cpu(), exact)
+            assert mx <= 2.5e-2 * max(1.0, float(exact.abs().max()))
+            # --- QKV + RoPE + V^T, transposed q / k tiles, q pre-multiplied (as sample() runs it)
+            npad = (Nq + 63) // 64 * 64
+            cos_t, sin_t = torch.empty((Nq, 32), device=DEV), torch.empty((Nq, 32), device=DEV)
+            E.check(lib.f5_op_rope_table(P(cos_t), P(sin_t), Nq, 64, stream()))
+            tt = [torch.empty((32, Nq), device=DEV) for _ in range(4)]
+            E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), Nq, 64, C.c_float(QPRE), stream()))
+            qk = torch.zeros((M, 2 * D), dtype=op_dtype(), device=DEV)
+            vt = torch.zeros((Bq * H, 64, npad), dtype=op_dtype(), device=DEV)
+            c1, c2, w64 = consts["qkv"]
+            E.check(lib.f5_debug_set_op_fold_consumer(P(stats), D // 64, P(c1[1]), P(c2[1])))
+            E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
+            E.check(lib.f5_debug_set_op_q_premul(C.c_float(QPRE)))
+            try:
+                E.check(lib.f5_op_qkv_rope(P(x16), P(None), P(wq_hi), P(None), P(None), P(cos_t), P(sin_t), P(qk), P(None), P(vt), P(None),
+                                           Bq, Nq, npad, H, D, 1, stream()), "qkv_rope folded")
+                sync()
+            finally:
+                E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+                E.check(lib.f5_debug_set_op_q_premul(C.c_float(0.0)))
+        finally:
+            E.check(lib.f5_debug_set_op_fold_consumer(P(None), 0, P(None), P(None)))
+        freqs = O.rotary_freqs(64, Nq).double()
+        got_q = qk.float().cpu()[:, :D].reshape(Bq, Nq, H, 64).transpose(1, 2) / QPRE
+        got_k = qk.float().cpu()[:, D:].reshape(Bq, Nq, H, 64).transpose(1, 2)
+        got_v = vt.float().cpu().reshape(Bq, H, 64, npad)[..., :Nq].transpose(-1, -2)
+        for label, qkv in (("folded formula", folded("qkv", biasq)), ("exact LN", h_exact @ w64.T + biasq.double())):
+            q, k, v = [t.reshape(Bq, Nq, H, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+            q, k = O.apply_rotary_pos_emb(q, freqs), O.apply_rotary_pos_emb(k, freqs)
+            for nm, g, rf in (("q", got_q, q), ("k", got_k, k), ("v", got_v, v)):
+                mx, _, _ = report(f"LN fold QKV tile={tile} {nm} vs {label}", g, rf)
+                rot = 0.0 if nm == "v" else 2.0 * Nq * 2.0 ** -23
+                tol = 2.5 * eps_op if label == "folded formula" else 2.5e-2
+                assert mx <= (tol + rot) * max(1.0, float(rf.abs().max())), (nm, label)
+        assert float(vt.float().cpu().reshape(Bq, H, 64, npad)[..., Nq:].abs().max()) == 0.0
+    finally:
+        E.check(lib.f5_debug_set_gemm_tile(0))
+
+
+def test_ln_fold_fields_fail_loudly_on_small_tile_launches(lib):
+    """The fold fields are only implemented by the staged epilogues: a launch that would run a small-tile kernel must refuse them."""
+    r = rng(5)
+    M, D = 937, 1024
+    a_hi, _ = split_bf16(randn(r, M, D).to(DEV))
+    w_hi, _ = split_bf16(randn(r, D, D, scale=D ** -0.5).to(DEV))
+    gate, sc = randn(r, D).to(DEV), randn(r, D).to(DEV)
+    x = randn(r, M, D).to(DEV)
+    x16 = torch.zeros((M, D), dtype=op_dtype(), device=DEV)
+    stats = torch.zeros((M, D // 64, 2), device=DEV)
+    E.check(lib.f5_debug_set_op_fold_producer(P(sc), P(x16), P(stats)))
+    try:
+        rc = lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(w_hi), P(None), P(None), P(gate), P(None), P(x), M, D, D, D, D, D, 1, stream())
+    finally:
+        E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None)))
+    sync()
+    assert rc != 0 and "LN fold" in lib.f5_last_error().decode()
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 4, 5])
 @pytest.mark.parametrize("nseg", [1, 3])
 def test_gemm_addrows(lib, tile, nseg):
