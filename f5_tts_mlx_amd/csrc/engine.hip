@@ -60,7 +60,8 @@ struct Workspace {
     size_t hc, x;
     size_t xb[2], c1[2], h[2], qk[2], vt[2], ao[2], ffh[2];
     size_t h8, h8s, ao8, ao8s, ffh8, ffh8s;   // precision mxfp8: block-GEMM A operands as e4m3 + E8M0
-    size_t lnstats;                // LN fold: per row and 64-column slice (sum, sum of squares) of the residual stream, [M2][D / 64][2] floats
+    size_t lnstats;                // LN fold: per 64-column slice and row (sum, sum of squares) of the residual stream, [D / 64][M2][2] floats
+    size_t lnrowf;                 // LN fold: row factors (rstd, rstd * mean), [M2][2] floats
     size_t foldc[2];               // LN fold: c1, c2 tables, [nfe][L][3 D + FF] floats each
     size_t vt_bytes;
 };
@@ -82,8 +83,9 @@ struct F5Options {
     int fuse_ln = 0;      // LN-modulate fused behind the small-tile residual GEMMs (measured slower, profiles/r02/ln_fusion_ab.txt)
     int gemm_flags = 0;   // F5GemmArgs::debug_flags of this engine's GEMM launches
     int attn_pipe = -1;   // large-grid attention: -1 = process default (f5_debug_set_attn_pipe), 0 = v2f, 1 = v2p (in-wave software pipeline)
-    int ln_fold = 0;      // LN-modulate folded into the GEMMs around it (gemm.hpp fold_*): -1 = wherever the four block GEMMs run on the staged
-                          // kernels (one-pass operand modes, batch >= 4), 0 = never, 1 = required (fails loudly where it cannot run)
+    int ln_fold = -1;     // LN-modulate folded into the GEMMs around it (gemm.hpp fold_*): -1 = where it is measured faster (>= LN_FOLD_AUTO_ROWS
+                          // rows and the four block GEMMs on the staged kernels, one-pass operand modes), 0 = never, 1 = wherever it can run
+                          // (batch >= 4 at the 335M shape; fails loudly elsewhere)
     int null_keeps_cond = 0;   // the second (null) branch keeps the audio conditioning: DiT.__call__(drop_audio_cond=False, drop_text=True), dit.py:374-401
 };
 static F5Options g_default_options;
@@ -505,6 +507,7 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
         w.ffh[p] = p < np ? b.take(M2 * FF * 2) : 0;
     }
     w.lnstats = b.take(M2 * (size_t)((D + 63) / 64) * 2 * 4);
+    w.lnrowf = b.take(M2 * 2 * 4);
     for (int p = 0; p < 2; ++p) w.foldc[p] = b.take(nfe1 * L * (size_t)(3 * D + FF) * 4);
     w.h8 = w.h8s = w.ao8 = w.ao8s = w.ffh8 = w.ffh8s = 0;
     if (e->prec == F5_PREC_MXFP8) {
@@ -600,6 +603,10 @@ static int ln_fold_state(const Ctx& c) {
             ok = ok && c.ops.gemm_runs_staged(g, sh[2]);
         }
     }
+    // measured on sample(), 335M shape, f16 (profiles/r04/ln_fold_ab.jsonl): batch 4 -1.2 %, 8 -1.1 %, 12 +0.3 %, 16 +0.8 %, 32 +2.5 %: the
+    // LN launches it removes cost ~2 us per thousand rows, what it adds (x16 write in the residual epilogues, the row-factor kernel) has a floor
+    constexpr int LN_FOLD_AUTO_ROWS = 22000;
+    if (e->opt.ln_fold < 0 && M < LN_FOLD_AUTO_ROWS) return 0;
     if (!ok && e->opt.ln_fold == 1) {
         f5_set_error("ln_fold = 1: this shape / precision cannot run the folded LN (needs f16 or bf16, qkv_transposed, no ln_fusion, dim %% 256 "
                      "== 0, and all four block GEMMs on the 256x256 / role-split 128x256 kernels: batch >= 4 at the 335M shape)");
@@ -852,18 +859,18 @@ static int run_dit(const Ctx& c, int j) {
     const float* fc1 = c.p<float>(w.foldc[0]) + (size_t)j * L * (3 * D + FF);
     const float* fc2 = c.p<float>(w.foldc[1]) + (size_t)j * L * (3 * D + FF);
     auto fold_consumer = [&](F5GemmArgs& g, int block, int col0) {
-        g.fold_stats = c.p<float>(w.lnstats);
-        g.fold_nslice = D / 64;
+        g.fold_rowf = c.p<float>(w.lnrowf);
         g.fold_c1 = fc1 + (size_t)block * (3 * D + FF) + col0;
         g.fold_c2 = fc2 + (size_t)block * (3 * D + FF) + col0;
-        g.fold_eps = 1e-6f;
     };
     auto fold_producer = [&](F5GemmArgs& g, const float* next_scale) {
         g.x16_out = c.pb(w.h, 0);
         g.ldx16 = D;
         g.x16_scale = next_scale;
         g.stats_out = c.p<float>(w.lnstats);
+        g.stats_ld = M;
     };
+    auto fold_rows = [&]() { return K.fold_rows(c.p<float>(w.lnstats), M, D / 64, M, 1e-6f, c.p<float>(w.lnrowf), s); };
     bool h_folded = false;                       // `h` holds x (1 + scale) + row sums (fold) instead of the finished LN-modulate
     for (int i = 0; i < L && e->prec != F5_PREC_MXFP8; ++i) {
         const BlockW& bw = e->blocks[i];
@@ -923,6 +930,7 @@ static int run_dit(const Ctx& c, int j) {
         const bool fused_mlp_ln = fuse_ln(go, m6 + 4 * D, m6 + 3 * D);     // h = LN(x) (1 + scale_mlp) + shift_mlp in the same launch
         if (fold) fold_producer(go, m6 + 4 * D);
         RC(K.gemm(go, EPI_RESID_GATE, s));
+        if (fold) RC(fold_rows());
 
         if (!fused_mlp_ln && !fold) RC(K.ln_modulate(c.p<float>(w.x), m6 + 4 * D, m6 + 3 * D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
         F5GemmArgs g1 = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.ff1, M, FF, D, c.a<float>(bw.bff1));
@@ -944,6 +952,7 @@ static int run_dit(const Ctx& c, int j) {
             h_ready = true;
         }
         RC(K.gemm(g2, EPI_RESID_GATE, s));
+        if (h_folded) RC(fold_rows());
     }
     if (!h_ready) RC(K.ln_modulate(c.p<float>(w.x), mf, mf + D, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
     F5GemmArgs gf = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, e->wout, M, cf.mel_dim, D, c.a<float>(e->bout));
@@ -1389,8 +1398,7 @@ static struct {
     const float* next_scale = nullptr;       // producer: f5_op_gemm_resid_gate
     op16_t* x16 = nullptr;
     float* stats_out = nullptr;
-    const float* stats = nullptr;            // consumer: f5_op_gemm (epi 2), f5_op_qkv_rope
-    int nslice = 0;
+    const float* rowf = nullptr;             // consumer: f5_op_gemm (epi 2), f5_op_qkv_rope
     const float* c1 = nullptr;
     const float* c2 = nullptr;
 } g_op_fold;
@@ -1400,19 +1408,19 @@ extern "C" int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_
     g_op_fold.stats_out = stats_out;
     return 0;
 }
-extern "C" int f5_debug_set_op_fold_consumer(const float* stats, int nslice, const float* c1, const float* c2) {
-    g_op_fold.stats = stats;
-    g_op_fold.nslice = nslice;
+extern "C" int f5_debug_set_op_fold_consumer(const float* rowf, const float* c1, const float* c2) {
+    g_op_fold.rowf = rowf;
     g_op_fold.c1 = c1;
     g_op_fold.c2 = c2;
     return 0;
 }
 static void op_fold_consumer(F5GemmArgs& g) {
-    g.fold_stats = g_op_fold.stats;
-    g.fold_nslice = g_op_fold.nslice;
+    g.fold_rowf = g_op_fold.rowf;
     g.fold_c1 = g_op_fold.c1;
     g.fold_c2 = g_op_fold.c2;
-    g.fold_eps = 1e-6f;
+}
+extern "C" int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, void* stream) {
+    return g_ops.fold_rows(stats, M, nslice, M, 1e-6f, rowf, (hipStream_t)stream);
 }
 extern "C" int f5_op_fold_consts(const void* w_hi, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride,
                                  int nvec, float* c1, float* c2, size_t out_stride, int N, int K, void* stream) {
@@ -1442,7 +1450,7 @@ extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, 
     g.out_bf[0] = (op16_t*)out_bf_hi;
     g.out_bf[1] = (op16_t*)out_bf_lo;
     g.ldob = ldo;
-    if (epi == EPI_GELU_TANH && g_op_fold.stats != nullptr) op_fold_consumer(g);
+    if (epi == EPI_GELU_TANH && g_op_fold.rowf != nullptr) op_fold_consumer(g);
     return g_ops.gemm(g, epi, (hipStream_t)stream);
 }
 
@@ -1558,7 +1566,7 @@ extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_
     g.rope_ldt = seq_len;
     g.vt[0] = (op16_t*)vt_hi;
     g.vt[1] = (op16_t*)vt_lo;
-    if (g_op_fold.stats != nullptr) op_fold_consumer(g);
+    if (g_op_fold.rowf != nullptr) op_fold_consumer(g);
     return g_ops.gemm(g, EPI_QKV_ROPE, (hipStream_t)stream);
 }
 
@@ -1719,6 +1727,7 @@ extern "C" int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const v
         g.ldx16 = N;
         g.x16_scale = g_op_fold.next_scale;
         g.stats_out = g_op_fold.stats_out;
+        g.stats_ld = M;
     }
     return g_ops.gemm(g, EPI_RESID_GATE, (hipStream_t)stream);
 }

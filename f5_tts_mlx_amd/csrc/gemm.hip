@@ -765,6 +765,31 @@ __global__ __launch_bounds__(256) void f5_fold_consts_kernel(const op16_t* __res
     }
 }
 
+__global__ __launch_bounds__(256) void f5_fold_rows_kernel(const float* __restrict__ stats, int ld, int nslice, int M, float eps,
+                                                           float* __restrict__ rowf) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const f5_f32x2* sp = reinterpret_cast<const f5_f32x2*>(stats) + m;
+    float s = 0.0f, q = 0.0f;
+#pragma unroll 8
+    for (int i = 0; i < nslice; ++i) {                  // slice order: deterministic
+        const f5_f32x2 t = sp[(size_t)i * ld];
+        s += t[0];
+        q += t[1];
+    }
+    const float inv_n = 1.0f / (64.0f * (float)nslice);
+    const float mean = s * inv_n;
+    const float var = fmaxf(q * inv_n - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + eps);
+    reinterpret_cast<f5_f32x2*>(rowf)[m] = f5_f32x2{rstd, rstd * mean};
+}
+int f5_launch_fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, hipStream_t stream) {
+    F5_REQUIRE(stats && rowf && nslice >= 1 && M >= 1 && ld >= M, "fold_rows: bad arguments");
+    hipLaunchKernelGGL(f5_fold_rows_kernel, dim3(f5_cdiv(M, 256)), dim3(256), 0, stream, stats, ld, nslice, M, eps, rowf);
+    F5_LAUNCH_CHECK();
+    return 0;
+}
+
 int f5_launch_fold_consts(const op16_t* w, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,
                           float* c1, float* c2, size_t out_stride, int N, int K, hipStream_t stream) {
     F5_REQUIRE(w && scale && shift && c1 && c2 && N > 0 && nvec > 0, "fold_consts: null argument");
@@ -798,7 +823,7 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     if (sel == 4 || (sel == 0 && v2ok && t256 >= 512)) {
         F5_REQUIRE(v2ok, "gemm: the 256x256 kernel needs N %% 256 == 0 and M >= 256");
 #if F5_LAB
-        F5_REQUIRE((a.x16_out == nullptr && a.fold_stats == nullptr) || (f5_gemm_big_kernel == 2 && !f5_gemm_streamk),
+        F5_REQUIRE((a.x16_out == nullptr && a.fold_rowf == nullptr) || (f5_gemm_big_kernel == 2 && !f5_gemm_streamk),
                    "gemm: the LN fold needs the product 256x256 kernel");
         if (f5_gemm_big_kernel == 4 || f5_gemm_streamk) return f5_launch_gemm_lab_v2(a, EPI, stream);      // lock-step predecessor (A/B)
         if constexpr (EPI == EPI_F32 || EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_RESID_GATE || EPI == EPI_QKV_ROPE) {
@@ -833,8 +858,8 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
         if ((sel == 14 || qkv14 || mid) && a.N % 256 == 0 && a.ln_counter == nullptr) return f5_launch_gemm_rs128(a, EPI, stream);
         if (sel == 14) sel = 0;
     }
-    F5_REQUIRE(a.x16_out == nullptr && a.fold_stats == nullptr,
-               "gemm: the LN fold (x16_out / fold_stats) needs a launch on the 256x256 or the role-split 128x256 kernel (f5_gemm_runs_staged)");
+    F5_REQUIRE(a.x16_out == nullptr && a.fold_rowf == nullptr,
+               "gemm: the LN fold (x16_out / fold_rowf) needs a launch on the 256x256 or the role-split 128x256 kernel (f5_gemm_runs_staged)");
     if constexpr (EPI == EPI_QKV_ROPE) {
         // batch-1-sized QKV projection with pair-major tables: one round of 8-wave 128 x 256 tiles with transposed q / k wave tiles
         // (f5_gemm_qkv_small_tile = 13 / 12) instead of 64 x 128 register-staged tiles (0)
@@ -893,18 +918,16 @@ int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
                "gemm: operands must stay below 4 GiB (the kernels use 32-bit byte offsets)");
     F5_REQUIRE(epi != EPI_RESID_GATE || (size_t)a.M * a.ldo * 4 < (1ull << 32), "gemm(resid): the residual stream must stay below 4 GiB");
     if (a.x16_out != nullptr || a.stats_out != nullptr) {
-        F5_REQUIRE(epi == EPI_RESID_GATE && a.x16_out && a.stats_out && a.x16_scale && a.N % 64 == 0 && a.ldx16 % 4 == 0 &&
-                       (reinterpret_cast<uintptr_t>(a.x16_scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.x16_out) & 7) == 0,
+        F5_REQUIRE(epi == EPI_RESID_GATE && a.x16_out && a.stats_out && a.x16_scale && a.N % 64 == 0 && a.ldx16 % 4 == 0 && a.stats_ld >= a.M &&
+                       (reinterpret_cast<uintptr_t>(a.x16_scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.x16_out) & 7) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.stats_out) & 7) == 0,
                    "gemm: LN-fold producer needs EPI_RESID_GATE, x16_out + stats_out + x16_scale (16-byte aligned), N %% 64 == 0");
     }
-    if (a.fold_stats != nullptr) {
+    if (a.fold_rowf != nullptr) {
         F5_REQUIRE((epi == EPI_QKV_ROPE || epi == EPI_GELU_TANH) && a.nseg == 1 && a.out_bf[1] == nullptr && a.fold_c1 && a.fold_c2 &&
-                       a.fold_nslice >= 2 && a.fold_nslice % 2 == 0 && a.fold_nslice * 64 == a.K &&
-                       ((reinterpret_cast<uintptr_t>(a.fold_c1) | reinterpret_cast<uintptr_t>(a.fold_c2) |
-                         reinterpret_cast<uintptr_t>(a.fold_stats)) & 15) == 0 &&
-                       (a.debug_flags & 16384) == 0,
-                   "gemm: LN-fold consumer needs EPI_QKV_ROPE / EPI_GELU_TANH, one-pass operands, aligned fold_c1 / fold_c2 / fold_stats, "
-                   "fold_nslice == K / 64");
+                       ((reinterpret_cast<uintptr_t>(a.fold_c1) | reinterpret_cast<uintptr_t>(a.fold_c2)) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.fold_rowf) & 7) == 0 && (a.debug_flags & 16384) == 0,
+                   "gemm: LN-fold consumer needs EPI_QKV_ROPE / EPI_GELU_TANH, one-pass operands, aligned fold_c1 / fold_c2 / fold_rowf");
         F5_REQUIRE(epi != EPI_QKV_ROPE || (a.rope_cos_tk && a.dmodel % 256 == 0), "gemm(qkv): the LN fold needs the transposed q / k tiles");
         a.bias = nullptr;                             // inside fold_c2
     }

@@ -64,18 +64,18 @@ struct F5GemmArgs {
     // ---- LN-modulate folded into the GEMMs around it (round 4; 256x256 and role-split 128x256 kernels, one-pass operand modes):
     //   (LN(x) (1 + s) + b) W^T + bias  =  rstd ((x (1 + s)) W^T) - rstd mu c1 + c2,    c1 = W (1 + s),  c2 = W b + bias
     // PRODUCER (EPI_RESID_GATE): besides x it writes x (1 + s) in the 16-bit operand type (the next GEMM's A operand; s = the scale of
-    // the LN that follows, x16_scale) and, per row and 64-column slice, the partial sums (sum x, sum x^2) of the new x.  CONSUMER
-    // (EPI_QKV_ROPE with transposed q / k tiles, EPI_GELU_TANH): A = that operand, W unchanged, and the epilogue applies the row
-    // factors from the partial sums before everything else; `bias` is ignored (it is inside fold_c2, f5_launch_fold_consts).
+    // the LN that follows, x16_scale) and, per row and 64-column slice, the partial sums (sum x, sum x^2) of the new x.
+    // f5_launch_fold_rows turns the partial sums into the row factors (rstd, rstd mu).  CONSUMER (EPI_QKV_ROPE with transposed q / k
+    // tiles, EPI_GELU_TANH): A = that operand, W unchanged, and the epilogue applies the row factors before everything else; `bias`
+    // is ignored (it is inside fold_c2, f5_launch_fold_consts).
     op16_t* x16_out;          // [M][ldx16] or null
     int ldx16;
     const float* x16_scale;   // [N]: s (the kernel adds the 1)
-    float* stats_out;         // [M][N / 64][2] (sum, sum of squares) or null; both or neither
-    const float* fold_stats;  // [M][fold_nslice][2] or null = plain GEMM
-    int fold_nslice;          // slices per row (LN width / 64)
+    float* stats_out;         // [N / 64][stats_ld][2] (sum, sum of squares), slice-major, or null; x16_out and stats_out: both or neither
+    int stats_ld;             // rows per slice of stats_out (>= M)
+    const float* fold_rowf;   // [M][2] (rstd, rstd * mean) or null = plain GEMM
     const float* fold_c1;     // [N], 16-byte aligned
     const float* fold_c2;     // [N], 16-byte aligned
-    float fold_eps;
     // ---- MX-fp8 path (f5_launch_gemm_f8): e4m3 operands with one E8M0 scale per 32 consecutive K elements
     const uint8_t* A8;        // [a_rows][lda8] bytes
     const uint8_t* W8;        // [>=ceil256(N)][ldw8] bytes
@@ -91,6 +91,8 @@ int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
 // true when f5_launch_gemm runs this launch on a kernel with the LDS-staged epilogues (256x256 / role-split 128x256): the only ones
 // that implement the x16_out / stats_out / fold_* fields (f5_launch_gemm fails loudly for the others)
 bool f5_gemm_runs_staged(const F5GemmArgs& a, int epi);
+// row factors of the fold: rowf[m] = (rstd, rstd * mean) of row m from its nslice partial sums (stats[slice][ld][2]; width = 64 nslice)
+int f5_launch_fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, hipStream_t stream);
 // Constants of the fold for `nvec` modulation vectors at once: c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k]
 // shift_v[k] + bias[n], fp32 sums over the operand-typed weights the GEMM multiplies by.  scale_v = scale + v * vec_stride (floats),
 // likewise shift_v; c1 / c2 rows are out_stride floats apart.  K % 256 == 0, K <= 2048.

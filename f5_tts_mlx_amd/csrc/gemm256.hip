@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
 
     op16_t* stage = smem + wave * 8192;                 // this wave's private 16 KB of epilogue staging
     float* fl = reinterpret_cast<float*>(stage + 6144); // its last 4 KB: row factors of a folded LN-modulate (the staged tiles use <= 9 KB)
-    const bool fold = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH) && p.fold_stats != nullptr;
+    const bool fold = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH) && p.fold_rowf != nullptr;
     const int row0 = m0 + wm * 128, col0 = n0 + wn * 64;
     // 16-bit row-major outputs: the tile is accumulated TRANSPOSED (operands swapped in every MFMA) for staged_epilogue_tr.  Both
     // loop copies end in their own epilogue: no join with 128 live accumulator registers.

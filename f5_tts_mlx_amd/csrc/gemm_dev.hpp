@@ -167,32 +167,31 @@ __device__ __forceinline__ void glds16(const op16_t* gptr, op16_t* lds_wave_base
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
 
-// ---- LN-modulate folded into the consumer GEMM (F5GemmArgs::fold_*): the row factors rstd and rstd * mean of the wave's ROWS rows,
-// from the per-slice partial sums the producing residual GEMM left in fold_stats, into the wave's private LDS scratch fl[ROWS][2].
-// Lane l finalises row l (+ 64): nslice (sum, sum of squares) pairs = nslice / 2 16-byte loads, summed in slice order (deterministic).
+// ---- LN-modulate folded into the consumer GEMM (F5GemmArgs::fold_*): the finished row factors (rstd, rstd * mean) of the wave's ROWS
+// rows from fold_rowf into the wave's private LDS scratch fl[ROWS][2] (the straight V tiles hold rows in registers: they read them back
+// as broadcasts).  One 8-byte load per lane and 64 rows, coalesced.
 template <int ROWS>
 __device__ __forceinline__ void fold_rows_to_lds(const F5GemmArgs& p, float* fl, int row0, int lane) {
-    const float inv_n = 1.0f / (64.0f * (float)p.fold_nslice);
 #pragma unroll
     for (int base = 0; base < ROWS; base += 64) {
         const int r = base + lane;
         int grow = row0 + r;
         if (grow > p.M - 1) grow = p.M - 1;
-        const f32x4* sp = reinterpret_cast<const f32x4*>(p.fold_stats + (size_t)grow * p.fold_nslice * 2);
-        float s = 0.0f, q = 0.0f;
-        for (int i = 0; i < (p.fold_nslice >> 1); ++i) {
-            const f32x4 t = sp[i];
-            s += t[0];
-            q += t[1];
-            s += t[2];
-            q += t[3];
-        }
-        const float mean = s * inv_n;
-        const float var = fmaxf(q * inv_n - mean * mean, 0.0f);
-        const float rstd = rsqrtf(var + p.fold_eps);
-        if (r < ROWS) *reinterpret_cast<f5_f32x2*>(&fl[2 * r]) = f5_f32x2{rstd, rstd * mean};
+        const f5_f32x2 t = reinterpret_cast<const f5_f32x2*>(p.fold_rowf)[grow];
+        if (r < ROWS) *reinterpret_cast<f5_f32x2*>(&fl[2 * r]) = t;
     }
     __builtin_amdgcn_wave_barrier();
+}
+// the same for the transposed tiles (lane = token lcol of every 32-row block): straight into registers, requested together with the
+// bias / rotation loads of the epilogue -- no extra round trip to memory
+template <int MBW>
+__device__ __forceinline__ void fold_rows_to_regs(const F5GemmArgs& p, f5_f32x2 (&rr)[MBW], int row0, int lcol) {
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) {
+        int grow = row0 + mb * 32 + lcol;
+        if (grow > p.M - 1) grow = p.M - 1;
+        rr[mb] = reinterpret_cast<const f5_f32x2*>(p.fold_rowf)[grow];
+    }
 }
 
 // ---- LDS-staged epilogues (used by the 256x256 and the 128x256 kernels).  A wave owns a (32*MBW) x (32*NBW) tile
@@ -202,7 +201,7 @@ __device__ __forceinline__ void fold_rows_to_lds(const F5GemmArgs& p, float* fl,
 // the token axis; those 16-byte stores may be only 2-byte aligned (legal on gfx950, tools/probes/unaligned.hip) and
 // are split element-wise where a chunk crosses a batch-element boundary.
 // FOLD (V tiles only): the LN-modulate fold of F5GemmArgs::fold_* -- value = rstd * acc - rstd * mean * c1[col] + c2[col], the row
-// factors from the wave's LDS scratch `fl` (fold_rows_to_lds).
+// factors (finished by f5_launch_fold_rows) from the wave's LDS scratch `fl` (fold_rows_to_lds).
 template <int EPI, int MBW, int NBW, bool VONLY = false, bool FOLD = false>
 __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
                                                      int colbase, int lane, float* fl = nullptr) {
@@ -389,24 +388,44 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
-            b4[nb][rg] = FOLD ? *reinterpret_cast<const f32x4*>(p.fold_c2 + colbase + nb * 32 + rg * 8 + hi * 4)
-                              : (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colbase + nb * 32 + rg * 8 + hi * 4) : f32x4{0.f, 0.f, 0.f, 0.f});
-    if (FOLD) fold_rows_to_lds<32 * MBW>(p, fl, row0, lane);
+            b4[nb][rg] = (!FOLD && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + colbase + nb * 32 + rg * 8 + hi * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f5_f32x2 rrv[MBW];
+    if (FOLD) {
+        // ONE round trip to memory for everything the fold needs: the lane's row factors into registers, the wave's W columns of c1 | c2
+        // into the LDS scratch (read back as 16-byte broadcasts inside the loops: no vmcnt waits between the staging passes)
+        fold_rows_to_regs<MBW>(p, rrv, row0, lcol);
+        if (lane < W) {
+            fl[lane] = p.fold_c1[colbase + lane];
+            fl[W + lane] = p.fold_c2[colbase + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the lane's c1 / c2 quads, read back ONCE (b4 = c2): LDS reads between the staging passes would serialise on lgkmcnt(0) with the
+    // staging writes -- 32 LDS round trips per tile, measured +16 us on the FF1 launch of batch 32
+    f32x4 c1r[FOLD ? NBW : 1][4];
+    if (FOLD) {
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                c1r[nb][rg] = *reinterpret_cast<const f32x4*>(&fl[nb * 32 + rg * 8 + hi * 4]);
+                b4[nb][rg] = *reinterpret_cast<const f32x4*>(&fl[W + nb * 32 + rg * 8 + hi * 4]);
+            }
+    }
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
         const int rowblk = row0 + mb * 32;
         f5_f32x2 rr = {1.0f, 0.0f};
-        if (FOLD) rr = *reinterpret_cast<const f5_f32x2*>(&fl[2 * (mb * 32 + lcol)]);
+        if (FOLD) rr = rrv[mb];
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 float v[4];
-                f32x4 c1q = {0.f, 0.f, 0.f, 0.f};
-                if (FOLD) c1q = *reinterpret_cast<const f32x4*>(p.fold_c1 + colbase + nb * 32 + rg * 8 + hi * 4);   // (L1-resident after block 0)
+                const f32x4 c1q = FOLD ? c1r[nb][rg] : f32x4{0.f, 0.f, 0.f, 0.f}, c2q = b4[nb][rg];
 #pragma unroll
                 for (int ri = 0; ri < 4; ++ri) {
-                    v[ri] = FOLD ? rr[0] * acc[mb][nb][rg * 4 + ri] + (b4[nb][rg][ri] - rr[1] * c1q[ri]) : acc[mb][nb][rg * 4 + ri] + b4[nb][rg][ri];
+                    v[ri] = FOLD ? rr[0] * acc[mb][nb][rg * 4 + ri] + (c2q[ri] - rr[1] * c1q[ri]) : acc[mb][nb][rg * 4 + ri] + b4[nb][rg][ri];
                     if (EPI == EPI_GELU_TANH) v[ri] = f5_gelu_tanh(v[ri]);
                     if (EPI == EPI_GELU_ERF_BF16) v[ri] = f5_gelu_erf(v[ri]);
                 }
@@ -448,7 +467,15 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
     const float* st = isq ? p.rope_sin_tq : p.rope_sin_tk;
     op16_t* rh = reg;
     op16_t* rl = reg + 32 * LD;
-    if (FOLD) fold_rows_to_lds<32 * MBW>(p, fl, row0, lane);
+    f5_f32x2 rrv[MBW];
+    if (FOLD) {                                              // as staged_epilogue_tr: row factors -> registers, c1 | c2 -> LDS scratch
+        fold_rows_to_regs<MBW>(p, rrv, row0, lcol);
+        if (lane < W) {
+            fl[lane] = p.fold_c1[colbase + lane];
+            fl[W + lane] = p.fold_c2[colbase + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
         const int rowblk = row0 + mb * 32;
@@ -456,7 +483,7 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
         if (row > p.M - 1) row = p.M - 1;                    // rows past the end compute a valid rotation and are never stored
         const int n = row % p.seq_len;
         f5_f32x2 rr = {1.0f, 0.0f};
-        if (FOLD) rr = *reinterpret_cast<const f5_f32x2*>(&fl[2 * (mb * 32 + lcol)]);
+        if (FOLD) rr = rrv[mb];
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
             // one batch of loads per 32-feature block: 16 rotation factors + 4 bias quads (the accumulators leave ~90 free VGPRs)
@@ -471,7 +498,7 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
                 s0[rg] = st[(size_t)j0 * p.rope_ldt + n];
                 s1[rg] = st[(size_t)(j0 + 1) * p.rope_ldt + n];
                 if (FOLD) {
-                    const f32x4 c1q = *reinterpret_cast<const f32x4*>(p.fold_c1 + c), c2q = *reinterpret_cast<const f32x4*>(p.fold_c2 + c);
+                    const f32x4 c1q = *reinterpret_cast<const f32x4*>(&fl[c - colbase]), c2q = *reinterpret_cast<const f32x4*>(&fl[W + c - colbase]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) b4[rg][e] = c2q[e] - rr[1] * c1q[e];
                 } else {
@@ -592,7 +619,7 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
                     *reinterpret_cast<u32x2*>(p.x16_out + (size_t)grow * p.ldx16 + colbase + chunk * 4) =
                         u32x2{f5_pack2(o[0] * sc4[0], o[1] * sc4[1]), f5_pack2(o[2] * sc4[2], o[3] * sc4[3])};
                     if (chunk == 0)
-                        *reinterpret_cast<f5_f32x2*>(p.stats_out + ((size_t)grow * (p.N >> 6) + (colbase >> 6)) * 2) = f5_f32x2{ps, pq};
+                        *reinterpret_cast<f5_f32x2*>(p.stats_out + ((size_t)(colbase >> 6) * p.stats_ld + grow) * 2) = f5_f32x2{ps, pq};
                 }
             }
         }

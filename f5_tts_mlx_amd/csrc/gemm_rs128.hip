@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
 
     op16_t* stage = smem + wave * 4608;                 // 9 KB of private epilogue staging per wave (32 x (64 + 8) hi + lo)
     float* fl = reinterpret_cast<float*>(smem + 8 * 4608) + wave * 128;     // behind the eight stages: row factors of a folded LN-modulate
-    const bool fold = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH) && p.fold_stats != nullptr;
+    const bool fold = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH) && p.fold_rowf != nullptr;
     const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
     constexpr bool TR_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
     if ((TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel)) {       // workgroup-uniform

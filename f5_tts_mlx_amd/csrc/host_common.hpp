@@ -57,6 +57,9 @@ struct Ops {
     bool gemm_runs_staged(const F5GemmArgs& a, int epi) const {
         return h ? f5hf::f5_gemm_runs_staged(reinterpret_cast<const f5hf::F5GemmArgs&>(a), epi) : f5bf::f5_gemm_runs_staged(a, epi);
     }
+    int fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, hipStream_t s) const {
+        return h ? f5hf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, s) : f5bf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, s);
+    }
     int fold_consts(const op16_t* w, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec, float* c1,
                     float* c2, size_t out_stride, int N, int K, hipStream_t s) const {
         return h ? f5hf::f5_launch_fold_consts(reinterpret_cast<const f5hf::op16_t*>(w), ldw, bias, scale, shift, vec_stride, nvec, c1, c2,

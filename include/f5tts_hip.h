@@ -66,8 +66,9 @@ int f5_engine_graph_count(f5_engine* e);
  * "attn_pipe" (-1 = the process default of f5_debug_set_attn_pipe, 0 = large-grid attention kernel v2f, 1 = in-wave software-pipelined v2p),
  * "null_keeps_cond" (0; 1 = the second branch of f5_dit_forward / f5_sample keeps the audio conditioning and drops only the text:
  * DiT.__call__(drop_audio_cond=False, drop_text=True), dit.py:374-401), "ln_fold" (LN-modulate folded into the epilogues of the block
- * GEMMs around it, see f5_debug_set_op_fold_producer: -1 = wherever the four block GEMMs run on the 256x256 / role-split 128x256
- * kernels in the f16 / bf16 modes (batch >= 4 at the 335M shape), 0 = never, 1 = required: f5_sample fails where it cannot run).
+ * GEMMs around it, see f5_debug_set_op_fold_producer: -1 (default) = where it is measured faster: >= 22 000 rows (batch >= 12 at the
+ * 335M shape and 937 frames) with the four block GEMMs on the 256x256 / role-split 128x256 kernels, f16 / bf16 modes; 0 = never;
+ * 1 = wherever it can run (batch >= 4 at that shape), f5_sample fails where it cannot).
  * Part of the hipGraph cache key.  New engines start from the process defaults (f5_debug_set_ln_fusion / _qkv_transposed /
  * _q_premul). */
 int f5_engine_set_option(f5_engine* e, const char* name, int value);
@@ -269,11 +270,13 @@ int f5_debug_set_qkv_transposed(int on);    /* 1 (default): sample() hands the p
 int f5_debug_set_q_premul(int on);          /* 1 (default): sample() multiplies q by softmax_scale * log2(e) in the QKV epilogue (single-segment operand modes) */
 /* LN-modulate folded into the GEMMs around it (dit.py:270 / :321 between the residual updates :319 / :323 and the projections;
  * csrc/gemm.hpp fold_*; engine option "ln_fold"):  (LN(x)(1 + s) + b) W^T + bias = rstd ((x (1 + s)) W^T) - rstd mean c1 + c2.
- * Op-level twins: with a producer set, f5_op_gemm_resid_gate also writes x (1 + next_scale) as [M][N] 16-bit operands and the row sums
- * [M][N / 64][2]; with a consumer set, f5_op_gemm (epi 2) and f5_op_qkv_rope take those as A operand / stats and finish the LN in
- * their epilogues (bias ignored: it is inside c2).  Shapes must run on the 256x256 / role-split 128x256 kernels.  NULLs = off. */
+ * Op-level twins: with a producer set, f5_op_gemm_resid_gate also writes x (1 + next_scale) as [M][N] 16-bit operands and the partial
+ * row sums [N / 64][M][2] (slice-major); f5_op_fold_rows turns those into the row factors [M][2] = (rstd, rstd * mean), eps 1e-6;
+ * with a consumer set, f5_op_gemm (epi 2) and f5_op_qkv_rope take the operands as A and finish the LN in their epilogues (bias
+ * ignored: it is inside c2).  Shapes must run on the 256x256 / role-split 128x256 kernels.  NULLs = off. */
 int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float* stats_out);
-int f5_debug_set_op_fold_consumer(const float* stats, int nslice, const float* c1, const float* c2);
+int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, void* stream);
+int f5_debug_set_op_fold_consumer(const float* rowf, const float* c1, const float* c2);
 /* c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k] shift_v[k] + bias[n] for nvec modulation vectors (vec_stride
  * floats apart; result rows out_stride floats apart); K % 256 == 0, K <= 2048 */
 int f5_op_fold_consts(const void* w_hi, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,

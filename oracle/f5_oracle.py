@@ -222,11 +222,12 @@ class DiTOracle:
         """emulate_bf16: GEMM / attention operands rounded to bf16 like the engine's `bf16` mode.  emulate_mxfp8: the engine's
         `mxfp8` mode (BASELINE configs[4], no reference counterpart): as bf16, except that both operands of the four
         per-block linears (to_q/k/v, to_out, ff.0, ff.2) are MX-fp8 (oracle/mx_oracle.py), weights from their bf16 copies."""
-        # ln_fold (numerics STUDY of a fusion the engine does not ship, DESIGN.md section 12): the two LayerNorm-modulate steps of a
-        # block are folded algebraically into the GEMM that consumes them -- the GEMM's A operand is the residual stream x itself
-        # rounded to 16 bits, its weight is W (1 + scale) rounded to 16 bits, and the normalisation arrives in the epilogue:
-        #   LN(x) (1 + s) + b) W^T  =  rstd (x W'^T) - rstd mu c1 + c2,   W' = W (1 + s),  c1 = W' 1,  c2 = W b + bias
-        # (mean / rstd from the fp32 x).  Only meaningful together with an emulate_* operand rounding.
+        # ln_fold: restates the engine option of the same name (csrc/gemm.hpp fold_*, DESIGN.md): the LayerNorm-modulate steps of a block
+        # are folded algebraically into the GEMM that consumes them -- the GEMM's A operand is the residual stream times (1 + scale)
+        # rounded to 16 bits, the weight is the ordinary 16-bit W, and the normalisation arrives in the epilogue:
+        #   (LN(x) (1 + s) + b) W^T + bias  =  rstd ((x (1 + s)) W^T) - rstd mu c1 + c2,   c1 = W (1 + s),  c2 = W b + bias
+        # (mean / rstd from the fp32 x; c1 / c2 fp32 sums over the rounded W).  Only meaningful together with an emulate_* rounding.
+        # (the engine keeps the LN kernel for block 0's first LN and for the final one; here every block LN is folded: an upper bound)
         self.ln_fold = ln_fold
         self.cfg = cfg
         self.dtype = dtype
@@ -346,15 +347,15 @@ class DiTOracle:
         return self.conv_pos_embed(x) + x
 
     def folded_linear(self, x: Tensor, scale: Tensor, shift: Tensor, name: str, eps: float = 1e-6) -> Tensor:
-        """(LN(x) (1 + scale) + shift) W^T + bias with the modulation folded into the weight (ln_fold, see __init__): x (b, n, d) fp32
+        """(LN(x) (1 + scale) + shift) W^T + bias with the normalisation folded behind the GEMM (ln_fold, see __init__): x (b, n, d) fp32
         residual stream, scale / shift (b, d)."""
         w, bias = self.w[name + ".weight"], self.w[name + ".bias"]
         mu = x.mean(dim=-1, keepdim=True)
         rstd = torch.rsqrt(((x - mu) ** 2).mean(dim=-1, keepdim=True) + eps)
-        wp = self._r(w[None] * (1 + scale)[:, None, :])                        # (b, out, in), rounded like a weight operand
-        acc = torch.einsum("bnk,bok->bno", self._r(x), wp)                     # A operand = the rounded residual stream
-        c1 = wp.sum(dim=-1)                                                    # (b, out)
-        c2 = shift @ w.T + bias                                                # (b, out), fp32
+        wr = self._r(w)                                                        # the ordinary weight operand
+        acc = self._r(x * (1 + scale)[:, None, :]) @ wr.T                      # A operand = x (1 + scale), rounded
+        c1 = (1 + scale) @ wr.T                                                # (b, out), fp32
+        c2 = shift @ wr.T + bias                                               # (b, out), fp32
         return rstd * acc - (rstd * mu) * c1[:, None, :] + c2[:, None, :]
 
     def attention(self, x: Tensor, i: int, mask: Optional[Tensor], rope: Tensor, fold=None) -> Tensor:

@@ -793,14 +793,19 @@ def test_fullsize_ln_fold_every_utterance_vs_oracle(full_f16, B):
     g = np.load(os.path.join(ROOT, "tests", "golden", "full_b16_euler5.npz"))
     cond, text, y0, _ = bench.synth_batch(B, 0, DEV)
     f5 = F5TTS(transformer=full_f16)
-    base, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=False, **mg.KW)
-    full_f16.engine.set_option("ln_fold", 1)
     try:
+        full_f16.engine.set_option("ln_fold", 0)
+        base, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=False, **mg.KW)
+        full_f16.engine.set_option("ln_fold", 1)
         out, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=False, **mg.KW)
         out2, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=True, **mg.KW)
+        full_f16.engine.set_option("ln_fold", -1)
+        auto, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=False, **mg.KW)
         torch.cuda.synchronize()
     finally:
-        full_f16.engine.set_option("ln_fold", 0)
+        full_f16.engine.set_option("ln_fold", -1)
+    # the default (-1) folds from 22 000 rows on (2 branches x B x 937 frames: batch >= 12)
+    assert torch.equal(auto.cpu(), (out if 2 * B * mg.N_FRAMES >= 22000 else base).cpu())
     out, base = out.cpu(), base.cpu()
     assert torch.isfinite(out).all() and torch.equal(out2.cpu(), out)
     l1 = [float((out[i] - torch.from_numpy(g["out"][i])).abs().mean()) for i in range(B)]
@@ -813,7 +818,7 @@ def test_fullsize_ln_fold_every_utterance_vs_oracle(full_f16, B):
 
 def test_ln_fold_ragged_batch_and_where_it_cannot_run(full_f16):
     """ln_fold on the RAGGED full-size batch (masked residual rows keep x: their x16 / row sums must still be written), and the option's
-    three values: 1 fails loudly at batch 1 (small-tile GEMMs), -1 silently keeps the LN kernels there, 0 is the default."""
+    three values: 1 fails loudly at batch 1 (small-tile GEMMs), -1 (the default) keeps the LN kernels there, 0 = never."""
     import os
     from f5test import ROOT
     import bench
@@ -824,7 +829,7 @@ def test_ln_fold_ragged_batch_and_where_it_cannot_run(full_f16):
     cond = log_mel_spectrogram(torch.from_numpy(waves).to(DEV))
     f5 = F5TTS(transformer=full_f16)
     eng = full_f16.engine
-    assert eng.get_option("ln_fold") == 0
+    assert eng.get_option("ln_fold") == -1
     eng.set_option("ln_fold", 1)
     try:
         out, _ = f5.sample(cond, torch.from_numpy(text), duration=torch.from_numpy(dur), y0=torch.from_numpy(y0), use_graph=False, **mg.KW)
@@ -844,7 +849,7 @@ def test_ln_fold_ragged_batch_and_where_it_cannot_run(full_f16):
         torch.cuda.synchronize()
         assert torch.equal(a, b)
     finally:
-        eng.set_option("ln_fold", 0)
+        eng.set_option("ln_fold", -1)
 
 
 def test_fullsize_ragged_batch_vs_oracle(full_f16):

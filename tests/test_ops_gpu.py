@@ -870,7 +870,7 @@ def test_gemm_rs128_several_rounds_all_epilogues(lib, tile):
 @pytest.mark.parametrize("tile", [4, 14])
 def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
     """LN fold (csrc/gemm.hpp fold_*; dit.py:319-321 and :323 -> :270 -> :136): the residual GEMM leaves x (1 + s) as 16-bit operands
-    plus per-row partial sums, the QKV / FF1 GEMM finishes the LN in its epilogue:
+    plus per-row partial sums (a tiny kernel turns them into rstd and rstd * mean), the QKV / FF1 GEMM finishes the LN in its epilogue:
         (LN(x)(1 + s) + b) W^T + bias = rstd ((x (1 + s)) W^T) - rstd mean c1 + c2,   c1 = W (1 + s),  c2 = W b + bias.
     Both staged kernels (tile 4 = 256x256, 14 = role-split 128x256), ragged last row tile, masked rows.  Checked piece by piece:
     x bit-identical to the plain launch, x16 the exact rounding of x (1 + s), the row sums and the constants against fp64, and the
@@ -891,7 +891,7 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
     bo_d, gate_d, keep_d, sv_d, bv_d = bo.to(DEV), gate.to(DEV), keep.to(DEV), sv.to(DEV), bv.to(DEV)
     x_plain, x = x0.to(DEV).clone(), x0.to(DEV).clone()
     x16 = torch.zeros((M, D), dtype=op_dtype(), device=DEV)
-    stats = torch.full((M, D // 64, 2), float("nan"), device=DEV)
+    stats = torch.full((D // 64, M, 2), float("nan"), device=DEV)             # slice-major
     s1, b1 = sv[1], bv[1]
     E.check(lib.f5_debug_set_gemm_tile(tile))
     try:
@@ -909,9 +909,19 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
         want16 = (xc * (1.0 + s1)).to(op_dtype())
         assert torch.equal(x16.cpu(), want16), "x16 is not the rounding of x (1 + s)"
         xs = xc.double().reshape(M, D // 64, 64)
-        st = stats.cpu().double()
+        st = stats.cpu().double().permute(1, 0, 2)
         assert float((st[..., 0] - xs.sum(-1)).abs().max()) <= 1e-5 * float(xs.abs().sum(-1).max())
         assert float((st[..., 1] - (xs * xs).sum(-1)).abs().max()) <= 1e-5 * float((xs * xs).sum(-1).max())
+        rowf = torch.full((M + 8, 2), float("nan"), device=DEV)
+        E.check(lib.f5_op_fold_rows(P(stats), D // 64, M, P(rowf), stream()), "fold_rows")
+        sync()
+        x64 = xc.double()
+        mean, var = x64.mean(-1, keepdim=True), x64.var(-1, unbiased=False, keepdim=True)
+        rstd = (var + 1e-6).rsqrt()
+        rf = rowf.cpu().double()
+        assert bool(torch.isnan(rf[M:]).all())
+        assert float((rf[:M, 0:1] - rstd).abs().max()) <= 1e-5 * float(rstd.max())
+        assert float((rf[:M, 1:2] - rstd * mean).abs().max()) <= 1e-5 * float((rstd * mean).abs().max() + 1.0)
         # --- constants, for both consumers
         w1, bias1 = randn(r, FF, D, scale=D ** -0.5), randn(r, FF, scale=0.1)
         wq, biasq = randn(r, 3 * D, D, scale=D ** -0.5), randn(r, 3 * D, scale=0.1)
@@ -933,9 +943,6 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
             assert bool(torch.isnan(c1[:, Nn:]).all()) and bool(torch.isnan(c2[:, Nn:]).all())
             consts[nm] = (c1, c2, w64)
         # --- the folded formula in fp64 on the operands the consumers see, and the exact LN-modulate + projection
-        x64 = xc.double()
-        mean, var = x64.mean(-1, keepdim=True), x64.var(-1, unbiased=False, keepdim=True)
-        rstd = (var + 1e-6).rsqrt()
         h_exact = (x64 - mean) * rstd * (1.0 + s1.double()) + b1.double()
 
         def folded(nm, bias):
@@ -945,7 +952,7 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
         # FF1 + GELU-tanh
         out16 = torch.zeros((M, FF), dtype=op_dtype(), device=DEV)
         c1, c2, w64 = consts["ff1"]
-        E.check(lib.f5_debug_set_op_fold_consumer(P(stats), D // 64, P(c1[1]), P(c2[1])))
+        E.check(lib.f5_debug_set_op_fold_consumer(P(rowf), P(c1[1]), P(c2[1])))
         try:
             E.check(lib.f5_op_gemm(P(x16), P(None), P(w1_hi), P(None), P(None), P(None), P(out16), P(None), M, FF, D, D, D, FF, 1, 2, stream()),
                     "gemm gelu folded")
@@ -965,7 +972,7 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
             qk = torch.zeros((M, 2 * D), dtype=op_dtype(), device=DEV)
             vt = torch.zeros((Bq * H, 64, npad), dtype=op_dtype(), device=DEV)
             c1, c2, w64 = consts["qkv"]
-            E.check(lib.f5_debug_set_op_fold_consumer(P(stats), D // 64, P(c1[1]), P(c2[1])))
+            E.check(lib.f5_debug_set_op_fold_consumer(P(rowf), P(c1[1]), P(c2[1])))
             E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
             E.check(lib.f5_debug_set_op_q_premul(C.c_float(QPRE)))
             try:
@@ -976,7 +983,7 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
                 E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
                 E.check(lib.f5_debug_set_op_q_premul(C.c_float(0.0)))
         finally:
-            E.check(lib.f5_debug_set_op_fold_consumer(P(None), 0, P(None), P(None)))
+            E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(None), P(None)))
         freqs = O.rotary_freqs(64, Nq).double()
         got_q = qk.float().cpu()[:, :D].reshape(Bq, Nq, H, 64).transpose(1, 2) / QPRE
         got_k = qk.float().cpu()[:, D:].reshape(Bq, Nq, H, 64).transpose(1, 2)
@@ -1003,7 +1010,7 @@ def test_ln_fold_fields_fail_loudly_on_small_tile_launches(lib):
     gate, sc = randn(r, D).to(DEV), randn(r, D).to(DEV)
     x = randn(r, M, D).to(DEV)
     x16 = torch.zeros((M, D), dtype=op_dtype(), device=DEV)
-    stats = torch.zeros((M, D // 64, 2), device=DEV)
+    stats = torch.zeros((D // 64, M, 2), device=DEV)
     E.check(lib.f5_debug_set_op_fold_producer(P(sc), P(x16), P(stats)))
     try:
         rc = lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(w_hi), P(None), P(None), P(gate), P(None), P(x), M, D, D, D, D, D, 1, stream())
