@@ -181,8 +181,49 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20, peak_meas: di
     ao = [torch.empty(M, D, dtype=opd, device=dev) for _ in range(2)]
     ffh = [torch.empty(M, FF, dtype=opd, device=dev) for _ in range(2)]
     xres = torch.zeros(M, D, device=dev)
+    # LN fold (engine option "ln_fold", default -1 = on from 22 000 rows in the one-pass modes): sample() then runs the residual GEMMs with
+    # the x (1 + s) operand / row-sum outputs and QKV / FF1 with the folded epilogue -- time (and count the bytes of) those launches
+    folded = nseg == 1 and M >= 22000
+    if folded:
+        fscale = torch.zeros(D, device=dev)
+        fstats = torch.zeros(D // 64, M, 2, device=dev)
+        frowf = torch.ones(M, 2, device=dev)
+        fh16 = torch.zeros(M, D, dtype=opd, device=dev)
+        fc = {n: (torch.zeros(n, device=dev), torch.zeros(n, device=dev)) for n in (3 * D, FF)}
+
+    class _fold:                                      # the op-level hooks are process-wide switches: set around ONE launch
+        def __init__(self, kind, n=0):
+            self.kind, self.n = kind, n
+
+        def __enter__(self):
+            if folded and self.kind == "producer":
+                E.check(lib.f5_debug_set_op_fold_producer(P(fscale), P(fh16), P(fstats)))
+            elif folded:
+                E.check(lib.f5_debug_set_op_fold_consumer(P(frowf), P(fc[self.n][0]), P(fc[self.n][1])))
+
+        def __exit__(self, *a):
+            if folded and self.kind == "producer":
+                E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None)))
+            elif folded:
+                E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(None), P(None)))
 
     def k_qkv():
+        with _fold("consumer", 3 * D):
+            _k_qkv()
+
+    def k_out():
+        with _fold("producer"):
+            _k_out()
+
+    def k_ff1():
+        with _fold("consumer", FF):
+            _k_ff1()
+
+    def k_ff2():
+        with _fold("producer"):
+            _k_ff2()
+
+    def _k_qkv():
         E.check(lib.f5_op_qkv_rope(P(x1), P(lo(x1l)), P(wq), P(lo(wql)), P(bq), P(cos_t), P(sin_t), P(qk[0]), P(lo(qk[1])), P(vt[0]),
                                    P(lo(vt[1])), 2 * B, N_FRAMES, npad, H, D, nseg, st()))
 
@@ -191,26 +232,27 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20, peak_meas: di
         E.check(lib.f5_op_attention(P(qk[0]), P(lo(qk[1])), P(vt[0]), P(lo(vt[1])), P(ao[0]), P(lo(ao[1])), P(None), 2 * B, H, N_FRAMES,
                                     npad, D, C.c_float(0.125), int(nseg == 3), st()))
 
-    def k_out():
+    def _k_out():
         E.check(lib.f5_op_gemm_resid_gate(P(x1), P(lo(x1l)), P(wo), P(lo(wol)), P(bd), P(gate), P(None), P(xres), M, D, D, D, D, D, nseg, st()))
 
-    def k_ff1():
+    def _k_ff1():
         E.check(lib.f5_op_gemm(P(x1), P(lo(x1l)), P(w1), P(lo(w1l)), P(b1), P(None), P(ffh[0]), P(lo(ffh[1])), M, FF, D, D, D, FF, nseg, 2, st()))
 
-    def k_ff2():
+    def _k_ff2():
         E.check(lib.f5_op_gemm_resid_gate(P(x2), P(lo(x2l)), P(w2), P(lo(w2l)), P(bd), P(gate), P(None), P(xres), M, D, FF, FF, FF, D, nseg, st()))
 
+    fold_bytes = (2 * M * D + 8 * M * (D // 64)) if folded else 0      # producer: + the 16-bit x (1 + s) operand and the partial row sums
     specs = [
         ("qkv_gemm", "QKV projection GEMM + bias + RoPE + head split (f5_gemm*_kernel<EPI_QKV_ROPE>)", k_qkv, 2.0 * M * D * 3 * D,
          f"M={M} N={3 * D} K={D}", 2 * M * D + 2 * 3 * D * D + 2 * M * 3 * D),
         ("attention", "flash attention, 16 heads x 64 (f5_attn*_kernel)", k_attn, 4.0 * 2 * B * H * N_FRAMES * N_FRAMES * 64,
          f"B={2 * B} H={H} N={N_FRAMES} d=64", 2 * 3 * M * D + 2 * M * D),
         ("out_proj_gemm", "attention out-projection GEMM + gated fp32 residual update (f5_gemm*_kernel<EPI_RESID_GATE>, K=1024)", k_out,
-         2.0 * M * D * D, f"M={M} N={D} K={D}", 2 * M * D + 2 * D * D + 8 * M * D),
+         2.0 * M * D * D, f"M={M} N={D} K={D}", 2 * M * D + 2 * D * D + 8 * M * D + fold_bytes),
         ("ff1_gemm", "FF1 GEMM + bias + GELU-tanh (f5_gemm*_kernel<EPI_GELU_TANH>)", k_ff1, 2.0 * M * D * FF, f"M={M} N={FF} K={D}",
          2 * M * D + 2 * D * FF + 2 * M * FF),
         ("ff2_gemm", "FF2 GEMM + gated fp32 residual update (f5_gemm*_kernel<EPI_RESID_GATE>, K=2048)", k_ff2, 2.0 * M * FF * D,
-         f"M={M} N={D} K={FF}", 2 * M * FF + 2 * D * FF + 8 * M * D),
+         f"M={M} N={D} K={FF}", 2 * M * FF + 2 * D * FF + 8 * M * D + fold_bytes),
     ]
     out = []
     import ctypes as C
@@ -231,7 +273,7 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20, peak_meas: di
                             peak_measured_constant_operands_tflops=peak_meas["constant_operands"],
                             frac_of_measured=ach / peak_meas["workload_like_operands"], traffic=_pmc_traffic(key, shape, precision),
                             traffic_unit="bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", algorithmic_bytes=alg_bytes,
-                            algorithmic_flops=flops))
+                            algorithmic_flops=flops, ln_fold=bool(folded)))
     lib.f5_debug_set_op_q_premul(C.c_float(0.0))
     E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
     total = sum(k["avg_launch_ms"] for k in out)

@@ -642,14 +642,29 @@ static int run_prep(const Ctx& c, int nfe) {
         // (scale_mlp, shift_mlp); mod rows are [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] (dit.py:53-58)
         const int FF = cf.ff_dim;
         const size_t vstride = (size_t)(6 * L + 2) * D, ostride = (size_t)L * (3 * D + FF);
-        for (int i = 0; i < L; ++i) {
+        // the 22 blocks of a projection in ONE launch when their weights sit at a uniform stride in the arena (they do: every block
+        // allocates the same tensors in the same order), else block by block
+        const BlockW& b0 = e->blocks[0];
+        bool uniform = L >= 2;
+        const long sq = L >= 2 ? (long)e->blocks[1].qkv.hi - (long)b0.qkv.hi : 0, sf = L >= 2 ? (long)e->blocks[1].ff1.hi - (long)b0.ff1.hi : 0;
+        const long sbq = L >= 2 ? (long)e->blocks[1].bqkv - (long)b0.bqkv : 0, sbf = L >= 2 ? (long)e->blocks[1].bff1 - (long)b0.bff1 : 0;
+        for (int i = 1; i < L && uniform; ++i) {
+            const BlockW& bw = e->blocks[i];
+            uniform = (long)bw.qkv.hi - (long)b0.qkv.hi == i * sq && (long)bw.ff1.hi - (long)b0.ff1.hi == i * sf &&
+                      (long)bw.bqkv - (long)b0.bqkv == i * sbq && (long)bw.bff1 - (long)b0.bff1 == i * sbf && bw.qkv.ld == b0.qkv.ld &&
+                      bw.ff1.ld == b0.ff1.ld;
+        }
+        uniform = uniform && sq > 0 && sf > 0 && sbq > 0 && sbf > 0 && sq % 8 == 0 && sf % 8 == 0 && sbq % 4 == 0 && sbf % 4 == 0;
+        const int nlaunch = uniform ? 1 : L, count = uniform ? L : 1;
+        for (int i = 0; i < nlaunch; ++i) {
             const BlockW& bw = e->blocks[i];
             const float* m6 = c.p<float>(w.mod) + (size_t)i * 6 * D;
             float* c1 = c.p<float>(w.foldc[0]) + (size_t)i * (3 * D + FF);
             float* c2 = c.p<float>(w.foldc[1]) + (size_t)i * (3 * D + FF);
-            RC(K.fold_consts(c.wm(bw.qkv, 0), bw.qkv.ld, c.a<float>(bw.bqkv), m6 + D, m6, vstride, nfe, c1, c2, ostride, 3 * D, D, s));
+            RC(K.fold_consts(c.wm(bw.qkv, 0), bw.qkv.ld, c.a<float>(bw.bqkv), m6 + D, m6, vstride, nfe, c1, c2, ostride, 3 * D, D, s, count,
+                             (size_t)sq / 2, (size_t)sbq / 4, (size_t)6 * D, (size_t)(3 * D + FF)));
             RC(K.fold_consts(c.wm(bw.ff1, 0), bw.ff1.ld, c.a<float>(bw.bff1), m6 + 4 * D, m6 + 3 * D, vstride, nfe, c1 + 3 * D, c2 + 3 * D,
-                             ostride, FF, D, s));
+                             ostride, FF, D, s, count, (size_t)sf / 2, (size_t)sbf / 4, (size_t)6 * D, (size_t)(3 * D + FF)));
         }
     }
     RC(f5_launch_rope_table(c.p<float>(w.rope_cos), c.p<float>(w.rope_sin), c.N, cf.dim_head, s));
@@ -1321,7 +1336,7 @@ extern "C" int f5_debug_set_gemm_ring(int v) {
     return 0;
 }
 extern "C" int f5_debug_set_gemm_order(int v) {
-    F5_REQUIRE(v >= 0 && v <= 2, "gemm order must be 0 (auto), 1 (n fastest) or 2 (m fastest)");
+    F5_REQUIRE(v >= 0 && v <= 3, "gemm order must be 0 (auto), 1 (n fastest), 2 (m fastest) or 3 (band-major where it applies)");
     F5_SET_BOTH(f5_gemm_order, v);
     return 0;
 }

@@ -317,12 +317,21 @@ __global__ __launch_bounds__(256) void f5_gemm_kernel(F5GemmArgs p, int tiles_n,
 // counted vmcnt, one barrier per K tile).  Used for small-batch shapes (M ~ 2 * 937 rows) where the chip is only
 // filled by 64x64 / 64x128 tiles and the old one-tile-deep register prefetch left every iteration latency bound.
 // =================================================================================================
-int f5_gemm_order = 0;   // 0 auto, 1 force n-fastest, 2 force m-fastest (ring kernel tile numbering)
+int f5_gemm_order = 0;   // 0 auto, 1 force n-fastest, 2 force m-fastest, 3 force band-major where it applies (ring kernel tile numbering)
 static bool gemm_mfast(const F5GemmArgs& a) {
     if (f5_gemm_order == 1) return false;
     if (f5_gemm_order == 2) return true;
     const size_t a_bytes = (size_t)(a.a_row_mod > 0 ? a.a_row_mod : a.M) * a.K * 2 * (a.nseg == 3 ? 2 : 1);
     return a_bytes <= (size_t)4 << 20;     // whole A operand fits in one XCD's 4 MB L2
+}
+// the ring kernels' tile-order argument: tiles_n (n fastest), -tiles_m (m fastest) or tiles_n | band << 20 (band-major, see the kernel).
+// Band-major replaces m-fastest for one-round launches whose column tiles split into bands of 4: every L2 then fetches a compact block
+// (fabric bytes per launch at batch 1, PMC: profiles/pmc_traffic.json).
+static int ring_order(const F5GemmArgs& a, int tiles_m, int tiles_n) {
+    const bool band_ok = tiles_n % 4 == 0 && tiles_n >= 8 && (long)tiles_m * tiles_n <= 512 && tiles_m >= 8;
+    if (f5_gemm_order == 3) return band_ok ? (tiles_n | (4 << 20)) : tiles_n;
+    if (!gemm_mfast(a)) return tiles_n;
+    return (f5_gemm_order == 0 && band_ok) ? (tiles_n | (4 << 20)) : -tiles_m;
 }
 
 // ABL (timing experiments only, results are garbage; tools/ring_ablate.py): 1 = no operand loads after the prologue, 2 = no MFMAs,
@@ -352,10 +361,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    // tile numbering: n fastest (neighbouring tiles share the A panel) or, when tiles_n < 0, m fastest with
-    // tiles_m = -tiles_n (neighbouring tiles share the W panel: better when the whole A operand fits in an XCD's L2)
+    // tile numbering: n fastest (neighbouring tiles share the A panel); when tiles_n < 0, m fastest with tiles_m = -tiles_n
+    // (neighbouring tiles share the W panel: better when the whole A operand fits in an XCD's L2); with a band width in bits 20+
+    // (ring_order), BAND-major: bands of `band` column tiles, n fastest inside a band -- an XCD's contiguous chunk of the list is then a
+    // compact block of tiles (batch-1 out-projection, 30 x 8 tiles: 7.5 rows x 4 columns per XCD = a quarter of A and half of W per L2
+    // instead of all of A and an eighth of W)
     int tm, tn;
-    if (tiles_n > 0) {
+    if (tiles_n >= (1 << 20)) {
+        const int band = tiles_n >> 20, tnn = tiles_n & ((1 << 20) - 1);
+        const int per_band = band * (ntiles / tnn);
+        const int b = tile / per_band, rem = tile - b * per_band;
+        tm = rem / band;
+        tn = b * band + (rem - tm * band);
+    } else if (tiles_n > 0) {
         tm = tile / tiles_n;
         tn = tile - tm * tiles_n;
     } else {
@@ -576,7 +594,7 @@ template <int EPI, int MB, int NB>
 static int launch_ring(const F5GemmArgs& a, hipStream_t stream) {
     const int tiles_m = f5_cdiv(a.M, 64 * MB), tiles_n = f5_cdiv(a.N, 64 * NB);
     const int ntiles = tiles_m * tiles_n;
-    const int order = gemm_mfast(a) ? -tiles_m : tiles_n;
+    const int order = ring_order(a, tiles_m, tiles_n);
     // ring depth: keep TWO workgroups per CU (<= 80 KB of LDS each): 64x64 tiles take 4 stages (64 KB), 64x128 take 3 (72 KB)
     constexpr int NST = (MB + NB) * 8 * 4 <= 80 ? 4 : 3;
     hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, NB, NST>), dim3(ntiles), dim3(256), 0, stream, a, order, ntiles);
@@ -595,7 +613,7 @@ static int launch_ring_ks2(const F5GemmArgs& a, hipStream_t stream) {
     constexpr int BMt = 64 * MB, BNt = 128;
     const int tiles_m = f5_cdiv(a.M, BMt), tiles_n = f5_cdiv(a.N, BNt);
     const int ntiles = tiles_m * tiles_n;
-    const int order = gemm_mfast(a) ? -tiles_m : tiles_n;
+    const int order = ring_order(a, tiles_m, tiles_n);
     constexpr int NST = MB == 1 ? 3 : 2;
     hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, 2, NST, 2, 2, 2>), dim3(ntiles), dim3(512), 0, stream, a, order, ntiles);
     F5_LAUNCH_CHECK();
@@ -607,7 +625,7 @@ static int launch_ring8(const F5GemmArgs& a, hipStream_t stream) {
     constexpr int BMt = 128, BNt = 64 * NB;
     const int tiles_m = f5_cdiv(a.M, BMt), tiles_n = a.N / BNt;
     const int ntiles = tiles_m * tiles_n;
-    const int order = gemm_mfast(a) ? -tiles_m : tiles_n;
+    const int order = ring_order(a, tiles_m, tiles_n);
     constexpr int NST = (BMt + BNt) * 64 * 2 * 4 <= 128 * 1024 ? 4 : 3;
     hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, 1, NB, NST, 4, 2>), dim3(ntiles), dim3(512), 0, stream, a, order, ntiles);
     F5_LAUNCH_CHECK();
@@ -626,7 +644,7 @@ static int launch_ring_wide(const F5GemmArgs& a, hipStream_t stream) {
     F5_REQUIRE(a.N % BNt == 0, "gemm: this tile needs N %% %d == 0", BNt);
     const int tiles_m = f5_cdiv(a.M, BMt), tiles_n = a.N / BNt;
     const int ntiles = tiles_m * tiles_n;
-    const int order = gemm_mfast(a) ? -tiles_m : tiles_n;
+    const int order = ring_order(a, tiles_m, tiles_n);
     hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, NB, 3, WM, WN, KS, ABL>), dim3(ntiles), dim3(64 * WM * WN * KS), 0, stream, a, order,
                        ntiles);
     F5_LAUNCH_CHECK();
@@ -708,7 +726,14 @@ constexpr int FC_ROWS = 4, FC_MAXC = 8;
 __global__ __launch_bounds__(256) void f5_fold_consts_kernel(const op16_t* __restrict__ w, int ldw, const float* __restrict__ bias,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, size_t vec_stride,
                                                              int nvec, float* __restrict__ c1, float* __restrict__ c2, size_t out_stride, int N,
-                                                             int K) {
+                                                             int K, F5FoldBatch bt) {
+    // blockIdx.y = one of bt.count equally shaped problems (the same projection of every DiT block) at uniform strides
+    w += (size_t)blockIdx.y * bt.w_stride;
+    if (bias) bias += (size_t)blockIdx.y * bt.bias_stride;
+    scale += (size_t)blockIdx.y * bt.mod_stride;
+    shift += (size_t)blockIdx.y * bt.mod_stride;
+    c1 += (size_t)blockIdx.y * bt.out_blk_stride;
+    c2 += (size_t)blockIdx.y * bt.out_blk_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = (blockIdx.x * 4 + wave) * FC_ROWS;
     if (n0 >= N) return;
@@ -791,14 +816,17 @@ int f5_launch_fold_rows(const float* stats, int ld, int nslice, int M, float eps
 }
 
 int f5_launch_fold_consts(const op16_t* w, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,
-                          float* c1, float* c2, size_t out_stride, int N, int K, hipStream_t stream) {
+                          float* c1, float* c2, size_t out_stride, int N, int K, hipStream_t stream, const F5FoldBatch* batch) {
+    F5FoldBatch bt = {1, 0, 0, 0, 0};
+    if (batch) bt = *batch;
+    F5_REQUIRE(bt.count >= 1 && bt.count <= 65535 && bt.mod_stride % 4 == 0 && bt.w_stride % 4 == 0, "fold_consts: bad batch");
     F5_REQUIRE(w && scale && shift && c1 && c2 && N > 0 && nvec > 0, "fold_consts: null argument");
     F5_REQUIRE(K % 256 == 0 && K <= 256 * FC_MAXC && ldw % 4 == 0 && vec_stride % 4 == 0, "fold_consts: K must be a multiple of 256, <= %d",
                256 * FC_MAXC);
     F5_REQUIRE(((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0,
                "fold_consts: unaligned operand");
-    hipLaunchKernelGGL(f5_fold_consts_kernel, dim3(f5_cdiv(N, 4 * FC_ROWS)), dim3(256), 0, stream, w, ldw, bias, scale, shift, vec_stride, nvec,
-                       c1, c2, out_stride, N, K);
+    hipLaunchKernelGGL(f5_fold_consts_kernel, dim3(f5_cdiv(N, 4 * FC_ROWS), bt.count), dim3(256), 0, stream, w, ldw, bias, scale, shift,
+                       vec_stride, nvec, c1, c2, out_stride, N, K, bt);
     F5_LAUNCH_CHECK();
     return 0;
 }

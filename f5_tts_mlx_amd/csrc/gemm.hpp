@@ -96,8 +96,14 @@ int f5_launch_fold_rows(const float* stats, int ld, int nslice, int M, float eps
 // Constants of the fold for `nvec` modulation vectors at once: c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k]
 // shift_v[k] + bias[n], fp32 sums over the operand-typed weights the GEMM multiplies by.  scale_v = scale + v * vec_stride (floats),
 // likewise shift_v; c1 / c2 rows are out_stride floats apart.  K % 256 == 0, K <= 2048.
+// `batch` (optional): count equally shaped problems in ONE launch -- problem i reads w + i * w_stride (elements), bias + i * bias_stride,
+// scale / shift + i * mod_stride and writes c1 / c2 + i * out_blk_stride (floats): the same projection of every DiT block.
+struct F5FoldBatch {
+    int count;
+    size_t w_stride, bias_stride, mod_stride, out_blk_stride;
+};
 int f5_launch_fold_consts(const op16_t* w, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,
-                          float* c1, float* c2, size_t out_stride, int N, int K, hipStream_t stream);
+                          float* c1, float* c2, size_t out_stride, int N, int K, hipStream_t stream, const F5FoldBatch* batch = nullptr);
 // the large-shape kernel (gemm256.hip: 256 x 256 tiles, one workgroup per CU); f5_launch_gemm routes N % 256 == 0, >= 512-tile shapes here
 int f5_launch_gemm256(const F5GemmArgs& a, int epi, hipStream_t stream);
 // batch-1-sized shapes: role-split 128 x 256 tiles, one round of 8-wave workgroups (gemm_rs128.hip)

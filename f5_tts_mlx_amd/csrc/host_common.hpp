@@ -60,11 +60,17 @@ struct Ops {
     int fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, hipStream_t s) const {
         return h ? f5hf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, s) : f5bf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, s);
     }
+    // batch: {count, w_stride, bias_stride, mod_stride, out_blk_stride} (gemm.hpp F5FoldBatch), count == 1 = a single problem
     int fold_consts(const op16_t* w, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec, float* c1,
-                    float* c2, size_t out_stride, int N, int K, hipStream_t s) const {
-        return h ? f5hf::f5_launch_fold_consts(reinterpret_cast<const f5hf::op16_t*>(w), ldw, bias, scale, shift, vec_stride, nvec, c1, c2,
-                                               out_stride, N, K, s)
-                 : f5bf::f5_launch_fold_consts(w, ldw, bias, scale, shift, vec_stride, nvec, c1, c2, out_stride, N, K, s);
+                    float* c2, size_t out_stride, int N, int K, hipStream_t s, int count = 1, size_t w_stride = 0, size_t bias_stride = 0,
+                    size_t mod_stride = 0, size_t out_blk_stride = 0) const {
+        if (h) {
+            const f5hf::F5FoldBatch bt = {count, w_stride, bias_stride, mod_stride, out_blk_stride};
+            return f5hf::f5_launch_fold_consts(reinterpret_cast<const f5hf::op16_t*>(w), ldw, bias, scale, shift, vec_stride, nvec, c1, c2,
+                                               out_stride, N, K, s, &bt);
+        }
+        const f5bf::F5FoldBatch bt = {count, w_stride, bias_stride, mod_stride, out_blk_stride};
+        return f5bf::f5_launch_fold_consts(w, ldw, bias, scale, shift, vec_stride, nvec, c1, c2, out_stride, N, K, s, &bt);
     }
     int attention(const F5AttnArgs& a, hipStream_t s) const {
         return h ? f5hf::f5_launch_attention(reinterpret_cast<const f5hf::F5AttnArgs&>(a), s) : f5bf::f5_launch_attention(a, s);

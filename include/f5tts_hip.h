@@ -250,7 +250,8 @@ int f5_debug_set_gemm_tile(int sel);
  *            2-byte staging writes instead of transposed with 8-byte ones (A/B; identical bits for FF1 / plain);
  * lab build only: bit 3 (8) residual update by no-return L2 atomics, bits 9-11 x-tile prefetch, bits 4-7 ring-loop ablations */
 int f5_debug_set_gemm_flags(int v);
-/* small-tile GEMM tile numbering: 0 auto, 1 n fastest, 2 m fastest */
+/* ring GEMM tile numbering: 0 auto (band-major one-round launches whose A fits an L2, else m / n fastest), 1 n fastest, 2 m fastest,
+ * 3 band-major (bands of 4 column tiles) wherever the tile grid allows */
 int f5_debug_set_gemm_order(int v);
 /* small-tile GEMM staging: 1 = global_load_lds ring (default), 0 = register-staged double buffer */
 int f5_debug_set_gemm_ring(int v);

@@ -1202,6 +1202,29 @@ def test_gemm_ring8_kernels(lib, tile):
         E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+@pytest.mark.parametrize("tile", [0, 5, 9, 10])
+def test_gemm_ring_band_major_numbering_same_bits(lib, tile):
+    """Ring kernels, tile numbering (f5_debug_set_gemm_order): band-major (3; the auto choice for one-round launches whose A operand fits
+    an L2 -- batch-1 out-projection / FF1 / FF2) only permutes which workgroup computes which tile: the results must be bit-identical to
+    m-fastest (2) and n-fastest (1), on the batch-1 shapes, a ragged one and one whose column tiles do not split into bands."""
+    E.check(lib.f5_debug_set_gemm_tile(tile))
+    try:
+        for (M, N, K) in ((1874, 1024, 1024), (1874, 2048, 1024), (1874, 1024, 2048), (999, 1536, 256), (700, 768, 128)):
+            r = rng(M + N + K)
+            a, w, bias = randn(r, M, K), randn(r, N, K, scale=K ** -0.5), randn(r, N, scale=0.1)
+            outs = {}
+            for order in (1, 2, 3, 0):
+                E.check(lib.f5_debug_set_gemm_order(order))
+                outs[order] = _gemm(lib, a, w, bias, 0, 1)[0].clone()
+            ref = (bf16r(a).double() @ bf16r(w).double().T) + bias.double()
+            assert float((outs[3].double() - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+            for order in (1, 2, 0):
+                assert torch.equal(outs[order], outs[3]), (tile, M, N, K, order)
+    finally:
+        E.check(lib.f5_debug_set_gemm_order(0))
+        E.check(lib.f5_debug_set_gemm_tile(0))
+
+
 @pytest.mark.parametrize("tile", [12, 13])
 def test_gemm_wide_ring_kernels(lib, tile):
     """128x256 ring tiles (8 waves of 64x64, 8 waves of 32x128): plain, bf16x3, GELU epilogue and the
