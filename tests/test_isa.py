@@ -38,6 +38,19 @@ def test_attention_loops_have_no_compiler_vmcnt_wait(f16):
     assert len(mf) > 100 and all(lines[i - 1].startswith("s_nop 1") for i in mf), "an asm MFMA of f5_attn2p_kernel lost its hazard guard"
 
 
+@pytest.mark.parametrize("name", ["gemm256", "gemm_rs128", "gemm_f8"])
+def test_large_gemm_k_loops_have_no_compiler_vmcnt_wait(name):
+    """the same scan over the large-shape GEMM kernels, every instantiation -- the bf16x3 passes are the same instantiation
+    (nseg is a run-time loop bound), the MX-fp8 kernel (gemm_f8.hip) its own: the K loops count their outstanding loads by hand, a wait
+    the compiler adds inside one of them drains the operand prefetch every step."""
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    for f16 in (0, 1):
+        asm = compile_to_asm(os.path.join(ROOT, "f5_tts_mlx_amd", "csrc", name + ".hip"), [f"-DF5_F16={f16}", "-fno-slp-vectorize"])
+        found = {k: v for k, v in scan(asm).items() if "gemm" in k}
+        assert "v_mfma" in asm and not found, (name, f16, found)
+
+
 def _noslp_list():
     """the files build.sh compiles with -fno-slp-vectorize, parsed from the script (single source of truth)"""
     import re
