@@ -325,13 +325,15 @@ static bool gemm_mfast(const F5GemmArgs& a) {
     return a_bytes <= (size_t)4 << 20;     // whole A operand fits in one XCD's 4 MB L2
 }
 // the ring kernels' tile-order argument: tiles_n (n fastest), -tiles_m (m fastest) or tiles_n | band << 20 (band-major, see the kernel).
-// Band-major replaces m-fastest for one-round launches whose column tiles split into bands of 4: every L2 then fetches a compact block
-// (fabric bytes per launch at batch 1, PMC: profiles/pmc_traffic.json).
+// Band-major is the automatic choice for launches of at most two rounds whose column tiles split into bands of 4: every L2 then fetches
+// a compact block (fabric bytes per launch at batch 1, PMC: profiles/pmc_traffic.json; op-level A/B of the four orders:
+// profiles/r04/ring_order_ab.json: out-proj 11.8 m-fastest / 10.7 n-fastest / 10.7-10.8 band-major us, FF1 14.7 / 14.8 / 14.4, FF2 17.5 /
+// 17.0 / 16.9).
 static int ring_order(const F5GemmArgs& a, int tiles_m, int tiles_n) {
     const bool band_ok = tiles_n % 4 == 0 && tiles_n >= 8 && (long)tiles_m * tiles_n <= 512 && tiles_m >= 8;
-    if (f5_gemm_order == 3) return band_ok ? (tiles_n | (4 << 20)) : tiles_n;
-    if (!gemm_mfast(a)) return tiles_n;
-    return (f5_gemm_order == 0 && band_ok) ? (tiles_n | (4 << 20)) : -tiles_m;
+    if ((f5_gemm_order == 3 || f5_gemm_order == 0) && band_ok) return tiles_n | (4 << 20);
+    if (f5_gemm_order == 3) return tiles_n;
+    return gemm_mfast(a) ? -tiles_m : tiles_n;
 }
 
 // ABL (timing experiments only, results are garbage; tools/ring_ablate.py): 1 = no operand loads after the prologue, 2 = no MFMAs,

@@ -44,15 +44,17 @@ def main():
                 if rep:
                     res[order].append((time.perf_counter() - t0) * 1e3)
                 outs[order] = out
-        for order in (2, 0):
+        for order in (2, 0, 3, 1, 2, 0, 3, 1):
             E.check(lib.f5_debug_set_gemm_order(order))
             ks, _ = bench.kernel_rooflines("f16", dev, 1, iters=50, peak_meas=dict(workload_like_operands=1.0, constant_operands=1.0))
-            ops[order] = {k["key"]: round(k["avg_launch_ms"] * 1e3, 2) for k in ks}
+            cur = {k["key"]: round(k["avg_launch_ms"] * 1e3, 2) for k in ks}
+            ops[order] = {k: min(v, ops[order][k]) for k, v in cur.items()} if order in ops else cur
     finally:
         E.check(lib.f5_debug_set_gemm_order(0))
     print(json.dumps(dict(B=1, precision="f16", ms_m_fastest=round(min(res[2]), 3), ms_auto_band_major=round(min(res[0]), 3),
                           all_m_fastest=[round(v, 2) for v in res[2]], all_auto=[round(v, 2) for v in res[0]],
-                          bit_identical=bool(torch.equal(outs[0], outs[2])), op_us_m_fastest=ops[2], op_us_auto=ops[0])))
+                          bit_identical=bool(torch.equal(outs[0], outs[2])), op_us_m_fastest=ops[2], op_us_auto=ops[0],
+                          op_us_band_major_forced=ops[3], op_us_n_fastest=ops[1])))
 
 
 if __name__ == "__main__":
