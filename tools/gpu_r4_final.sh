@@ -27,5 +27,8 @@ for B in 1 32; do
   python tools/pmc_mfma_summary.py $D f16 $B > $OUT/mfma_util_b${B}_f16.json 2> $OUT/mfma_util_b${B}_f16.err
   head -c 1500 $OUT/mfma_util_b${B}_f16.json; tail -2 $OUT/mfma_util_b${B}_f16.err
 done
+timeout 900 python tools/yardstick.py > $OUT/yardstick_gemm_attention_mfma.jsonl 2> $OUT/yardstick.err; tail -3 $OUT/yardstick_gemm_attention_mfma.jsonl | cut -c1-300
+timeout 600 python tools/r4_ln_fold_ab.py --batches 12,16,32 --reps 2 > $OUT/ln_fold_ab.jsonl 2> $OUT/ln_fold_ab.err; cat $OUT/ln_fold_ab.jsonl
+timeout 300 python tools/r4_ring_order_ab.py --reps 3 > $OUT/ring_order_ab.json 2> $OUT/ring_order_ab.err; cut -c1-400 $OUT/ring_order_ab.json
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.csv" -size +4M -delete
 ls $OUT
