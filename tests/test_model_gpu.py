@@ -816,6 +816,45 @@ def test_fullsize_ln_fold_every_utterance_vs_oracle(full_f16, B):
     assert not torch.equal(out, base)
 
 
+def test_ln_fold_single_forward_and_single_branch(full_f16):
+    """ln_fold through the other two entry shapes: f5_dit_forward (one evaluation, its constants computed for nfe = 1) at batch 12, where
+    the default (-1) folds, and sample() WITHOUT classifier-free guidance (one branch: 24 x 937 = 22 488 rows) -- each against the same
+    call with the fold off: close (a different rounding sequence), not identical."""
+    import bench
+    mg = _golden_module("make_batch_golden")
+    eng = full_f16.engine
+    cond, text, y0, _ = bench.synth_batch(12, 0, DEV)
+    lens = [int(cond.shape[1])] * 12
+    durs = [mg.N_FRAMES] * 12
+    condp = torch.nn.functional.pad(cond, (0, 0, 0, mg.N_FRAMES - cond.shape[1]))
+    res = {}
+    try:
+        for opt in (0, -1):
+            eng.set_option("ln_fold", opt)
+            pred, null = eng.dit_forward(y0, text, condp, lens, durs, 0.37, cfg_strength=2.0)
+            torch.cuda.synchronize()
+            res[opt] = (pred.cpu(), null.cpu())
+        for k in (0, 1):
+            a, b = res[0][k], res[-1][k]
+            rel = float((a - b).abs().mean() / a.abs().mean())
+            print(f"[ln_fold dit_forward] branch {k}: mean |d| / mean |v| = {rel:.3e}")
+            assert torch.isfinite(b).all() and rel <= 2e-3 and not torch.equal(a, b)
+        cond24, text24, y24, _ = bench.synth_batch(24, 0, DEV)
+        kw = dict(mg.KW)
+        kw["cfg_strength"] = 0.0
+        outs = {}
+        for opt in (0, -1):
+            eng.set_option("ln_fold", opt)
+            out, _ = F5TTS(transformer=full_f16).sample(cond24, text24, duration=mg.N_FRAMES, y0=y24, use_graph=False, **kw)
+            torch.cuda.synchronize()
+            outs[opt] = out.cpu()
+        d = float((outs[0] - outs[-1]).abs().mean())
+        print(f"[ln_fold no-CFG batch 24] mel L1 folded vs unfolded = {d:.3e}")
+        assert torch.isfinite(outs[-1]).all() and 0.0 < d <= MEL_L1_TOL
+    finally:
+        eng.set_option("ln_fold", -1)
+
+
 def test_ln_fold_ragged_batch_and_where_it_cannot_run(full_f16):
     """ln_fold on the RAGGED full-size batch (masked residual rows keep x: their x16 / row sums must still be written), and the option's
     three values: 1 fails loudly at batch 1 (small-tile GEMMs), -1 (the default) keeps the LN kernels there, 0 = never."""
