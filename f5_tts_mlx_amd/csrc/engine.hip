@@ -47,7 +47,8 @@ struct TextBlockW {
 
 struct Workspace {
     size_t total = 0;
-    size_t scal, scal_words;   // per-call host scalars, contiguous: [lens B | dur2 2B | tgrid nfe | dt steps | cfg 1 | lncnt] (32-bit words)
+    size_t scal, scal_words;   // per-call host scalars, contiguous: [lens B | dur2 2B | tgrid nfe | dt steps | cfg 1 | lncnt | status 1] (32-bit words)
+    size_t status;             // one word, zeroed with the scalars: bit 0 = LN-fold operand overflow (fp16), read by f5_sample_status
     size_t lncnt, lncnt_words; // row-block arrival counters of the fused LN tail (zeroed with the scalars; 0 words = no fusion)
     size_t lens, dur2, text, ids, keep, rowkeep;
     size_t tgrid, dt, cfgv, sinus, th, temb, mod;
@@ -459,7 +460,7 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
     const size_t nfe1 = (size_t)(nfe > 0 ? nfe : 1);
     // one counter per 64 rows of the residual stream; only small-M launches fuse (gemm.hpp ln_counter), large ones get none
     w.lncnt_words = (M2 + 63) / 64 <= 512 ? (M2 + 63) / 64 : 0;
-    w.scal_words = (size_t)3 * B + nfe1 + steps + 1 + w.lncnt_words;
+    w.scal_words = (size_t)3 * B + nfe1 + steps + 1 + w.lncnt_words + 1;
     w.scal = b.take(w.scal_words * 4);
     w.lens = w.scal;
     w.dur2 = w.lens + (size_t)B * 4;
@@ -467,6 +468,7 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
     w.dt = w.tgrid + nfe1 * 4;
     w.cfgv = w.dt + (size_t)steps * 4;
     w.lncnt = w.cfgv + 4;
+    w.status = w.lncnt + w.lncnt_words * 4;
     w.text = b.take((size_t)B * (nt > 0 ? nt : 1) * 4);
     w.ids = b.take(M2 * 4);
     w.keep = b.take(M2);
@@ -884,6 +886,7 @@ static int run_dit(const Ctx& c, int j) {
         g.x16_scale = next_scale;
         g.stats_out = c.p<float>(w.lnstats);
         g.stats_ld = M;
+        g.x16_overflow = c.p<int>(w.status);
     };
     auto fold_rows = [&]() { return K.fold_rows(c.p<float>(w.lnstats), M, D / 64, M, 1e-6f, c.p<float>(w.lnrowf), s); };
     bool h_folded = false;                       // `h` holds x (1 + scale) + row sums (fold) instead of the finished LN-modulate
@@ -1077,7 +1080,7 @@ static int stage_inputs(Ctx& c, const f5_sample_args* a, const float* x_override
     // host scalars -> workspace as kernel arguments (no host buffer outlives this call, no host synchronisation)
     const size_t nfe1 = tnfe.empty() ? 1 : tnfe.size();
     std::vector<uint32_t> words(w.scal_words, 0u);
-    F5_REQUIRE(w.scal_words == (size_t)3 * c.B + nfe1 + a->steps + 1 + w.lncnt_words && dts.size() <= (size_t)a->steps,
+    F5_REQUIRE(w.scal_words == (size_t)3 * c.B + nfe1 + a->steps + 1 + w.lncnt_words + 1 && dts.size() <= (size_t)a->steps,
                "internal: scalar staging layout");
     memcpy(words.data(), a->lens, (size_t)c.B * 4);
     for (int b = 0; b < c.B; ++b) words[c.B + b] = words[2 * c.B + b] = (uint32_t)a->durations[b];
@@ -1211,6 +1214,18 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     const float* ylast = c.p<float>(c.w.traj) + (size_t)(a->steps - 1) * M1 * mel;
     RC(f5_launch_splice(c.p<float>(c.w.cond), ylast, c.p<int>(c.w.lens), a->out, c.B, c.N, mel, s));
     if (a->trajectory) RC(f5_launch_copy_words(c.ws + c.w.traj, a->trajectory, (size_t)a->steps * M1 * mel, s));
+    return 0;
+}
+
+// Status word of the last f5_sample / f5_dit_forward that used this workspace with these sizes: bit 0 = a value of the folded LN
+// operand x (1 + scale) did not fit fp16 (ln_fold active, precision f16): the result is saturated there -- rerun with the engine
+// option ln_fold = 0 or in bf16.  Synchronises the stream.
+extern "C" int f5_sample_status(f5_engine* e, const f5_sample_args* a, int* flags, void* stream) {
+    F5_REQUIRE(e && a && flags && a->workspace, "null argument");
+    const Workspace w = plan_workspace(e, a->B, a->N, a->nt, a->steps, a->method);
+    F5_REQUIRE(a->workspace_bytes >= w.total, "workspace too small");
+    F5_HIP_CHECK(hipMemcpyAsync(flags, (const char*)a->workspace + w.status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    F5_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 
@@ -1421,6 +1436,11 @@ extern "C" int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_
     g_op_fold.next_scale = next_scale;
     g_op_fold.x16 = (op16_t*)x16_out;
     g_op_fold.stats_out = stats_out;
+    return 0;
+}
+static int* g_op_fold_overflow = nullptr;
+extern "C" int f5_debug_set_op_fold_overflow_flag(int* flag) {
+    g_op_fold_overflow = flag;
     return 0;
 }
 extern "C" int f5_debug_set_op_fold_consumer(const float* rowf, const float* c1, const float* c2) {
@@ -1743,6 +1763,7 @@ extern "C" int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const v
         g.x16_scale = g_op_fold.next_scale;
         g.stats_out = g_op_fold.stats_out;
         g.stats_ld = M;
+        g.x16_overflow = g_op_fold_overflow;
     }
     return g_ops.gemm(g, EPI_RESID_GATE, (hipStream_t)stream);
 }

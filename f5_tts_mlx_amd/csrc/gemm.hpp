@@ -73,6 +73,8 @@ struct F5GemmArgs {
     const float* x16_scale;   // [N]: s (the kernel adds the 1)
     float* stats_out;         // [N / 64][stats_ld][2] (sum, sum of squares), slice-major, or null; x16_out and stats_out: both or neither
     int stats_ld;             // rows per slice of stats_out (>= M)
+    int* x16_overflow;        // or null: bit 0 is set when a value of x (1 + s) does not fit the operand type (fp16 build: |v| > 65 504 or
+                              // not finite -- the un-normalised residual stream is the one operand producer without a natural bound)
     const float* fold_rowf;   // [M][2] (rstd, rstd * mean) or null = plain GEMM
     const float* fold_c1;     // [N], 16-byte aligned
     const float* fold_c2;     // [N], 16-byte aligned

@@ -615,6 +615,13 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
                 pq += f5_dpp_row<0x122>(pq);
                 ps += f5_dpp_row<0x121>(ps);
                 pq += f5_dpp_row<0x121>(pq);
+#if F5_F16
+                if (p.x16_overflow != nullptr) {             // fail loudly: f5_pack2 saturates, the engine reports the flag (f5_sample_status)
+                    const bool ov = grow < p.M && !(fmaxf(fmaxf(fabsf(o[0] * sc4[0]), fabsf(o[1] * sc4[1])),
+                                                          fmaxf(fabsf(o[2] * sc4[2]), fabsf(o[3] * sc4[3]))) <= 65504.0f);
+                    if (__any(ov) && lane == 0) atomicOr(p.x16_overflow, 1);
+                }
+#endif
                 if (grow < p.M) {
                     *reinterpret_cast<u32x2*>(p.x16_out + (size_t)grow * p.ldx16 + colbase + chunk * 4) =
                         u32x2{f5_pack2(o[0] * sc4[0], o[1] * sc4[1]), f5_pack2(o[2] * sc4[2], o[3] * sc4[3])};

@@ -294,8 +294,26 @@ class Engine:
         a, keep = self._args(text, cond, lens, durations, y0, t, steps, method, cfg_strength, use_mask, use_graph, out,
                              trajectory if return_trajectory else None, ws)
         self._run_on_side_stream(lambda st: check(self.lib.f5_sample(self._h, C.byref(a), st), "f5_sample"))
+        self._raise_on_operand_overflow(a, B, N, cfg_strength)
         del keep
         return out, (trajectory if return_trajectory else None)
+
+    def _raise_on_operand_overflow(self, a, B: int, N: int, cfg_strength: float) -> None:
+        """LN fold (engine option "ln_fold", active from 22 000 rows in the f16 mode): the GEMM operand x (1 + scale) is the
+        UN-normalised residual stream in fp16.  Every other operand producer has a natural bound; this one is checked: the kernels
+        flag a value beyond +-65 504 and the call fails here instead of returning a saturated result (costs one stream
+        synchronisation, only where the fold can run)."""
+        if self.precision != "f16":
+            return
+        opt = self.get_option("ln_fold")
+        rows = (2 if cfg_strength >= 1e-5 else 1) * B * N
+        if opt == 0 or (opt < 0 and rows < 22000):
+            return
+        flags = C.c_int(0)
+        self._run_on_side_stream(lambda st: check(self.lib.f5_sample_status(self._h, C.byref(a), C.byref(flags), st), "f5_sample_status"))
+        if flags.value & 1:
+            raise RuntimeError("ln_fold: the residual stream times (1 + scale) left the fp16 range (|v| > 65504); the result is saturated. "
+                               "Set the engine option ln_fold to 0 (Engine.set_option('ln_fold', 0)) or use precision 'bf16' / 'bf16x3'.")
 
     def dit_forward(self, x: torch.Tensor, text: torch.Tensor, cond: torch.Tensor, lens, durations, t: float,
                     cfg_strength: float = 2.0, use_mask: Optional[bool] = None):
@@ -311,5 +329,6 @@ class Engine:
                              False, None, None, ws)
         self._run_on_side_stream(lambda st: check(
             self.lib.f5_dit_forward(self._h, C.byref(a), ptr(x), C.c_float(t), ptr(pred), ptr(null), st), "f5_dit_forward"))
+        self._raise_on_operand_overflow(a, B, N, cfg_strength)
         del keep
         return pred, null

@@ -121,6 +121,12 @@ typedef struct f5_sample_args {
 int f5_workspace_bytes(f5_engine* e, int B, int N, int nt, int steps, int method, size_t* bytes);
 int f5_sample(f5_engine* e, const f5_sample_args* args, void* stream);
 
+/* Status word of the last f5_sample / f5_dit_forward on this workspace with these sizes (B, N, nt, steps, method, workspace of `args`):
+ * bit 0 = a value of the folded LayerNorm operand x (1 + scale) did not fit fp16 (engine option "ln_fold" active, precision f16): the
+ * output is saturated there -- rerun with ln_fold = 0 or in bf16.  Synchronises `stream`.  No reference counterpart (the reference has
+ * no reduced-precision operands). */
+int f5_sample_status(f5_engine* e, const f5_sample_args* args, int* flags, void* stream);
+
 /* One DiT forward (dit.py:374-401) for tests/diagnostics: same inputs as f5_sample, evaluates the
  * velocity field at time `t` for state `x` (dev [B][N][mel]); writes pred (and null when
  * cfg_strength >= 1e-5) as dev [B][N][mel] each. */
@@ -278,6 +284,7 @@ int f5_debug_set_q_premul(int on);          /* 1 (default): sample() multiplies 
 int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float* stats_out);
 int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, void* stream);
 int f5_debug_set_op_fold_consumer(const float* rowf, const float* c1, const float* c2);
+int f5_debug_set_op_fold_overflow_flag(int* flag);   /* device word the producer ORs bit 0 into when x (1 + s) leaves the fp16 range; NULL = off */
 /* c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k] shift_v[k] + bias[n] for nvec modulation vectors (vec_stride
  * floats apart; result rows out_stride floats apart); K % 256 == 0, K <= 2048 */
 int f5_op_fold_consts(const void* w_hi, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,

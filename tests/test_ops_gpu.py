@@ -904,6 +904,24 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
         finally:
             E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None)))
         sync()
+        # the operand-range flag: x (1 + s) is the one fp16 operand without a natural bound -- a value beyond +-65 504 must raise bit 0
+        # of the flag word (fp16 build only; bf16 has the range), ordinary data must leave it alone
+        flag = torch.zeros(4, dtype=torch.int32, device=DEV)
+        xbig = (x0 * 3.0e4).to(DEV).clone()
+        for xin, want in ((x0.to(DEV).clone(), 0), (xbig, 1 if op_dtype() == torch.float16 else 0)):
+            flag.zero_()
+            E.check(lib.f5_debug_set_op_fold_overflow_flag(P(flag)))
+            E.check(lib.f5_debug_set_op_fold_producer(P(sv_d[1]), P(torch.zeros_like(x16)), P(torch.zeros_like(stats))))
+            try:
+                x16_tmp, stats_tmp = torch.zeros_like(x16), torch.zeros_like(stats)
+                E.check(lib.f5_debug_set_op_fold_producer(P(sv_d[1]), P(x16_tmp), P(stats_tmp)))
+                E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(wo_hi), P(None), P(bo_d), P(gate_d), P(keep_d), P(xin), M, D, D, D, D, D, 1,
+                                                  stream()), "resid_gate fold producer (range flag)")
+                sync()
+            finally:
+                E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None)))
+                E.check(lib.f5_debug_set_op_fold_overflow_flag(P(None)))
+            assert flag.cpu().tolist() == [want, 0, 0, 0], (flag.cpu().tolist(), want)
         assert torch.equal(x, x_plain), "the fold producer changed the residual stream"
         xc = x.cpu()
         want16 = (xc * (1.0 + s1)).to(op_dtype())
