@@ -49,6 +49,11 @@ def test_large_gemm_k_loops_have_no_compiler_vmcnt_wait(name):
         asm = compile_to_asm(os.path.join(ROOT, "f5_tts_mlx_amd", "csrc", name + ".hip"), [f"-DF5_F16={f16}", "-fno-slp-vectorize"])
         found = {k: v for k, v in scan(asm).items() if "gemm" in k}
         assert "v_mfma" in asm and not found, (name, f16, found)
+        # ... and no instantiation spills: the FOLD epilogues (LN fold, round 4) sit on top of 128 live accumulators -- a persistent-walk
+        # experiment on these kernels spilled 200-600 bytes and ran 0.2-0.6x (profiles/r04/gemm256_persistent_walk_rejected.jsonl)
+        import re
+        sizes = re.findall(r"\.amdhsa_kernel (\S+).*?\.amdhsa_private_segment_fixed_size (\d+)", asm, re.S)
+        assert sizes and all(int(n) == 0 for k, n in sizes if "gemm" in k), [(k, n) for k, n in sizes if int(n)]
 
 
 def _noslp_list():
