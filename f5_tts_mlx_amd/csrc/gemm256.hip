@@ -251,7 +251,9 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     // 16-bit row-major outputs: the tile is accumulated TRANSPOSED (operands swapped in every MFMA) for staged_epilogue_tr.  Both
     // loop copies end in their own epilogue: no join with 128 live accumulator registers.
     constexpr bool TR_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
+    FoldPre fpre;                                       // (FOLD epilogues: their operands are requested before the K loop)
     if ((TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel)) {       // workgroup-uniform
+        if (fold) fold_prefetch_tr<4>(p, fpre, row0, col0, lane);
         for (int tt = 0; tt < T; tt += 2) {
             G256_KSTEP(0, tt, true);
             if (tt + 1 < T) G256_KSTEP(1, tt + 1, true);
@@ -259,14 +261,15 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         if (wm == 0) G256_BARRIER();                    // group 0 waits for group 1's last MATRIX segment: the ring is dead
         if ((p.debug_flags & 1) || !act_lo) return;     // flag 1 = timing experiment: main loop only
         if (fold) {                                     // LN-modulate folded into this GEMM (F5GemmArgs::fold_*; workgroup-uniform)
-            if (QT) staged_epilogue_tr_rope<4, 2, true>(p, acc, stage, row0, col0, lane, fl);
-            else staged_epilogue_tr<EPI, 4, 2, true>(p, acc, stage, row0, col0, lane, fl);
+            if (QT) staged_epilogue_tr_rope<4, 2, true>(p, acc, stage, row0, col0, lane, fl, &fpre);
+            else staged_epilogue_tr<EPI, 4, 2, true>(p, acc, stage, row0, col0, lane, fl, &fpre);
             return;
         }
         if (QT) staged_epilogue_tr_rope<4, 2>(p, acc, stage, row0, col0, lane);
         else staged_epilogue_tr<EPI, 4, 2>(p, acc, stage, row0, col0, lane);
         return;
     }
+    if (QT && fold) fold_prefetch_v<4>(p, fpre, row0, col0, lane);
     for (int tt = 0; tt < T; tt += 2) {
         G256_KSTEP(0, tt, false);
         if (tt + 1 < T) G256_KSTEP(1, tt + 1, false);
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     }
     if (!act_lo) return;
     if (QT) {                                                               // (the q / k tiles finished above)
-        if (fold) staged_epilogue_bf16<EPI, 4, 2, true, true>(p, acc, stage, row0, col0, lane, fl);
+        if (fold) staged_epilogue_bf16<EPI, 4, 2, true, true>(p, acc, stage, row0, col0, lane, fl, &fpre);
         else staged_epilogue_bf16<EPI, 4, 2, true>(p, acc, stage, row0, col0, lane);
     } else if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
         staged_epilogue_bf16<EPI, 4, 2>(p, acc, stage, row0, col0, lane);

@@ -167,31 +167,43 @@ __device__ __forceinline__ void glds16(const op16_t* gptr, op16_t* lds_wave_base
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0);
 }
 
-// ---- LN-modulate folded into the consumer GEMM (F5GemmArgs::fold_*): the finished row factors (rstd, rstd * mean) of the wave's ROWS
-// rows from fold_rowf into the wave's private LDS scratch fl[ROWS][2] (the straight V tiles hold rows in registers: they read them back
-// as broadcasts).  One 8-byte load per lane and 64 rows, coalesced.
-template <int ROWS>
-__device__ __forceinline__ void fold_rows_to_lds(const F5GemmArgs& p, float* fl, int row0, int lane) {
-#pragma unroll
-    for (int base = 0; base < ROWS; base += 64) {
-        const int r = base + lane;
-        int grow = row0 + r;
-        if (grow > p.M - 1) grow = p.M - 1;
-        const f5_f32x2 t = reinterpret_cast<const f5_f32x2*>(p.fold_rowf)[grow];
-        if (r < ROWS) *reinterpret_cast<f5_f32x2*>(&fl[2 * r]) = t;
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-// the same for the transposed tiles (lane = token lcol of every 32-row block): straight into registers, requested together with the
-// bias / rotation loads of the epilogue -- no extra round trip to memory
+// ---- LN-modulate folded into the consumer GEMM (F5GemmArgs::fold_*)
+// What a FOLD epilogue needs from memory, requested BEFORE the K loop (10 registers through the loop): a one-workgroup-per-CU kernel
+// has nothing to hide a load round trip at the head of its epilogue behind -- requested there it cost 1 us per tile (round 4:
+// +8 us on the FF1 launch of batch 32, +4 on QKV).  Transposed tiles (lane = token): rr[mb] = row factors of the lane's token in each
+// 32-row block, c[0] / c[1] = c1 / c2 of column col0 + lane.  Straight V tiles (lane = feature, rows in registers): rr[i] = row factors
+// of row i * 64 + lane (spread to the wave through LDS later), c[0..3] = c1 / c2 of the lane's two columns.
+struct FoldPre {
+    f5_f32x2 rr[4];
+    float c[4];
+};
 template <int MBW>
-__device__ __forceinline__ void fold_rows_to_regs(const F5GemmArgs& p, f5_f32x2 (&rr)[MBW], int row0, int lcol) {
+__device__ __forceinline__ void fold_prefetch_tr(const F5GemmArgs& p, FoldPre& f, int row0, int col0, int lane) {
+    static_assert(MBW <= 4, "row blocks per wave");
+    const f5_f32x2* rf = reinterpret_cast<const f5_f32x2*>(p.fold_rowf);
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
-        int grow = row0 + mb * 32 + lcol;
+        int grow = row0 + mb * 32 + (lane & 31);
         if (grow > p.M - 1) grow = p.M - 1;
-        rr[mb] = reinterpret_cast<const f5_f32x2*>(p.fold_rowf)[grow];
+        f.rr[mb] = rf[grow];
     }
+    f.c[0] = p.fold_c1[col0 + lane];
+    f.c[1] = p.fold_c2[col0 + lane];
+}
+template <int MBW>
+__device__ __forceinline__ void fold_prefetch_v(const F5GemmArgs& p, FoldPre& f, int row0, int col0, int lane) {
+    const f5_f32x2* rf = reinterpret_cast<const f5_f32x2*>(p.fold_rowf);
+#pragma unroll
+    for (int i = 0; i < (32 * MBW + 63) / 64; ++i) {
+        int grow = row0 + i * 64 + lane;
+        if (grow > p.M - 1) grow = p.M - 1;
+        f.rr[i] = rf[grow];
+    }
+    const int lcol = lane & 31;
+    f.c[0] = p.fold_c1[col0 + lcol];
+    f.c[1] = p.fold_c1[col0 + 32 + lcol];
+    f.c[2] = p.fold_c2[col0 + lcol];
+    f.c[3] = p.fold_c2[col0 + 32 + lcol];
 }
 
 // ---- LDS-staged epilogues (used by the 256x256 and the 128x256 kernels).  A wave owns a (32*MBW) x (32*NBW) tile
@@ -201,10 +213,10 @@ __device__ __forceinline__ void fold_rows_to_regs(const F5GemmArgs& p, f5_f32x2 
 // the token axis; those 16-byte stores may be only 2-byte aligned (legal on gfx950, tools/probes/unaligned.hip) and
 // are split element-wise where a chunk crosses a batch-element boundary.
 // FOLD (V tiles only): the LN-modulate fold of F5GemmArgs::fold_* -- value = rstd * acc - rstd * mean * c1[col] + c2[col], the row
-// factors (finished by f5_launch_fold_rows) from the wave's LDS scratch `fl` (fold_rows_to_lds).
+// factors (finished by f5_launch_fold_rows, requested before the K loop: FoldPre) through the wave's LDS scratch `fl`.
 template <int EPI, int MBW, int NBW, bool VONLY = false, bool FOLD = false>
 __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
-                                                     int colbase, int lane, float* fl = nullptr) {
+                                                     int colbase, int lane, float* fl = nullptr, const FoldPre* pre = nullptr) {
     static_assert(!FOLD || VONLY, "the straight q / k / FF1 tiles have no folded form");
     constexpr int W = 32 * NBW;
     constexpr int LD = W + 8;
@@ -216,14 +228,20 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         if (FOLD) {
-            bcol[nb] = p.fold_c2[colbase + nb * 32 + lcol];
-            c1col[nb] = p.fold_c1[colbase + nb * 32 + lcol];
+            static_assert(!FOLD || NBW == 2, "FoldPre holds two columns per lane");
+            bcol[nb] = pre->c[2 + (nb & 1)];
+            c1col[nb] = pre->c[nb & 1];
         } else {
             bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
             c1col[nb] = 0.0f;
         }
     }
-    if (FOLD) fold_rows_to_lds<32 * MBW>(p, fl, row0, lane);
+    if (FOLD) {                                          // the row factors requested before the K loop, spread to the wave through LDS
+#pragma unroll
+        for (int i = 0; i < (32 * MBW + 63) / 64; ++i)
+            if (i * 64 + lane < 32 * MBW) *reinterpret_cast<f5_f32x2*>(&fl[2 * (i * 64 + lane)]) = pre->rr[i];
+        __builtin_amdgcn_wave_barrier();
+    }
     const bool is_v = VONLY || ((EPI == EPI_QKV_ROPE) && (colbase >= 2 * p.dmodel));   // VONLY: the q / k tiles went elsewhere
 
     if (!is_v) {
@@ -374,7 +392,7 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
 // FOLD: the LN-modulate fold of F5GemmArgs::fold_* (lane = token: its two row factors are one 8-byte LDS read per 32-token block).
 template <int EPI, int MBW, int NBW, bool FOLD = false>
 __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0, int colbase,
-                                                   int lane, float* fl = nullptr) {
+                                                   int lane, float* fl = nullptr, const FoldPre* pre = nullptr) {
     constexpr int W = 32 * NBW;
     constexpr int LD = W + 8;
     constexpr int CPR = W / 8;             // 16-byte chunks per row
@@ -391,13 +409,13 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
             b4[nb][rg] = (!FOLD && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + colbase + nb * 32 + rg * 8 + hi * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     f5_f32x2 rrv[MBW];
     if (FOLD) {
-        // ONE round trip to memory for everything the fold needs: the lane's row factors into registers, the wave's W columns of c1 | c2
-        // into the LDS scratch (read back as 16-byte broadcasts inside the loops: no vmcnt waits between the staging passes)
-        fold_rows_to_regs<MBW>(p, rrv, row0, lcol);
-        if (lane < W) {
-            fl[lane] = p.fold_c1[colbase + lane];
-            fl[W + lane] = p.fold_c2[colbase + lane];
-        }
+        // everything the fold needs was requested before the K loop (FoldPre): the lane's row factors are registers, the wave's W
+        // columns of c1 | c2 go through the LDS scratch (read back as 16-byte broadcasts, once)
+        static_assert(!FOLD || W == 64, "one column of c1 | c2 per lane");
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) rrv[mb] = pre->rr[mb];
+        fl[lane] = pre->c[0];
+        fl[W + lane] = pre->c[1];
         __builtin_amdgcn_wave_barrier();
     }
     // the lane's c1 / c2 quads, read back ONCE (b4 = c2): LDS reads between the staging passes would serialise on lgkmcnt(0) with the
@@ -455,7 +473,7 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
 // block).  q_premul is folded into the q tables by the host.  dit.py:136-158.
 template <int MBW, int NBW, bool FOLD = false>
 __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], op16_t* reg, int row0,
-                                                        int colbase, int lane, float* fl = nullptr) {
+                                                        int colbase, int lane, float* fl = nullptr, const FoldPre* pre = nullptr) {
     constexpr int W = 32 * NBW;
     constexpr int LD = W + 8;
     constexpr int CPR = W / 8;
@@ -468,12 +486,12 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
     op16_t* rh = reg;
     op16_t* rl = reg + 32 * LD;
     f5_f32x2 rrv[MBW];
-    if (FOLD) {                                              // as staged_epilogue_tr: row factors -> registers, c1 | c2 -> LDS scratch
-        fold_rows_to_regs<MBW>(p, rrv, row0, lcol);
-        if (lane < W) {
-            fl[lane] = p.fold_c1[colbase + lane];
-            fl[W + lane] = p.fold_c2[colbase + lane];
-        }
+    if (FOLD) {                                              // as staged_epilogue_tr: FoldPre -> registers / LDS scratch
+        static_assert(!FOLD || W == 64, "one column of c1 | c2 per lane");
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) rrv[mb] = pre->rr[mb];
+        fl[lane] = pre->c[0];
+        fl[W + lane] = pre->c[1];
         __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll

@@ -225,20 +225,23 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
     const bool fold = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH) && p.fold_rowf != nullptr;
     const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
     constexpr bool TR_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
+    FoldPre fpre;                                       // (FOLD epilogues: their operands are requested before the K loop)
     if ((TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel)) {       // workgroup-uniform
+        if (fold && active) fold_prefetch_tr<2>(p, fpre, row0, col0, lane);
         for (int tt = 0; tt < T; ++tt) RS_STEP(tt, true);
         if (wm == 0) RS_BARRIER();                      // group 0 waits for group 1's last MATRIX segment: the ring is dead
         if ((p.debug_flags & 1) || !active) return;
         // (requesting the rotation factors before the K loop -- 64 more live registers -- was measured neutral: 25.3 vs 25.6 us)
         if (fold) {                                     // LN-modulate folded into this GEMM (F5GemmArgs::fold_*; workgroup-uniform)
-            if (QT) staged_epilogue_tr_rope<2, 2, true>(p, acc, stage, row0, col0, lane, fl);
-            else staged_epilogue_tr<EPI, 2, 2, true>(p, acc, stage, row0, col0, lane, fl);
+            if (QT) staged_epilogue_tr_rope<2, 2, true>(p, acc, stage, row0, col0, lane, fl, &fpre);
+            else staged_epilogue_tr<EPI, 2, 2, true>(p, acc, stage, row0, col0, lane, fl, &fpre);
             return;
         }
         if (QT) staged_epilogue_tr_rope<2, 2>(p, acc, stage, row0, col0, lane);
         else staged_epilogue_tr<EPI, 2, 2>(p, acc, stage, row0, col0, lane);
         return;
     }
+    if (QT && fold && active) fold_prefetch_v<2>(p, fpre, row0, col0, lane);
     for (int tt = 0; tt < T; ++tt) RS_STEP(tt, false);
     if (wm == 0) RS_BARRIER();
     if (p.debug_flags & 1) {
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
     }
     if (!active) return;
     if (QT) {
-        if (fold) staged_epilogue_bf16<EPI, 2, 2, true, true>(p, acc, stage, row0, col0, lane, fl);
+        if (fold) staged_epilogue_bf16<EPI, 2, 2, true, true>(p, acc, stage, row0, col0, lane, fl, &fpre);
         else staged_epilogue_bf16<EPI, 2, 2, true>(p, acc, stage, row0, col0, lane);
     } else if (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16 || EPI == EPI_QKV_ROPE) {
         staged_epilogue_bf16<EPI, 2, 2>(p, acc, stage, row0, col0, lane);
