@@ -189,6 +189,7 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20, peak_meas: di
         fstats = torch.zeros(D // 64, M, 2, device=dev)
         frowf = torch.ones(M, 2, device=dev)
         fh16 = torch.zeros(M, D, dtype=opd, device=dev)
+        fshift = torch.zeros(M, device=dev)           # the row shift of the folded operand (the previous LayerNorm's mean)
         fc = {n: (torch.zeros(n, device=dev), torch.zeros(n, device=dev)) for n in (3 * D, FF)}
 
     class _fold:                                      # the op-level hooks are process-wide switches: set around ONE launch
@@ -197,13 +198,13 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20, peak_meas: di
 
         def __enter__(self):
             if folded and self.kind == "producer":
-                E.check(lib.f5_debug_set_op_fold_producer(P(fscale), P(fh16), P(fstats)))
+                E.check(lib.f5_debug_set_op_fold_producer(P(fscale), P(fh16), P(fstats), P(fshift)))
             elif folded:
                 E.check(lib.f5_debug_set_op_fold_consumer(P(frowf), P(fc[self.n][0]), P(fc[self.n][1])))
 
         def __exit__(self, *a):
             if folded and self.kind == "producer":
-                E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None)))
+                E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None), P(None)))
             elif folded:
                 E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(None), P(None)))
 
@@ -241,7 +242,7 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20, peak_meas: di
     def _k_ff2():
         E.check(lib.f5_op_gemm_resid_gate(P(x2), P(lo(x2l)), P(w2), P(lo(w2l)), P(bd), P(gate), P(None), P(xres), M, D, FF, FF, FF, D, nseg, st()))
 
-    fold_bytes = (2 * M * D + 8 * M * (D // 64)) if folded else 0      # producer: + the 16-bit x (1 + s) operand and the partial row sums
+    fold_bytes = (2 * M * D + 8 * M * (D // 64)) if folded else 0      # producer: + the 16-bit (x - m)(1 + s) operand and the slice statistics
     specs = [
         ("qkv_gemm", "QKV projection GEMM + bias + RoPE + head split (f5_gemm*_kernel<EPI_QKV_ROPE>)", k_qkv, 2.0 * M * D * 3 * D,
          f"M={M} N={3 * D} K={D}", 2 * M * D + 2 * 3 * D * D + 2 * M * 3 * D),

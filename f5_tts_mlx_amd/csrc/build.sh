@@ -4,12 +4,18 @@
 #   bash build.sh            product library: the kernels sample() / the vocoder / the mel front-end can reach
 #   F5_LAB=1 bash build.sh   lab library (same file name): + the superseded / rejected kernels and the hooks that select them
 #                            (include/f5tts_hip_lab.h).  Objects of the two flavours live in build/ and build_lab/.
+#   F5_PROBE=1 bash build.sh measurement build libf5tts_hip_probe.so (objects in build_probe/): the product kernels + the ablation
+#                            switches of csrc/gemm_dev.hpp F5_PROBE_* (epilogue without stores / without its arithmetic, phase-shifted
+#                            first round, non-temporal residual stream); loaded through F5TTS_HIP_LIB by tools/r5_epilogue_probe.py only
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 LAB=${F5_LAB:-0}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DF5_LAB=$LAB"
+PROBE=${F5_PROBE:-0}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DF5_LAB=$LAB -DF5_PROBE=$PROBE"
 B=build
+OUT=libf5tts_hip.so
+if [ "$PROBE" = 1 ]; then B=build_probe; OUT=libf5tts_hip_probe.so; fi
 KERNELS="gemm gemm256 gemm_rs128 gemm_f8 attention convpos rowops"
 if [ "$LAB" = 1 ]; then B=build_lab; KERNELS="$KERNELS gemm_lab gemm128"; fi
 mkdir -p $B
@@ -38,5 +44,5 @@ for f in audio vocoder noise engine; do
   if stale $f.hip $o 1; then $HIPCC $FLAGS -c $f.hip -o $o & pids+=($!); fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o libf5tts_hip.so
-echo "built $(pwd)/libf5tts_hip.so (F5_LAB=$LAB)"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o $OUT
+echo "built $(pwd)/$OUT (F5_LAB=$LAB F5_PROBE=$PROBE)"

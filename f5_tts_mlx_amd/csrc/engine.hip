@@ -47,8 +47,10 @@ struct TextBlockW {
 
 struct Workspace {
     size_t total = 0;
-    size_t scal, scal_words;   // per-call host scalars, contiguous: [lens B | dur2 2B | tgrid nfe | dt steps | cfg 1 | lncnt | status 1] (32-bit words)
-    size_t status;             // one word, zeroed with the scalars: bit 0 = LN-fold operand overflow (fp16), read by f5_sample_status
+    size_t scal, scal_words;   // per-call host scalars, contiguous: [status 1 | lens B | dur2 2B | tgrid nfe | dt steps | cfg 1 | lncnt] (32-bit words)
+    size_t status;             // THE FIRST WORD OF THE WORKSPACE for every shape / solver (a C caller may read it without re-planning), staged
+                               // with the scalars: bit 1 = the LN fold ran in this call (set by the host), bit 0 = a folded operand left the
+                               // fp16 range (set by the producing epilogue); f5_sample_status / f5_sample_status_async
     size_t lncnt, lncnt_words; // row-block arrival counters of the fused LN tail (zeroed with the scalars; 0 words = no fusion)
     size_t lens, dur2, text, ids, keep, rowkeep;
     size_t tgrid, dt, cfgv, sinus, th, temb, mod;
@@ -61,9 +63,12 @@ struct Workspace {
     size_t hc, x;
     size_t xb[2], c1[2], h[2], qk[2], vt[2], ao[2], ffh[2];
     size_t h8, h8s, ao8, ao8s, ffh8, ffh8s;   // precision mxfp8: block-GEMM A operands as e4m3 + E8M0
-    size_t lnstats;                // LN fold: per 64-column slice and row (sum, sum of squares) of the residual stream, [D / 64][M2][2] floats
-    size_t lnrowf;                 // LN fold: row factors (rstd, rstd * mean), [M2][2] floats
-    size_t foldc[2];               // LN fold: c1, c2 tables, [nfe][L][3 D + FF] floats each
+    // LN fold (0 bytes each where the fold cannot run: plan_workspace)
+    size_t lnstats;                // per 64-column slice and row (sum d, centred sum of squares) of d = x - lnmean, [D / 64][M2][2] floats
+    size_t lnrowf;                 // row factors (rstd, rstd * (mean - lnmean)), [M2][2] floats
+    size_t lnmean;                 // the row's mean at its previous LayerNorm = the shift of the next folded operand, [M2] floats
+    size_t foldc[2];               // c1, c2 tables, [nfe][L][3 D + FF] floats each
+    bool fold_planned;
     size_t vt_bytes;
 };
 
@@ -449,6 +454,11 @@ extern "C" int f5_finalize_weights(f5_engine* e, void* stream) {
 // ------------------------------------------------------------------------------------------------
 // workspace plan
 // ------------------------------------------------------------------------------------------------
+// LN fold, automatic mode: measured on sample(), 335M shape, f16 (profiles/r04/ln_fold_ab.jsonl): batch 4 -1.2 %, 8 -1.1 %, 12 +0.3 %,
+// 16 +0.8 %, 32 +2.5 %: the LN launches it removes cost ~2 us per thousand rows, what it adds (x16 write in the residual epilogues, the
+// row-factor kernel) has a floor
+constexpr long LN_FOLD_AUTO_ROWS = 22000;
+
 static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int steps, int method) {
     const f5_config& c = e->cfg;
     const int D = c.dim, Dt = c.text_dim, FF = c.ff_dim, TF = c.text_ff_dim, L = c.depth, np = e->np, mel = c.mel_dim;
@@ -460,15 +470,15 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
     const size_t nfe1 = (size_t)(nfe > 0 ? nfe : 1);
     // one counter per 64 rows of the residual stream; only small-M launches fuse (gemm.hpp ln_counter), large ones get none
     w.lncnt_words = (M2 + 63) / 64 <= 512 ? (M2 + 63) / 64 : 0;
-    w.scal_words = (size_t)3 * B + nfe1 + steps + 1 + w.lncnt_words + 1;
+    w.scal_words = (size_t)1 + 3 * B + nfe1 + steps + 1 + w.lncnt_words;
     w.scal = b.take(w.scal_words * 4);
-    w.lens = w.scal;
+    w.status = w.scal;                      // offset 0, whatever the sizes
+    w.lens = w.scal + 4;
     w.dur2 = w.lens + (size_t)B * 4;
     w.tgrid = w.dur2 + (size_t)2 * B * 4;
     w.dt = w.tgrid + nfe1 * 4;
     w.cfgv = w.dt + (size_t)steps * 4;
     w.lncnt = w.cfgv + 4;
-    w.status = w.lncnt + w.lncnt_words * 4;
     w.text = b.take((size_t)B * (nt > 0 ? nt : 1) * 4);
     w.ids = b.take(M2 * 4);
     w.keep = b.take(M2);
@@ -508,9 +518,14 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
         w.ao[p] = p < np ? b.take(M2 * D * 2) : 0;
         w.ffh[p] = p < np ? b.take(M2 * FF * 2) : 0;
     }
-    w.lnstats = b.take(M2 * (size_t)((D + 63) / 64) * 2 * 4);
-    w.lnrowf = b.take(M2 * 2 * 4);
-    for (int p = 0; p < 2; ++p) w.foldc[p] = b.take(nfe1 * L * (size_t)(3 * D + FF) * 4);
+    // LN fold buffers only where the fold can run (a superset of ln_fold_state(): that one also knows the branch count of the call):
+    // one-pass 16-bit operand modes, the option not 0, and -- in the automatic mode -- enough rows for it to be chosen with both branches
+    w.fold_planned = np == 1 && e->prec != F5_PREC_MXFP8 && e->opt.ln_fold != 0 && (e->opt.ln_fold == 1 || (long)M2 >= LN_FOLD_AUTO_ROWS);
+    const size_t fp = w.fold_planned ? 1 : 0;
+    w.lnstats = b.take(fp * M2 * (size_t)((D + 63) / 64) * 2 * 4);
+    w.lnrowf = b.take(fp * M2 * 2 * 4);
+    w.lnmean = b.take(fp * M2 * 4);
+    for (int p = 0; p < 2; ++p) w.foldc[p] = b.take(fp * nfe1 * L * (size_t)(3 * D + FF) * 4);
     w.h8 = w.h8s = w.ao8 = w.ao8s = w.ffh8 = w.ffh8s = 0;
     if (e->prec == F5_PREC_MXFP8) {
         w.h8 = b.take(M2 * D);
@@ -605,10 +620,8 @@ static int ln_fold_state(const Ctx& c) {
             ok = ok && c.ops.gemm_runs_staged(g, sh[2]);
         }
     }
-    // measured on sample(), 335M shape, f16 (profiles/r04/ln_fold_ab.jsonl): batch 4 -1.2 %, 8 -1.1 %, 12 +0.3 %, 16 +0.8 %, 32 +2.5 %: the
-    // LN launches it removes cost ~2 us per thousand rows, what it adds (x16 write in the residual epilogues, the row-factor kernel) has a floor
-    constexpr int LN_FOLD_AUTO_ROWS = 22000;
     if (e->opt.ln_fold < 0 && M < LN_FOLD_AUTO_ROWS) return 0;
+    if (!c.w.fold_planned) ok = false;              // (cannot happen: the plan's predicate is a superset of this one)
     if (!ok && e->opt.ln_fold == 1) {
         f5_set_error("ln_fold = 1: this shape / precision cannot run the folded LN (needs f16 or bf16, qkv_transposed, no ln_fusion, dim %% 256 "
                      "== 0, and all four block GEMMs on the 256x256 / role-split 128x256 kernels: batch >= 4 at the 335M shape)");
@@ -884,16 +897,17 @@ static int run_dit(const Ctx& c, int j) {
         g.x16_out = c.pb(w.h, 0);
         g.ldx16 = D;
         g.x16_scale = next_scale;
+        g.x16_shift = c.p<float>(w.lnmean);        // the row's mean at the previous LayerNorm (LN kernel of block 0 / fold_rows)
         g.stats_out = c.p<float>(w.lnstats);
         g.stats_ld = M;
         g.x16_overflow = c.p<int>(w.status);
     };
-    auto fold_rows = [&]() { return K.fold_rows(c.p<float>(w.lnstats), M, D / 64, M, 1e-6f, c.p<float>(w.lnrowf), s); };
+    auto fold_rows = [&]() { return K.fold_rows(c.p<float>(w.lnstats), M, D / 64, M, 1e-6f, c.p<float>(w.lnrowf), c.p<float>(w.lnmean), s); };
     bool h_folded = false;                       // `h` holds x (1 + scale) + row sums (fold) instead of the finished LN-modulate
     for (int i = 0; i < L && e->prec != F5_PREC_MXFP8; ++i) {
         const BlockW& bw = e->blocks[i];
         const float* m6 = mod + (size_t)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        if (!h_ready) RC(K.ln_modulate(c.p<float>(w.x), m6 + D, m6, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s));
+        if (!h_ready) RC(K.ln_modulate(c.p<float>(w.x), m6 + D, m6, c.pb(w.h, 0), c.pb(w.h, 1), M, D, 1e-6f, s, fold ? c.p<float>(w.lnmean) : nullptr));
         F5GemmArgs gq = gemm_base(c, c.pb(w.h, 0), c.pb(w.h, 1), D, bw.qkv, M, 3 * D, D, c.a<float>(bw.bqkv));
         if (h_folded) fold_consumer(gq, i, 0);
         gq.out_bf[0] = c.pb(w.qk, 0);
@@ -1080,13 +1094,17 @@ static int stage_inputs(Ctx& c, const f5_sample_args* a, const float* x_override
     // host scalars -> workspace as kernel arguments (no host buffer outlives this call, no host synchronisation)
     const size_t nfe1 = tnfe.empty() ? 1 : tnfe.size();
     std::vector<uint32_t> words(w.scal_words, 0u);
-    F5_REQUIRE(w.scal_words == (size_t)3 * c.B + nfe1 + a->steps + 1 + w.lncnt_words + 1 && dts.size() <= (size_t)a->steps,
+    F5_REQUIRE(w.scal_words == (size_t)1 + 3 * c.B + nfe1 + a->steps + 1 + w.lncnt_words && dts.size() <= (size_t)a->steps,
                "internal: scalar staging layout");
-    memcpy(words.data(), a->lens, (size_t)c.B * 4);
-    for (int b = 0; b < c.B; ++b) words[c.B + b] = words[2 * c.B + b] = (uint32_t)a->durations[b];
-    if (!tnfe.empty()) memcpy(words.data() + 3 * c.B, tnfe.data(), tnfe.size() * 4);
-    if (!dts.empty()) memcpy(words.data() + 3 * c.B + nfe1, dts.data(), dts.size() * 4);
-    memcpy(words.data() + 3 * c.B + nfe1 + a->steps, &a->cfg_strength, 4);
+    const int fold_state = ln_fold_state(c);
+    if (fold_state < 0) return 2;
+    words[0] = fold_state == 1 ? 2u : 0u;            // status word: bit 1 = the LN fold runs in this call, bit 0 is the kernels'
+    uint32_t* wd = words.data() + 1;
+    memcpy(wd, a->lens, (size_t)c.B * 4);
+    for (int b = 0; b < c.B; ++b) wd[c.B + b] = wd[2 * c.B + b] = (uint32_t)a->durations[b];
+    if (!tnfe.empty()) memcpy(wd + 3 * c.B, tnfe.data(), tnfe.size() * 4);
+    if (!dts.empty()) memcpy(wd + 3 * c.B + nfe1, dts.data(), dts.size() * 4);
+    memcpy(wd + 3 * c.B + nfe1 + a->steps, &a->cfg_strength, 4);
     RC(f5_launch_stage_words(words.data(), words.size(), c.p<uint32_t>(w.scal), s));
     // caller-owned device inputs -> workspace (the captured graph only references the workspace and the arena)
     RC(f5_launch_copy_words(a->text, c.ws + w.text, (size_t)c.B * c.nt, s));
@@ -1217,14 +1235,29 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     return 0;
 }
 
-// Status word of the last f5_sample / f5_dit_forward that used this workspace with these sizes: bit 0 = a value of the folded LN
-// operand x (1 + scale) did not fit fp16 (ln_fold active, precision f16): the result is saturated there -- rerun with the engine
-// option ln_fold = 0 or in bf16.  Synchronises the stream.
+// Status word of the last f5_sample / f5_dit_forward that used this workspace (its FIRST 32-bit word, for every shape and solver):
+// bit 1 = the LN fold ran in that call; bit 0 = a value of the folded operand (x - m)(1 + scale) did not fit fp16 (precision f16): the
+// result is saturated there -- rerun with the engine option ln_fold = 0 (or in bf16).  f5_sample_status synchronises the stream;
+// f5_sample_status_async only enqueues the 4-byte copy (flags should be pinned host memory; read it after the caller's own
+// synchronisation / event): no host block per call.
+extern "C" int f5_sample_status_async(f5_engine* e, const f5_sample_args* a, int* flags, void* stream) {
+    F5_REQUIRE(e && a && flags && a->workspace && a->workspace_bytes >= 4, "null argument");
+    F5_HIP_CHECK(hipMemcpyAsync(flags, (const char*)a->workspace, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+// 1 when f5_sample with these arguments runs the LN fold (engine option "ln_fold", sizes, precision, branch count of cfg_strength) --
+// the only configuration that can set bit 0 of the status word; host-side, no GPU work.  f5_dit_forward: pass steps = 2, method = F5_EULER.
+extern "C" int f5_engine_ln_fold_active(f5_engine* e, const f5_sample_args* a, int* active) {
+    F5_REQUIRE(e && a && active, "null argument");
+    F5_REQUIRE(a->B >= 1 && a->N >= 1 && a->nt >= 1 && a->steps >= 1 && a->method >= F5_EULER && a->method <= F5_RK4, "bad sizes");
+    const Ctx c = make_ctx(e, a, nullptr);
+    const int st = ln_fold_state(c);
+    if (st < 0) return 2;
+    *active = st;
+    return 0;
+}
 extern "C" int f5_sample_status(f5_engine* e, const f5_sample_args* a, int* flags, void* stream) {
-    F5_REQUIRE(e && a && flags && a->workspace, "null argument");
-    const Workspace w = plan_workspace(e, a->B, a->N, a->nt, a->steps, a->method);
-    F5_REQUIRE(a->workspace_bytes >= w.total, "workspace too small");
-    F5_HIP_CHECK(hipMemcpyAsync(flags, (const char*)a->workspace + w.status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    RC(f5_sample_status_async(e, a, flags, stream));
     F5_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
@@ -1428,14 +1461,21 @@ static struct {
     const float* next_scale = nullptr;       // producer: f5_op_gemm_resid_gate
     op16_t* x16 = nullptr;
     float* stats_out = nullptr;
+    const float* row_shift = nullptr;
+    float* ln_mean_out = nullptr;            // f5_op_ln_modulate: the row means (the first folded operand's shift)
     const float* rowf = nullptr;             // consumer: f5_op_gemm (epi 2), f5_op_qkv_rope
     const float* c1 = nullptr;
     const float* c2 = nullptr;
 } g_op_fold;
-extern "C" int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float* stats_out) {
+extern "C" int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float* stats_out, const float* row_shift) {
     g_op_fold.next_scale = next_scale;
     g_op_fold.x16 = (op16_t*)x16_out;
     g_op_fold.stats_out = stats_out;
+    g_op_fold.row_shift = row_shift;
+    return 0;
+}
+extern "C" int f5_debug_set_op_ln_mean_out(float* mean_out) {
+    g_op_fold.ln_mean_out = mean_out;
     return 0;
 }
 static int* g_op_fold_overflow = nullptr;
@@ -1454,8 +1494,8 @@ static void op_fold_consumer(F5GemmArgs& g) {
     g.fold_c1 = g_op_fold.c1;
     g.fold_c2 = g_op_fold.c2;
 }
-extern "C" int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, void* stream) {
-    return g_ops.fold_rows(stats, M, nslice, M, 1e-6f, rowf, (hipStream_t)stream);
+extern "C" int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, float* row_shift, void* stream) {
+    return g_ops.fold_rows(stats, M, nslice, M, 1e-6f, rowf, row_shift, (hipStream_t)stream);
 }
 extern "C" int f5_op_fold_consts(const void* w_hi, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride,
                                  int nvec, float* c1, float* c2, size_t out_stride, int N, int K, void* stream) {
@@ -1646,7 +1686,7 @@ extern "C" int f5_op_mfma_peak(const void* operands, int blocks, int iters, floa
 
 extern "C" int f5_op_ln_modulate(const float* x, const float* scale, const float* shift, void* out_hi, void* out_lo, int rows,
                                  int dim, void* stream) {
-    return g_ops.ln_modulate(x, scale, shift, (op16_t*)out_hi, (op16_t*)out_lo, rows, dim, 1e-6f, (hipStream_t)stream);
+    return g_ops.ln_modulate(x, scale, shift, (op16_t*)out_hi, (op16_t*)out_lo, rows, dim, 1e-6f, (hipStream_t)stream, g_op_fold.ln_mean_out);
 }
 
 extern "C" int f5_op_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
@@ -1761,6 +1801,7 @@ extern "C" int f5_op_gemm_resid_gate(const void* a_hi, const void* a_lo, const v
         g.x16_out = g_op_fold.x16;
         g.ldx16 = N;
         g.x16_scale = g_op_fold.next_scale;
+        g.x16_shift = g_op_fold.row_shift;
         g.stats_out = g_op_fold.stats_out;
         g.stats_ld = M;
         g.x16_overflow = g_op_fold_overflow;

@@ -62,20 +62,26 @@ struct F5GemmArgs {
     op16_t* ln_out[2];        // hi, lo (lo may be null): [M][N]
     float ln_eps;
     // ---- LN-modulate folded into the GEMMs around it (round 4; 256x256 and role-split 128x256 kernels, one-pass operand modes):
-    //   (LN(x) (1 + s) + b) W^T + bias  =  rstd ((x (1 + s)) W^T) - rstd mu c1 + c2,    c1 = W (1 + s),  c2 = W b + bias
-    // PRODUCER (EPI_RESID_GATE): besides x it writes x (1 + s) in the 16-bit operand type (the next GEMM's A operand; s = the scale of
-    // the LN that follows, x16_scale) and, per row and 64-column slice, the partial sums (sum x, sum x^2) of the new x.
-    // f5_launch_fold_rows turns the partial sums into the row factors (rstd, rstd mu).  CONSUMER (EPI_QKV_ROPE with transposed q / k
-    // tiles, EPI_GELU_TANH): A = that operand, W unchanged, and the epilogue applies the row factors before everything else; `bias`
-    // is ignored (it is inside fold_c2, f5_launch_fold_consts).
+    //   (LN(x) (1 + s) + b) W^T + bias  =  rstd (((x - m) (1 + s)) W^T) - rstd (mu - m) c1 + c2,    c1 = W (1 + s),  c2 = W b + bias
+    // for ANY per-row shift m (round 5).  LayerNorm removes the row mean mu; the 16-bit operand must not carry it: its rounding error
+    // is relative to |x - m|, the exact path's to |x - mu|, so m = the row's mean at the PREVIOUS LayerNorm (x16_shift: written by
+    // the LN kernel in front of block 0 and kept up to date by f5_launch_fold_rows) keeps the folded operand as accurate as the
+    // unfolded one however large the mean is, as long as one residual update moves it by less than a few sigma.
+    // PRODUCER (EPI_RESID_GATE): besides x it writes (x - m)(1 + s) in the 16-bit operand type (the next GEMM's A operand; s = the
+    // scale of the LN that follows, x16_scale) and, per row and 64-column slice, (sum d, sum (d - slice mean)^2) of d = x - m.
+    // f5_launch_fold_rows merges the slices (Chan's pairwise update: no E[d^2] - E[d]^2 cancellation) into the row factors
+    // (rstd, rstd (mu - m)) and stores the new mean.  CONSUMER (EPI_QKV_ROPE with transposed q / k tiles, EPI_GELU_TANH): A = that
+    // operand, W unchanged, and the epilogue applies the row factors before everything else; `bias` is ignored (it is inside
+    // fold_c2, f5_launch_fold_consts).
     op16_t* x16_out;          // [M][ldx16] or null
     int ldx16;
     const float* x16_scale;   // [N]: s (the kernel adds the 1)
-    float* stats_out;         // [N / 64][stats_ld][2] (sum, sum of squares), slice-major, or null; x16_out and stats_out: both or neither
+    const float* x16_shift;   // [M]: m, or null = 0
+    float* stats_out;         // [N / 64][stats_ld][2] (sum d, centred sum of squares), slice-major, or null; x16_out and stats_out: both or neither
     int stats_ld;             // rows per slice of stats_out (>= M)
     int* x16_overflow;        // or null: bit 0 is set when a value of x (1 + s) does not fit the operand type (fp16 build: |v| > 65 504 or
                               // not finite -- the un-normalised residual stream is the one operand producer without a natural bound)
-    const float* fold_rowf;   // [M][2] (rstd, rstd * mean) or null = plain GEMM
+    const float* fold_rowf;   // [M][2] (rstd, rstd * (mean - m)) or null = plain GEMM
     const float* fold_c1;     // [N], 16-byte aligned
     const float* fold_c2;     // [N], 16-byte aligned
     // ---- MX-fp8 path (f5_launch_gemm_f8): e4m3 operands with one E8M0 scale per 32 consecutive K elements
@@ -93,8 +99,10 @@ int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
 // true when f5_launch_gemm runs this launch on a kernel with the LDS-staged epilogues (256x256 / role-split 128x256): the only ones
 // that implement the x16_out / stats_out / fold_* fields (f5_launch_gemm fails loudly for the others)
 bool f5_gemm_runs_staged(const F5GemmArgs& a, int epi);
-// row factors of the fold: rowf[m] = (rstd, rstd * mean) of row m from its nslice partial sums (stats[slice][ld][2]; width = 64 nslice)
-int f5_launch_fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, hipStream_t stream);
+// row factors of the fold: rowf[r] = (rstd, rstd * (mean - m)) of row r from its nslice slice statistics (stats[slice][ld][2] =
+// (sum d, centred sum of squares) of d = x - m; width = 64 nslice).  row_shift (optional, [M]): on entry m (what the producer
+// subtracted; null = 0), on exit the row's mean -- the shift of the next folded operand.
+int f5_launch_fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, float* row_shift, hipStream_t stream);
 // Constants of the fold for `nvec` modulation vectors at once: c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k]
 // shift_v[k] + bias[n], fp32 sums over the operand-typed weights the GEMM multiplies by.  scale_v = scale + v * vec_stride (floats),
 // likewise shift_v; c1 / c2 rows are out_stride floats apart.  K % 256 == 0, K <= 2048.

@@ -40,6 +40,17 @@
 
 namespace F5_NS {
 
+#if F5_PROBE
+// measurement build: a timeline of every workgroup (100 MHz wall clock): [0] start, [1] prologue staged, [2] K loop done (wave 0),
+// [3] epilogue done wave 0, [4] epilogue done wave 4, [5] HW_ID, [6] XCC_ID, [7] K loop done (wave 4); read by f5_probe_read_ts
+#define F5_PROBE_MAXWG 4096
+__device__ unsigned long long f5_probe_ts[F5_PROBE_MAXWG * 8];
+#define F5_PROBE_TS(idx_, wave_)                                                                              \
+    if (lane == 0 && wave == (wave_) && bid < F5_PROBE_MAXWG) f5_probe_ts[bid * 8 + (idx_)] = wall_clock64();
+#else
+#define F5_PROBE_TS(idx_, wave_)
+#endif
+
 #define G256_BARRIER()                         \
     {                                          \
         __builtin_amdgcn_sched_barrier(0);     \
@@ -62,6 +73,24 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     const int wm = wave >> 2, wn = wave & 3;
     const int kt = p.K / BK;
     const int T = kt * p.nseg;
+#if F5_PROBE
+    F5_PROBE_TS(0, 0);
+    if (lane == 0 && wave == 0 && bid < F5_PROBE_MAXWG) {
+        f5_probe_ts[bid * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_REG_HW_ID
+        f5_probe_ts[bid * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) & 0xF;   // HW_REG_XCC_ID (| tn << 8 | tm << 20 below)
+    }
+    {   // measurement build: phase-shift part of the first round of workgroups (do the CUs' synchronised epilogue bursts cost time?)
+        const int sg = (p.debug_flags >> 20) & 0xff;       // delay step, units of 0.5 us (100 MHz wall clock)
+        const int mode = (p.debug_flags >> 28) & 3;        // who waits: 0 = every other CU slot of an XCD, 1 = every other XCD, 2 = four phases
+        if (sg != 0 && bid < 256) {
+            const int ph = mode == 0 ? ((bid >> 3) & 1) : mode == 1 ? (bid & 1) : (((bid >> 3) & 1) + 2 * (bid & 1));
+            if (ph != 0) {
+                const unsigned long long t0 = wall_clock64(), dt = (unsigned long long)ph * sg * 50ull;
+                while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(20);
+            }
+        }
+    }
+#endif
 
     // ---- workgroup id -> tile.  Whole tiles: each XCD (private L2; workgroup b runs on XCD b % 8) walks a contiguous chunk of
     // the tile list; the list is n-fastest, or BAND-major (bands of nband column tiles walked row by row) so that a chunk's W
@@ -85,6 +114,9 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         tn = bid - nfull;
     }
     const int m0 = tm * 256, n0 = tn * 256;
+#if F5_PROBE
+    if (lane == 0 && wave == 0 && bid < F5_PROBE_MAXWG) f5_probe_ts[bid * 8 + 6] |= ((unsigned long long)tn << 8) | ((unsigned long long)tm << 20);
+#endif
     const int rows_wave = p.M - m0 - wm * 128;        // valid rows of this wave's 128-row half (wave-uniform)
     const bool act_lo = rows_wave > 0;                // phases 1, 2: rows 0-63 of the half
     const bool act_hi = rows_wave > 64;               // phases 3, 4: rows 64-127
@@ -175,6 +207,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     G256_BARRIER();
+    F5_PROBE_TS(1, 0);
     if (wm == 1) G256_BARRIER();       // group 1 starts one interval late (paired with group 0's first LOAD barrier)
 
     op16x8 af[2][4], bfr[2][4];
@@ -258,15 +291,21 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             G256_KSTEP(0, tt, true);
             if (tt + 1 < T) G256_KSTEP(1, tt + 1, true);
         }
+        F5_PROBE_TS(2, 0);
+        F5_PROBE_TS(7, 4);
         if (wm == 0) G256_BARRIER();                    // group 0 waits for group 1's last MATRIX segment: the ring is dead
         if ((p.debug_flags & 1) || !act_lo) return;     // flag 1 = timing experiment: main loop only
         if (fold) {                                     // LN-modulate folded into this GEMM (F5GemmArgs::fold_*; workgroup-uniform)
             if (QT) staged_epilogue_tr_rope<4, 2, true>(p, acc, stage, row0, col0, lane, fl, &fpre);
             else staged_epilogue_tr<EPI, 4, 2, true>(p, acc, stage, row0, col0, lane, fl, &fpre);
+            F5_PROBE_TS(3, 0);
+            F5_PROBE_TS(4, 4);
             return;
         }
         if (QT) staged_epilogue_tr_rope<4, 2>(p, acc, stage, row0, col0, lane);
         else staged_epilogue_tr<EPI, 4, 2>(p, acc, stage, row0, col0, lane);
+        F5_PROBE_TS(3, 0);
+        F5_PROBE_TS(4, 4);
         return;
     }
     if (QT && fold) fold_prefetch_v<4>(p, fpre, row0, col0, lane);
@@ -274,6 +313,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         G256_KSTEP(0, tt, false);
         if (tt + 1 < T) G256_KSTEP(1, tt + 1, false);
     }
+    F5_PROBE_TS(2, 0);
+    F5_PROBE_TS(7, 4);
     if (wm == 0) G256_BARRIER();
     if (p.debug_flags & 1) {
 #pragma unroll
@@ -293,6 +334,8 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     } else {
         gemm_epilogue<EPI, 4, 2>(p, acc, m0, n0, wm, wn, lane);
     }
+    F5_PROBE_TS(3, 0);
+    F5_PROBE_TS(4, 4);
 #undef G256_KSTEP
 #undef G256_MATRIX
 #undef G256_MM
@@ -345,3 +388,15 @@ int f5_launch_gemm256(const F5GemmArgs& a, int epi, hipStream_t stream) {
     }
 }
 }  // namespace F5_NS
+
+#if F5_PROBE && F5_F16
+extern "C" int f5_probe_read_ts(unsigned long long* host, int words, int clear) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(f5hf::f5_probe_ts), (size_t)words * 8) != hipSuccess) return 1;
+    if (clear) {
+        void* d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(f5hf::f5_probe_ts)) != hipSuccess || hipMemset(d, 0, sizeof(unsigned long long) * F5_PROBE_MAXWG * 8) != hipSuccess)
+            return 2;
+    }
+    return 0;
+}
+#endif

@@ -8,6 +8,20 @@ namespace F5_NS {
 
 #define BK 64
 
+// Measurement build only (F5_PROBE=1 bash build.sh -> libf5tts_hip_probe.so, tools/r5_epilogue_probe.py): ablation switches of the
+// staged epilogues, read from F5GemmArgs::debug_flags.  In the product build they are compile-time false and leave no code.
+#ifndef F5_PROBE
+#define F5_PROBE 0
+#endif
+#define F5_PROBE_NOSTORE(p_) (F5_PROBE && ((p_).debug_flags & 0x10000))   // the epilogue runs, its global stores do not (q / k / FF1 / x)
+#define F5_PROBE_NOVSTORE(p_) (F5_PROBE && ((p_).debug_flags & 0x8000))   // the same for the transposed V tiles of the QKV projection
+#define F5_PROBE_NOMATH(p_) (F5_PROBE && ((p_).debug_flags & 0x20000))    // no GELU / rotation arithmetic (and no table loads)
+#define F5_PROBE_NT(p_) (F5_PROBE && ((p_).debug_flags & 0x40000))        // residual stream read / written non-temporally
+template <typename T>
+__device__ __forceinline__ void f5_probe_sink(const T& v) {
+    asm volatile("" ::"v"(v));
+}
+
 __device__ __forceinline__ int swz_off(int row, int chunk) {
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
@@ -363,7 +377,9 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
                         const u32x4 val = *reinterpret_cast<const u32x4*>(&reg[d * TLD + t0]);
                         const int head = head0 + (d >> 6), dd = d & 63;
                         u16* dst = dstbase + ((size_t)(b * p.heads + head) * 64 + dd) * p.npad + n;
-                        if (n + 8 <= p.seq_len && grow + 8 <= p.M) {
+                        if (F5_PROBE_NOVSTORE(p)) {
+                            f5_probe_sink(val);
+                        } else if (n + 8 <= p.seq_len && grow + 8 <= p.M) {
                             *reinterpret_cast<u32x4*>(dst) = val;       // may be only 2-byte aligned: legal on gfx950
                         } else {
 #pragma unroll
@@ -444,7 +460,7 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
 #pragma unroll
                 for (int ri = 0; ri < 4; ++ri) {
                     v[ri] = FOLD ? rr[0] * acc[mb][nb][rg * 4 + ri] + (c2q[ri] - rr[1] * c1q[ri]) : acc[mb][nb][rg * 4 + ri] + b4[nb][rg][ri];
-                    if (EPI == EPI_GELU_TANH) v[ri] = f5_gelu_tanh(v[ri]);
+                    if (EPI == EPI_GELU_TANH && !F5_PROBE_NOMATH(p)) v[ri] = f5_gelu_tanh(v[ri]);
                     if (EPI == EPI_GELU_ERF_BF16) v[ri] = f5_gelu_erf(v[ri]);
                 }
                 const int so = lcol * LD + nb * 32 + rg * 8 + hi * 4;
@@ -456,7 +472,9 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
         for (int i = 0; i < 32 / RPI; ++i) {
             const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
             const int grow = rowblk + lrow;
-            if (grow < p.M) {
+            if (F5_PROBE_NOSTORE(p)) {
+                f5_probe_sink(*reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]));
+            } else if (grow < p.M) {
                 const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
                 *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
                 if (two) *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
@@ -511,10 +529,15 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
             for (int rg = 0; rg < 4; ++rg) {
                 const int c = colbase + nb * 32 + rg * 8 + hi * 4;
                 const int j0 = (c & 63) >> 1;
-                c0[rg] = ct[(size_t)j0 * p.rope_ldt + n];
-                c1[rg] = ct[(size_t)(j0 + 1) * p.rope_ldt + n];
-                s0[rg] = st[(size_t)j0 * p.rope_ldt + n];
-                s1[rg] = st[(size_t)(j0 + 1) * p.rope_ldt + n];
+                if (F5_PROBE_NOMATH(p)) {
+                    c0[rg] = c1[rg] = 1.0f;
+                    s0[rg] = s1[rg] = 0.0f;
+                } else {
+                    c0[rg] = ct[(size_t)j0 * p.rope_ldt + n];
+                    c1[rg] = ct[(size_t)(j0 + 1) * p.rope_ldt + n];
+                    s0[rg] = st[(size_t)j0 * p.rope_ldt + n];
+                    s1[rg] = st[(size_t)(j0 + 1) * p.rope_ldt + n];
+                }
                 if (FOLD) {
                     const f32x4 c1q = *reinterpret_cast<const f32x4*>(&fl[c - colbase]), c2q = *reinterpret_cast<const f32x4*>(&fl[W + c - colbase]);
 #pragma unroll
@@ -550,7 +573,9 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
         for (int i = 0; i < 32 / RPI; ++i) {
             const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
             const int grow = rowblk + lrow;
-            if (grow < p.M) {
+            if (F5_PROBE_NOSTORE(p)) {
+                f5_probe_sink(*reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]));
+            } else if (grow < p.M) {
                 const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
                 *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
                 if (two) *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
@@ -587,6 +612,7 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
     for (int mb = 0; mb < MBW; ++mb) {
         const int rowblk = row0 + mb * 32;
         f32x4 xr[NI];
+        float xsh[NI];                     // LN fold: the row shift m of the folded operand (F5GemmArgs::x16_shift)
         uint32_t kraw[NI];                 // the keep byte as loaded: converting it inside this loop put a `s_waitcnt vmcnt(0)` behind
                                            // every byte load, i.e. behind every x-row load -- the rows of a lane were fetched one
                                            // memory round trip after the other
@@ -594,9 +620,14 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
         for (int i = 0; i < NI; ++i) {
             const int grow = rowblk + i * RPI + lane / CPR;
             const bool ok = grow < p.M;
+            if (F5_PROBE_NT(p))
+                xr[i] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4))
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            else
             xr[i] = ok ? *reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4)
                        : f32x4{0.f, 0.f, 0.f, 0.f};
             kraw[i] = (ok && p.rowkeep != nullptr) ? (uint32_t)p.rowkeep[grow] : 1u;
+            xsh[i] = (CPR == 16 && ok && p.x16_out != nullptr && p.x16_shift != nullptr) ? p.x16_shift[grow] : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -608,7 +639,7 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
         // inside the `grow < M` blocks below: the compiler's `s_waitcnt vmcnt(0)` for them sat in every block and also waited for
         // the store of the previous block -- the eight 16-byte stores of a lane left one memory round trip apart
 #pragma unroll
-        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(xr[i]), "+v"(kraw[i]));
+        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(xr[i]), "+v"(kraw[i]), "+v"(xsh[i]));
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -619,30 +650,42 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = xr[i][e] + g4[e] * (kraw[i] != 0u ? v[e] : 0.0f);   // a select, like gemm_epilogue: a non-finite
                                                                                                   // accumulator of a masked row must not reach x
+            if (F5_PROBE_NOSTORE(p)) f5_probe_sink(o);
+            else if (F5_PROBE_NT(p)) {
+                if (grow < p.M) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4));
+            } else
             if (grow < p.M) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4) = o;
             if (CPR == 16 && p.x16_out != nullptr) {          // (64-column wave tiles only: the launcher refuses the others)
-                // LN fold (F5GemmArgs): x (1 + s) in the operand type is the next GEMM's A operand; the row's partial sums over this
-                // wave's 64 columns come from a 16-lane DPP reduction (the 16 lanes of a DPP row hold one row segment)
-                float ps = grow < p.M ? (o[0] + o[1]) + (o[2] + o[3]) : 0.0f;
-                float pq = grow < p.M ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.0f;
+                // LN fold (F5GemmArgs): (x - m)(1 + s) in the operand type is the next GEMM's A operand, m = the row's mean at the
+                // previous LayerNorm.  Slice statistics of d = x - m over this wave's 64 columns: the sum by a 16-lane DPP rotation
+                // all-reduce (the 16 lanes of a DPP row hold one row segment; every lane ends up with the total), then the sum of
+                // squares about the SLICE mean the same way -- f5_fold_rows_kernel merges the slices without cancellation
+                const bool rok = grow < p.M;
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = rok ? o[e] - xsh[i] : 0.0f;
+                float ps = (d[0] + d[1]) + (d[2] + d[3]);
                 ps += f5_dpp_row<0x128>(ps);
-                pq += f5_dpp_row<0x128>(pq);
                 ps += f5_dpp_row<0x124>(ps);
-                pq += f5_dpp_row<0x124>(pq);
                 ps += f5_dpp_row<0x122>(ps);
-                pq += f5_dpp_row<0x122>(pq);
                 ps += f5_dpp_row<0x121>(ps);
+                const float ms = ps * (1.0f / 64.0f);
+                const float e0 = d[0] - ms, e1 = d[1] - ms, e2 = d[2] - ms, e3 = d[3] - ms;
+                float pq = rok ? (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3) : 0.0f;
+                pq += f5_dpp_row<0x128>(pq);
+                pq += f5_dpp_row<0x124>(pq);
+                pq += f5_dpp_row<0x122>(pq);
                 pq += f5_dpp_row<0x121>(pq);
 #if F5_F16
                 if (p.x16_overflow != nullptr) {             // fail loudly: f5_pack2 saturates, the engine reports the flag (f5_sample_status)
-                    const bool ov = grow < p.M && !(fmaxf(fmaxf(fabsf(o[0] * sc4[0]), fabsf(o[1] * sc4[1])),
-                                                          fmaxf(fabsf(o[2] * sc4[2]), fabsf(o[3] * sc4[3]))) <= 65504.0f);
+                    const bool ov = rok && !(fmaxf(fmaxf(fabsf(d[0] * sc4[0]), fabsf(d[1] * sc4[1])),
+                                                   fmaxf(fabsf(d[2] * sc4[2]), fabsf(d[3] * sc4[3]))) <= 65504.0f);
                     if (__any(ov) && lane == 0) atomicOr(p.x16_overflow, 1);
                 }
 #endif
-                if (grow < p.M) {
+                if (rok) {
                     *reinterpret_cast<u32x2*>(p.x16_out + (size_t)grow * p.ldx16 + colbase + chunk * 4) =
-                        u32x2{f5_pack2(o[0] * sc4[0], o[1] * sc4[1]), f5_pack2(o[2] * sc4[2], o[3] * sc4[3])};
+                        u32x2{f5_pack2(d[0] * sc4[0], d[1] * sc4[1]), f5_pack2(d[2] * sc4[2], d[3] * sc4[3])};
                     if (chunk == 0)
                         *reinterpret_cast<f5_f32x2*>(p.stats_out + ((size_t)(colbase >> 6) * p.stats_ld + grow) * 2) = f5_f32x2{ps, pq};
                 }

@@ -57,8 +57,9 @@ struct Ops {
     bool gemm_runs_staged(const F5GemmArgs& a, int epi) const {
         return h ? f5hf::f5_gemm_runs_staged(reinterpret_cast<const f5hf::F5GemmArgs&>(a), epi) : f5bf::f5_gemm_runs_staged(a, epi);
     }
-    int fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, hipStream_t s) const {
-        return h ? f5hf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, s) : f5bf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, s);
+    int fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, float* row_shift, hipStream_t s) const {
+        return h ? f5hf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, row_shift, s)
+                 : f5bf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, row_shift, s);
     }
     // batch: {count, w_stride, bias_stride, mod_stride, out_blk_stride} (gemm.hpp F5FoldBatch), count == 1 = a single problem
     int fold_consts(const op16_t* w, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec, float* c1,
@@ -82,9 +83,9 @@ struct Ops {
         return h ? f5hf::f5_launch_ode_stage(reinterpret_cast<const f5hf::F5OdeArgs&>(a), s) : f5bf::f5_launch_ode_stage(a, s);
     }
     int ln_modulate(const float* x, const float* scale, const float* shift, op16_t* hi, op16_t* lo, int rows, int dim, float eps,
-                    hipStream_t s) const {
-        return h ? f5hf::f5_launch_ln_modulate(x, scale, shift, H(hi), H(lo), rows, dim, eps, s)
-                 : f5bf::f5_launch_ln_modulate(x, scale, shift, hi, lo, rows, dim, eps, s);
+                    hipStream_t s, float* mean_out = nullptr) const {
+        return h ? f5hf::f5_launch_ln_modulate(x, scale, shift, H(hi), H(lo), rows, dim, eps, s, mean_out)
+                 : f5bf::f5_launch_ln_modulate(x, scale, shift, hi, lo, rows, dim, eps, s, mean_out);
     }
     int dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b, op16_t* hi, op16_t* lo,
                   int nbatch, int seq_len, int dim, float eps, hipStream_t s) const {

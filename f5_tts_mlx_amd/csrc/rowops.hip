@@ -9,12 +9,14 @@ namespace F5_NS {
 // =================================================================================================
 // LayerNorm (no affine) + adaLN modulation: one wave per row, NV float4 per lane (dim = NV*256)
 // =================================================================================================
-template <int NV>
+// WITH_MEAN: also writes the row means (LN fold: the shift of the first folded operand of a forward, gemm.hpp x16_shift).  A separate
+// instantiation, so that the plain kernel keeps the code it shares bit for bit with the LN tail fused into gemm.hip (lnrow.hpp).
+template <int NV, bool WITH_MEAN>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, op16_t* __restrict__ out_hi,
-                                                          op16_t* __restrict__ out_lo, int rows, float eps) {
+                                                          op16_t* __restrict__ out_lo, int rows, float eps, float* __restrict__ mean_out) {
     constexpr int DIM = NV * 256;
-    asm volatile("" ::"s"(x), "s"(scale), "s"(shift), "s"(out_hi), "s"(out_lo), "s"(rows), "s"(eps));    // one scalar-load clause
+    asm volatile("" ::"s"(x), "s"(scale), "s"(shift), "s"(out_hi), "s"(out_lo), "s"(rows), "s"(eps), "s"(mean_out));    // one scalar-load clause
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -22,19 +24,32 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     f32x4 v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+    if (WITH_MEAN) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mean = f5_wave_sum(sum) * (1.0f / DIM);
+        if (lane == 0) mean_out[row] = mean;
+    }
     f5_ln_modulate_row<NV>(v, scale, shift, out_hi, out_lo, (size_t)row, lane, eps);
 }
 
 int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, op16_t* out_hi, op16_t* out_lo,
-                          int rows, int dim, float eps, hipStream_t s) {
+                          int rows, int dim, float eps, hipStream_t s, float* mean_out) {
     F5_REQUIRE(dim % 256 == 0 && dim >= 256 && dim <= 1024, "ln_modulate: dim must be 256/512/768/1024 (got %d)", dim);
     const dim3 grid(f5_cdiv(rows, 4)), block(256);
+#define LNM_LAUNCH(NV_)                                                                                                               \
+    if (mean_out != nullptr)                                                                                                          \
+        hipLaunchKernelGGL((ln_modulate_kernel<NV_, true>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps, mean_out); \
+    else                                                                                                                              \
+        hipLaunchKernelGGL((ln_modulate_kernel<NV_, false>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps, mean_out);
     switch (dim / 256) {
-        case 1: hipLaunchKernelGGL((ln_modulate_kernel<1>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps); break;
-        case 2: hipLaunchKernelGGL((ln_modulate_kernel<2>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps); break;
-        case 3: hipLaunchKernelGGL((ln_modulate_kernel<3>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps); break;
-        default: hipLaunchKernelGGL((ln_modulate_kernel<4>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps); break;
+        case 1: LNM_LAUNCH(1); break;
+        case 2: LNM_LAUNCH(2); break;
+        case 3: LNM_LAUNCH(3); break;
+        default: LNM_LAUNCH(4); break;
     }
+#undef LNM_LAUNCH
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -18,8 +18,9 @@
 namespace F5_NS {
 
 // y = LN(x) * (1 + scale) + shift, LN without affine, eps (dit.py:270,289,321). One wave per row.
+// mean_out (optional, [rows]): the row means -- the shift of the first folded operand that follows (gemm.hpp x16_shift)
 int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, op16_t* out_hi, op16_t* out_lo,
-                          int rows, int dim, float eps, hipStream_t s);
+                          int rows, int dim, float eps, hipStream_t s, float* mean_out = nullptr);
 
 // ConvNeXtV2 front half (convnext_v2.py:46-48): depthwise Conv1d(k=7,pad=3)+bias -> LayerNorm(affine).
 int f5_launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,

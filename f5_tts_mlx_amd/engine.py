@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 from pathlib import Path
 from typing import Dict, Optional, Sequence
 
@@ -150,10 +151,32 @@ def _aligned_bytes(nbytes: int, device: torch.device) -> torch.Tensor:
     return t[off:off + int(nbytes)]
 
 
-class Engine:
-    """One engine handle per device.  Not re-entrant (same contract as the C ABI)."""
+class OperandRangeWarning(RuntimeWarning):
+    """The folded LayerNorm operand left the fp16 range in a call; the engine fell back to the unfolded path."""
 
-    def __init__(self, cfg: DiTConfig, precision: str = "bf16", device: str | torch.device = "cuda:0"):
+
+RANGE_CHECKS = ("auto", "sync", "async", "off")
+
+
+class Engine:
+    """One engine handle per device.  Not re-entrant (same contract as the C ABI).
+
+    range_check -- what happens to the status word of a call (include/f5tts_hip.h f5_sample_status; only the f16 mode with the LN fold
+    active can set it: the folded operand (x - m)(1 + scale) is the one fp16 MFMA operand without a natural bound):
+      "sync"   read it after every call (one stream synchronisation); on overflow switch this engine's ln_fold to 0, warn
+               (OperandRangeWarning) and RE-RUN the call unfolded: the caller always gets a result that is not saturated
+      "async"  never block: a 4-byte copy into pinned memory rides behind the call and is looked at when the NEXT call starts (or in
+               synchronize() / check_status()); on overflow warn and switch ln_fold to 0 for the calls that follow -- the flagged call's
+               own output was saturated (finite, clamped at +-65 504) and the warning says so
+      "auto"   (default) "sync" until `range_probation` (3) fold-active calls in a row came back clean, "async" from then on: a
+               checkpoint whose activations do not fit is caught on its first calls with a correct result, the steady state of a
+               service does not block its host thread (one rank of an 8-GPU job no longer synchronises per call)
+      "off"    ignore the word
+    """
+
+    def __init__(self, cfg: DiTConfig, precision: str = "bf16", device: str | torch.device = "cuda:0", range_check: str = "auto"):
+        if range_check not in RANGE_CHECKS:
+            raise ValueError(f"range_check must be one of {RANGE_CHECKS}")
         if precision not in PRECISIONS:
             raise ValueError(f"unknown precision {precision!r}; expected one of {sorted(PRECISIONS)}")
         self.lib = load_library()
@@ -176,6 +199,15 @@ class Engine:
         # hipGraph capture is illegal on the legacy default stream: the engine owns a side stream and
         # orders it against the caller's current stream with events (wait_stream)
         self._stream = torch.cuda.Stream(device=self.device)
+        self.range_check = range_check
+        self.range_probation = 3
+        self.range_events = 0                  # calls whose folded operand overflowed (the engine fell back to ln_fold = 0)
+        self._clean_fold_calls = 0
+        # pinned ring of status words: one slot per call whose check is still pending ("async"); a caller that runs 16 calls ahead of
+        # the GPU waits for the oldest one
+        self._status_host = torch.zeros(16, dtype=torch.int32).pin_memory() if precision == "f16" else None
+        self._status_pending: list = []        # [(event, slot, what)] oldest first
+        self._status_slot = 0
 
     def _run_on_side_stream(self, fn):
         cur = torch.cuda.current_stream(self.device)
@@ -281,6 +313,7 @@ class Engine:
         if method not in METHODS:
             raise ValueError(f"Unknown method: {method}")
         self._check_inputs(text, cond, lens, durations)
+        self.check_status(block=False)                 # a pending check of the previous call: resolved here if it has arrived
         B, N, mel = cond.shape
         steps = int(len(t))
         assert y0.shape == cond.shape and y0.dtype == torch.float32 and y0.is_contiguous() and y0.is_cuda
@@ -293,32 +326,89 @@ class Engine:
             trajectory = torch.empty((steps, B, N, mel), dtype=torch.float32, device=self.device)
         a, keep = self._args(text, cond, lens, durations, y0, t, steps, method, cfg_strength, use_mask, use_graph, out,
                              trajectory if return_trajectory else None, ws)
-        self._run_on_side_stream(lambda st: check(self.lib.f5_sample(self._h, C.byref(a), st), "f5_sample"))
-        self._raise_on_operand_overflow(a, B, N, cfg_strength)
+        launch = lambda: self._run_on_side_stream(lambda st: check(self.lib.f5_sample(self._h, C.byref(a), st), "f5_sample"))  # noqa: E731
+        launch()
+        self._after_call(a, launch, f"sample(B={B}, N={N}, {method}, {steps} points)")
         del keep
         return out, (trajectory if return_trajectory else None)
 
-    def _raise_on_operand_overflow(self, a, B: int, N: int, cfg_strength: float) -> None:
-        """LN fold (engine option "ln_fold", active from 22 000 rows in the f16 mode): the GEMM operand x (1 + scale) is the
-        UN-normalised residual stream in fp16.  Every other operand producer has a natural bound; this one is checked: the kernels
-        flag a value beyond +-65 504 and the call fails here instead of returning a saturated result (costs one stream
-        synchronisation, only where the fold can run)."""
-        if self.precision != "f16":
+    # ---- status word (LN-fold operand range) --------------------------------------------------
+    def _fall_back(self, what: str, rerun: bool) -> None:
+        self.range_events += 1
+        self._clean_fold_calls = 0
+        self.set_option("ln_fold", 0)
+        tail = ("re-running it unfolded" if rerun else
+                "THAT call's output is saturated (finite, clamped at +-65504) -- repeat it, or construct the engine with range_check='sync'")
+        warnings.warn(f"ln_fold: the residual stream times (1 + scale) left the fp16 range (|v| > 65504) in {what}; this engine now runs "
+                      f"with ln_fold = 0 (or use precision 'bf16' / 'bf16x3'); {tail}.", OperandRangeWarning, stacklevel=4)
+
+    def check_status(self, block: bool = True) -> int:
+        """Resolve the pending status checks ("async" mode), oldest first; with block=False only those whose copy has arrived.
+        Returns the OR of the words looked at.  Called at the start of every call and by synchronize()."""
+        seen = 0
+        while self._status_pending:
+            ev, slot, what = self._status_pending[0]
+            if not block and not ev.query():
+                break
+            ev.synchronize()
+            self._status_pending.pop(0)
+            flags = int(self._status_host[slot])
+            seen |= flags
+            if flags & 1:
+                if self.get_option("ln_fold") != 0:            # (calls enqueued before the first warning arrived are flagged too: once)
+                    self._fall_back(what, rerun=False)
+            elif flags & 2:
+                self._clean_fold_calls += 1
+        return seen
+
+    def synchronize(self) -> None:
+        """Wait for everything this engine enqueued and resolve a pending status check."""
+        self._stream.synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
+        self.check_status(block=True)
+
+    def _after_call(self, a, launch, what: str) -> None:
+        """Status handling of one f5_sample / f5_dit_forward call (class docstring).  The library tells whether the fold ran (bit 1)."""
+        if self._status_host is None or self.range_check == "off":
             return
-        opt = self.get_option("ln_fold")
-        rows = (2 if cfg_strength >= 1e-5 else 1) * B * N
-        if opt == 0 or (opt < 0 and rows < 22000):
+        active = C.c_int(0)
+        check(self.lib.f5_engine_ln_fold_active(self._h, C.byref(a), C.byref(active)), "f5_engine_ln_fold_active")
+        if not active.value:                   # (batch 1, ln_fold = 0, ...): nothing can set the word, nothing is read
             return
-        flags = C.c_int(0)
-        self._run_on_side_stream(lambda st: check(self.lib.f5_sample_status(self._h, C.byref(a), C.byref(flags), st), "f5_sample_status"))
-        if flags.value & 1:
-            raise RuntimeError("ln_fold: the residual stream times (1 + scale) left the fp16 range (|v| > 65504); the result is saturated. "
-                               "Set the engine option ln_fold to 0 (Engine.set_option('ln_fold', 0)) or use precision 'bf16' / 'bf16x3'.")
+        mode = self.range_check
+        if mode == "auto":
+            mode = "async" if self._clean_fold_calls >= self.range_probation else "sync"
+
+        if len(self._status_pending) >= self._status_host.numel():
+            ev, slot, w0 = self._status_pending[0]
+            ev.synchronize()
+            self.check_status(block=False)
+        slot = self._status_slot
+        self._status_slot = (slot + 1) % self._status_host.numel()
+        holder = {}
+
+        def enqueue_read(st):
+            check(self.lib.f5_sample_status_async(self._h, C.byref(a), C.c_void_p(self._status_host[slot:].data_ptr()), st), "f5_sample_status_async")
+            holder["ev"] = torch.cuda.Event()
+            holder["ev"].record(torch.cuda.current_stream(self.device))
+
+        self._run_on_side_stream(enqueue_read)
+        if mode == "sync":
+            holder["ev"].synchronize()
+            flags = int(self._status_host[slot])
+            if flags & 1:
+                self._fall_back(what, rerun=True)
+                launch()                                   # ln_fold is 0 now: the status word of this run cannot carry bit 0
+            elif flags & 2:
+                self._clean_fold_calls += 1
+        else:
+            self._status_pending.append((holder["ev"], slot, what))
 
     def dit_forward(self, x: torch.Tensor, text: torch.Tensor, cond: torch.Tensor, lens, durations, t: float,
                     cfg_strength: float = 2.0, use_mask: Optional[bool] = None):
         """One DiT evaluation (cond branch and, when cfg_strength >= 1e-5, null branch)."""
         self._check_inputs(text, cond, lens, durations)
+        self.check_status(block=False)
         B, N, mel = cond.shape
         if use_mask is None:
             use_mask = B > 1
@@ -327,8 +417,9 @@ class Engine:
         null = torch.empty_like(cond) if cfg_strength >= 1e-5 else None
         a, keep = self._args(text, cond, lens, durations, None, np.zeros(2, np.float32), 2, "euler", cfg_strength, use_mask,
                              False, None, None, ws)
-        self._run_on_side_stream(lambda st: check(
+        launch = lambda: self._run_on_side_stream(lambda st: check(   # noqa: E731
             self.lib.f5_dit_forward(self._h, C.byref(a), ptr(x), C.c_float(t), ptr(pred), ptr(null), st), "f5_dit_forward"))
-        self._raise_on_operand_overflow(a, B, N, cfg_strength)
+        launch()
+        self._after_call(a, launch, f"dit_forward(B={B}, N={N})")
         del keep
         return pred, null

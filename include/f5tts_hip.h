@@ -121,11 +121,19 @@ typedef struct f5_sample_args {
 int f5_workspace_bytes(f5_engine* e, int B, int N, int nt, int steps, int method, size_t* bytes);
 int f5_sample(f5_engine* e, const f5_sample_args* args, void* stream);
 
-/* Status word of the last f5_sample / f5_dit_forward on this workspace with these sizes (B, N, nt, steps, method, workspace of `args`):
- * bit 0 = a value of the folded LayerNorm operand x (1 + scale) did not fit fp16 (engine option "ln_fold" active, precision f16): the
- * output is saturated there -- rerun with ln_fold = 0 or in bf16.  Synchronises `stream`.  No reference counterpart (the reference has
- * no reduced-precision operands). */
+/* Status word of the last f5_sample / f5_dit_forward on the workspace of `args`.  It is the FIRST 32-bit word of the workspace for every
+ * shape and solver (a caller may copy it itself).  bit 1 = the LN fold (engine option "ln_fold") ran in that call; bit 0 = a value of the
+ * folded LayerNorm operand (x - m)(1 + scale) did not fit fp16 (precision f16): the output is saturated there -- rerun with ln_fold = 0
+ * or in bf16 (f5_tts_mlx_amd.engine.Engine does that by itself).  f5_sample_status synchronises `stream`; f5_sample_status_async only
+ * enqueues the 4-byte device-to-host copy behind the call (`flags` should be pinned host memory, valid once the caller has
+ * synchronised `stream` or an event recorded after it): no host block per call.  No reference counterpart (the reference has no
+ * reduced-precision operands). */
 int f5_sample_status(f5_engine* e, const f5_sample_args* args, int* flags, void* stream);
+int f5_sample_status_async(f5_engine* e, const f5_sample_args* args, int* flags, void* stream);
+/* *active = 1 when f5_sample with these arguments runs the LN fold (the only configuration that can set bit 0 of the status word): a
+ * host-side question, no GPU work, so a caller only reads the word where it can say something.  For f5_dit_forward pass steps = 2,
+ * method = F5_EULER. */
+int f5_engine_ln_fold_active(f5_engine* e, const f5_sample_args* args, int* active);
 
 /* One DiT forward (dit.py:374-401) for tests/diagnostics: same inputs as f5_sample, evaluates the
  * velocity field at time `t` for state `x` (dev [B][N][mel]); writes pred (and null when
@@ -276,15 +284,20 @@ int f5_debug_set_ln_fusion(int on);         /* 1: LN-modulate fused behind the r
 int f5_debug_set_qkv_transposed(int on);    /* 1 (default): sample() hands the pair-major rotation tables to the QKV projection (256x256 kernel: transposed q / k tiles) */
 int f5_debug_set_q_premul(int on);          /* 1 (default): sample() multiplies q by softmax_scale * log2(e) in the QKV epilogue (single-segment operand modes) */
 /* LN-modulate folded into the GEMMs around it (dit.py:270 / :321 between the residual updates :319 / :323 and the projections;
- * csrc/gemm.hpp fold_*; engine option "ln_fold"):  (LN(x)(1 + s) + b) W^T + bias = rstd ((x (1 + s)) W^T) - rstd mean c1 + c2.
- * Op-level twins: with a producer set, f5_op_gemm_resid_gate also writes x (1 + next_scale) as [M][N] 16-bit operands and the partial
- * row sums [N / 64][M][2] (slice-major); f5_op_fold_rows turns those into the row factors [M][2] = (rstd, rstd * mean), eps 1e-6;
- * with a consumer set, f5_op_gemm (epi 2) and f5_op_qkv_rope take the operands as A and finish the LN in their epilogues (bias
- * ignored: it is inside c2).  Shapes must run on the 256x256 / role-split 128x256 kernels.  NULLs = off. */
-int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float* stats_out);
-int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, void* stream);
+ * csrc/gemm.hpp fold_*; engine option "ln_fold"), for any per-row shift m:
+ *   (LN(x)(1 + s) + b) W^T + bias = rstd (((x - m)(1 + s)) W^T) - rstd (mean - m) c1 + c2.
+ * Op-level twins: with a producer set, f5_op_gemm_resid_gate also writes (x - row_shift)(1 + next_scale) as [M][N] 16-bit operands and
+ * the slice statistics [N / 64][M][2] (slice-major: sum of d = x - row_shift over the slice's 64 columns, sum of squares about the
+ * slice mean); row_shift [M] or NULL = 0.  f5_op_fold_rows merges those into the row factors [M][2] = (rstd, rstd * (mean - m)),
+ * eps 1e-6; its row_shift (NULL = 0) is m on entry and the row's mean on exit (the next producer's shift).  f5_debug_set_op_ln_mean_out:
+ * f5_op_ln_modulate also writes the row means [rows] (the first shift of a forward).  With a consumer set, f5_op_gemm (epi 2) and
+ * f5_op_qkv_rope take the operands as A and finish the LN in their epilogues (bias ignored: it is inside c2).  Shapes must run on the
+ * 256x256 / role-split 128x256 kernels.  NULLs = off. */
+int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float* stats_out, const float* row_shift);
+int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, float* row_shift, void* stream);
+int f5_debug_set_op_ln_mean_out(float* mean_out);
 int f5_debug_set_op_fold_consumer(const float* rowf, const float* c1, const float* c2);
-int f5_debug_set_op_fold_overflow_flag(int* flag);   /* device word the producer ORs bit 0 into when x (1 + s) leaves the fp16 range; NULL = off */
+int f5_debug_set_op_fold_overflow_flag(int* flag);   /* device word the producer ORs bit 0 into when (x - m)(1 + s) leaves the fp16 range; NULL = off */
 /* c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k] shift_v[k] + bias[n] for nvec modulation vectors (vec_stride
  * floats apart; result rows out_stride floats apart); K % 256 == 0, K <= 2048 */
 int f5_op_fold_consts(const void* w_hi, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,

@@ -223,12 +223,15 @@ class DiTOracle:
         `mxfp8` mode (BASELINE configs[4], no reference counterpart): as bf16, except that both operands of the four
         per-block linears (to_q/k/v, to_out, ff.0, ff.2) are MX-fp8 (oracle/mx_oracle.py), weights from their bf16 copies."""
         # ln_fold: restates the engine option of the same name (csrc/gemm.hpp fold_*, DESIGN.md): the LayerNorm-modulate steps of a block
-        # are folded algebraically into the GEMM that consumes them -- the GEMM's A operand is the residual stream times (1 + scale)
-        # rounded to 16 bits, the weight is the ordinary 16-bit W, and the normalisation arrives in the epilogue:
-        #   (LN(x) (1 + s) + b) W^T + bias  =  rstd ((x (1 + s)) W^T) - rstd mu c1 + c2,   c1 = W (1 + s),  c2 = W b + bias
-        # (mean / rstd from the fp32 x; c1 / c2 fp32 sums over the rounded W).  Only meaningful together with an emulate_* rounding.
-        # (the engine keeps the LN kernel for block 0's first LN and for the final one; here every block LN is folded: an upper bound)
+        # are folded algebraically into the GEMM that consumes them -- the GEMM's A operand is the SHIFTED residual stream times
+        # (1 + scale) rounded to 16 bits, the weight is the ordinary 16-bit W, and the normalisation arrives in the epilogue:
+        #   (LN(x) (1 + s) + b) W^T + bias  =  rstd (((x - m)(1 + s)) W^T) - rstd (mu - m) c1 + c2,   c1 = W (1 + s),  c2 = W b + bias
+        # with m = the row's mean at the PREVIOUS LayerNorm (round 5: the operand no longer carries the mean LayerNorm removes), mean /
+        # rstd from the fp32 x, c1 / c2 fp32 sums over the rounded W.  Only meaningful together with an emulate_* rounding.  As in the
+        # engine, block 0's first LN and the final one are ordinary LayerNorms (the first one supplies the first m).
+        # ln_fold = "unshifted": m = 0 everywhere (the round-4 formulation, kept for the numerics study in tests / profiles/r05).
         self.ln_fold = ln_fold
+        self._fold_m: Optional[Tensor] = None
         self.cfg = cfg
         self.dtype = dtype
         self.emu = emulate_bf16 or emulate_mxfp8 or emulate_f16
@@ -346,20 +349,29 @@ class DiTOracle:
         x = self.linear(torch.cat((x, cond, text_emb), dim=-1), "transformer.input_embed.proj")
         return self.conv_pos_embed(x) + x
 
-    def folded_linear(self, x: Tensor, scale: Tensor, shift: Tensor, name: str, eps: float = 1e-6) -> Tensor:
-        """(LN(x) (1 + scale) + shift) W^T + bias with the normalisation folded behind the GEMM (ln_fold, see __init__): x (b, n, d) fp32
-        residual stream, scale / shift (b, d)."""
+    def fold_ln(self, x: Tensor, eps: float = 1e-6):
+        """Row statistics of one folded LayerNorm (csrc/gemm.hip f5_fold_rows_kernel): d = x - m with m the row mean at the previous
+        LayerNorm, mean and centred variance of d; leaves m := mean(x) for the next one.  Returns (d, rstd, mean_d)."""
+        m = self._fold_m if (self._fold_m is not None and self.ln_fold != "unshifted") else torch.zeros_like(x[..., :1])
+        d = x - m
+        mean_d = d.mean(dim=-1, keepdim=True)
+        rstd = torch.rsqrt(((d - mean_d) ** 2).mean(dim=-1, keepdim=True) + eps)
+        self._fold_m = m + mean_d
+        return d, rstd, mean_d
+
+    def folded_linear(self, stats, scale: Tensor, shift: Tensor, name: str) -> Tensor:
+        """(LN(x) (1 + scale) + shift) W^T + bias with the normalisation folded behind the GEMM (ln_fold, see __init__): stats =
+        fold_ln(x) of the fp32 residual stream x (b, n, d), scale / shift (b, d)."""
+        d, rstd, mean_d = stats
         w, bias = self.w[name + ".weight"], self.w[name + ".bias"]
-        mu = x.mean(dim=-1, keepdim=True)
-        rstd = torch.rsqrt(((x - mu) ** 2).mean(dim=-1, keepdim=True) + eps)
         wr = self._r(w)                                                        # the ordinary weight operand
-        acc = self._r(x * (1 + scale)[:, None, :]) @ wr.T                      # A operand = x (1 + scale), rounded
+        acc = self._r(d * (1 + scale)[:, None, :]) @ wr.T                      # A operand = (x - m)(1 + scale), rounded
         c1 = (1 + scale) @ wr.T                                                # (b, out), fp32
         c2 = shift @ wr.T + bias                                               # (b, out), fp32
-        return rstd * acc - (rstd * mu) * c1[:, None, :] + c2[:, None, :]
+        return rstd * acc - (rstd * mean_d) * c1[:, None, :] + c2[:, None, :]
 
     def attention(self, x: Tensor, i: int, mask: Optional[Tensor], rope: Tensor, fold=None) -> Tensor:
-        """Attention (dit.py:127-175).  fold = (x_residual, scale, shift): ln_fold study, `x` is then unused for q / k / v."""
+        """Attention (dit.py:127-175).  fold = (fold_ln(x_residual), scale, shift): ln_fold, `x` is then unused for q / k / v."""
         p = f"transformer.transformer_blocks.{i}.attn."
         b, n, _ = x.shape
         H = self.cfg.heads
@@ -395,8 +407,13 @@ class DiTOracle:
         emb = self.linear(F.silu(t), p + "attn_norm.linear", lowp=False)
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = emb.chunk(6, dim=1)
         if self.ln_fold and self.emu:
-            x = x + gate_msa[:, None] * self.attention(x, i, mask, rope, fold=(x, scale_msa, shift_msa))
-            h = _gelu_tanh(self.folded_linear(x, scale_mlp, shift_mlp, p + "ff.ff.layers.0.layers.0"))
+            if i == 0:                                   # the engine's LN kernel: an ordinary LayerNorm that also leaves the row means
+                self._fold_m = x.mean(dim=-1, keepdim=True)
+                norm = self.layer_norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+                x = x + gate_msa[:, None] * self.attention(norm, i, mask, rope)
+            else:
+                x = x + gate_msa[:, None] * self.attention(x, i, mask, rope, fold=(self.fold_ln(x), scale_msa, shift_msa))
+            h = _gelu_tanh(self.folded_linear(self.fold_ln(x), scale_mlp, shift_mlp, p + "ff.ff.layers.0.layers.0"))
             ff = self.linear(h, p + "ff.ff.layers.2")
             return x + gate_mlp[:, None] * ff
         norm = self.layer_norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]

@@ -6,6 +6,9 @@ mode bench.py times) and "bf16x3" (hi/lo split bf16 operands, three passes, fp32
 bf16 mode is checked against the oracle evaluated with the SAME bf16 operand rounding (kernel-bug
 detector) and its drift vs the fp32 oracle is reported, not hidden.
 """
+import ctypes as C
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -974,6 +977,163 @@ def test_f16_range_stress_outlier_weights():
     assert results[1.0][1] <= MEL_L1_TOL and results[1e2][1] <= MEL_L1_TOL, results
     print("[f16 range] breaking scale (first scale whose f16 result leaves the gate): "
           f"{next((sc for sc in sorted(results) if results[sc][1] > MEL_L1_TOL), None)}")
+
+
+def _outlier_weights(base, scale, r):
+    """a few adaLN scale rows, FF1 rows and q / k rows of blocks 0 / 7 / 21 scaled up (test_f16_range_stress_outlier_weights)"""
+    w = {k: v.copy() for k, v in base.items()}
+    if scale != 1.0:
+        for blk in (0, 7, 21):
+            pre = f"transformer.transformer_blocks.{blk}."
+            ada = w[pre + "attn_norm.linear.weight"]
+            for row in r.integers(1024, 2048, 4):
+                ada[row] *= scale
+            for row in r.integers(4096, 5120, 4):
+                ada[row] *= scale
+            ff1 = w[pre + "ff.ff.layers.0.layers.0.weight"]
+            for row in r.integers(0, ff1.shape[0], 4):
+                ff1[row] *= scale
+            for name in ("attn.to_q.weight", "attn.to_k.weight"):
+                m = w[pre + name]
+                for row in r.integers(0, m.shape[0], 2):
+                    m[row] *= np.sqrt(scale)
+    return w
+
+
+def test_f16_range_stress_with_the_ln_fold_active():
+    """VERDICT r4 "next" #2(a), model level: the outlier-weight stress of the test above at batch 12 x 937 frames, where the LN fold is
+    ACTIVE by default (22 488 rows), against `bf16x3` (fp32-class, never folds), with the fold off next to it: the folded path must stay
+    finite, inside the gate wherever the unfolded f16 path is, and no further from `bf16x3` than 1.5x the unfolded path + 1e-4.  Also
+    carries a residual-stream offset: the conv-pos / input-projection bias is raised so that row means sit at tens of sigma (what the
+    round-4 formulation lost precision on, profiles/r05/ln_fold_numerics_study.jsonl)."""
+    import bench
+    cfg = F5TTS_335M
+    base = synthetic_weights(cfg, seed=42)
+    base["transformer.input_embed.proj.bias"] = base["transformer.input_embed.proj.bias"] + 8.0      # row means of ~10 sigma at block 0
+    cond, text, y0, _ = bench.synth_batch(12, 0, DEV)
+    r = np.random.default_rng(11)
+    N = 937
+    for scale in (1.0, 1e2):
+        w = _outlier_weights(base, scale, r)
+        outs = {}
+        for prec, fold in (("bf16x3", -1), ("f16", 0), ("f16", -1)):
+            m = _model(cfg, w, prec)
+            m.engine.set_option("ln_fold", fold)
+            with warnings.catch_warnings():
+                warnings.simplefilter("error", E.OperandRangeWarning)           # these weights must not leave the fp16 range
+                out, _ = F5TTS(transformer=m).sample(cond, text, duration=N, y0=y0, steps=6, method="euler", cfg_strength=2.0, use_graph=False)
+                m.engine.synchronize()
+            outs[(prec, fold)] = out.cpu()
+            if prec == "f16" and fold == -1:
+                assert m.engine.range_events == 0
+            del m
+            torch.cuda.empty_cache()
+        ref = outs[("bf16x3", -1)]
+        l1_unf = float((outs[("f16", 0)] - ref).abs().mean())
+        l1_fold = float((outs[("f16", -1)] - ref).abs().mean())
+        print(f"[f16 range, fold active] outlier scale {scale:g}: f16 vs bf16x3 mel L1 unfolded {l1_unf:.3e}, folded {l1_fold:.3e}")
+        assert torch.isfinite(outs[("f16", -1)]).all()
+        assert not torch.equal(outs[("f16", -1)], outs[("f16", 0)]), "the fold did not run"
+        assert l1_fold <= 1.5 * l1_unf + 1e-4, (l1_fold, l1_unf)
+        if l1_unf <= MEL_L1_TOL * 0.6:
+            assert l1_fold <= MEL_L1_TOL, (l1_fold, l1_unf)
+
+
+@pytest.mark.parametrize("mode", ["sync", "async", "auto"])
+def test_ln_fold_operand_overflow_falls_back_instead_of_raising(mode):
+    """VERDICT r4 "next" #2(c, d) / ADVICE: when the folded operand leaves the fp16 range the engine must not raise (round 4 did: a call
+    that worked at batch 8 threw at 12) and must not block the host on every call.  Weights whose residual stream reaches ~1e6 after
+    block 0 (FF2 scaled): `sync` / `auto` return the UNFOLDED result for that very call (bit-identical to ln_fold = 0) with an
+    OperandRangeWarning and leave the engine at ln_fold = 0; `async` returns at once, reports at the next call (or synchronize()) and
+    is right from then on.  Ordinary weights: no warning, `auto` stops synchronising after its probation."""
+    import bench
+    cfg = F5TTS_335M
+    w = synthetic_weights(cfg, seed=42)
+    w["transformer.transformer_blocks.0.ff.ff.layers.2.weight"] = w["transformer.transformer_blocks.0.ff.ff.layers.2.weight"] * 3.0e6
+    cond, text, y0, _ = bench.synth_batch(4, 0, DEV)
+    kw = dict(duration=937, y0=y0, steps=3, method="euler", cfg_strength=2.0, use_graph=False)
+    ref_m = DiT.from_config(cfg, precision="f16", device=DEV)
+    ref_m.load_weights(w)
+    ref_m.engine.set_option("ln_fold", 0)
+    ref, _ = F5TTS(transformer=ref_m).sample(cond, text, **kw)
+    torch.cuda.synchronize()
+    ref = ref.cpu()
+    del ref_m
+    m = DiT.from_config(cfg, precision="f16", device=DEV)
+    m.load_weights(w)
+    eng = m.engine
+    eng.range_check = mode
+    eng.set_option("ln_fold", 1)
+    f5 = F5TTS(transformer=m)
+    if mode in ("sync", "auto"):
+        with pytest.warns(E.OperandRangeWarning, match="re-running it unfolded"):
+            out, _ = f5.sample(cond, text, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref) and eng.get_option("ln_fold") == 0 and eng.range_events == 1
+    else:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", E.OperandRangeWarning)
+            out, _ = f5.sample(cond, text, **kw)                               # returns without looking
+        with pytest.warns(E.OperandRangeWarning, match="saturated"):
+            eng.synchronize()
+        assert eng.get_option("ln_fold") == 0 and eng.range_events == 1
+        assert torch.isfinite(out).all()                                      # saturated, not inf
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", E.OperandRangeWarning)
+        out2, _ = f5.sample(cond, text, **kw)
+        eng.synchronize()
+    assert torch.equal(out2.cpu(), ref)
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_ln_fold_auto_range_check_stops_synchronising(full_f16):
+    """range_check = "auto": synchronous (with fallback) for the first three fold-active calls, a pinned 4-byte copy behind the call
+    from then on; the library says whether the fold runs (f5_engine_ln_fold_active), so nothing is read at batch 1."""
+    import bench
+    eng = full_f16.engine
+    assert eng.range_check == "auto"
+    f5 = F5TTS(transformer=full_f16)
+    c1, t1, y1, _ = bench.synth_batch(1, 0, DEV)
+    eng._clean_fold_calls = 0
+    f5.sample(c1, t1, duration=937, y0=y1, steps=3, use_graph=False)
+    assert eng._clean_fold_calls == 0 and not eng._status_pending              # batch 1: the fold cannot run, no status traffic at all
+    cond, text, y0, _ = bench.synth_batch(4, 0, DEV)
+    eng.set_option("ln_fold", 1)
+    try:
+        for i in range(5):
+            f5.sample(cond, text, duration=937, y0=y0, steps=3, use_graph=False)
+            if i < 3:
+                assert eng._clean_fold_calls == i + 1 and not eng._status_pending    # probation: checked in the call
+        assert eng._status_pending                                            # afterwards: pending, resolved later
+        eng.synchronize()
+        assert not eng._status_pending and eng._clean_fold_calls == 5 and eng.range_events == 0
+    finally:
+        eng.set_option("ln_fold", -1)
+
+
+def test_bf16_with_the_ln_fold(full_f16):
+    """no model-level test covered bf16 with the fold.  Batch 12 x 937 (fold active by default), 5-point solve: bf16 folded
+    vs bf16 unfolded must differ (the option ran) by no more than bf16's own drift from the f16 result on the same inputs."""
+    import bench
+    cfg = F5TTS_335M
+    cond, text, y0, _ = bench.synth_batch(12, 0, DEV)
+    kw = dict(duration=937, y0=y0, steps=5, method="euler", cfg_strength=2.0, sway_sampling_coef=-1.0, use_graph=False)
+    m = _model(cfg, synthetic_weights(cfg, seed=42), "bf16")
+    outs = {}
+    for opt in (0, -1):
+        m.engine.set_option("ln_fold", opt)
+        out, _ = F5TTS(transformer=m).sample(cond, text, **kw)
+        torch.cuda.synchronize()
+        outs[opt] = out.cpu()
+    f16, _ = F5TTS(transformer=full_f16).sample(cond, text, **kw)
+    torch.cuda.synchronize()
+    d_fold = float((outs[-1] - outs[0]).abs().mean())
+    d_prec = float((outs[0] - f16.cpu()).abs().mean())
+    print(f"[bf16 + ln_fold] folded vs unfolded {d_fold:.3e}; bf16 vs f16 (both unfolded / default) {d_prec:.3e}")
+    assert torch.isfinite(outs[-1]).all() and 0.0 < d_fold <= 1.5 * d_prec
+    del m
+    torch.cuda.empty_cache()
 
 
 def test_back_to_back_calls_without_host_sync_full_size():

@@ -867,22 +867,36 @@ def test_gemm_rs128_several_rounds_all_epilogues(lib, tile):
         E.check(lib.f5_debug_set_gemm_tile(0))
 
 
+# (row mean / sigma, massive-activation channels, drift of the mean since the previous LayerNorm / sigma): the first row is ordinary data,
+# the others are what a trained checkpoint may hold -- VERDICT r4 "next" #2
+FOLD_STRESS = [(0.5, False, 0.2), (10.0, False, 0.3), (100.0, True, 1.0), (1.0, True, 0.0)]
+
+
 @pytest.mark.parametrize("tile", [4, 14])
-def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
-    """LN fold (csrc/gemm.hpp fold_*; dit.py:319-321 and :323 -> :270 -> :136): the residual GEMM leaves x (1 + s) as 16-bit operands
-    plus per-row partial sums (a tiny kernel turns them into rstd and rstd * mean), the QKV / FF1 GEMM finishes the LN in its epilogue:
-        (LN(x)(1 + s) + b) W^T + bias = rstd ((x (1 + s)) W^T) - rstd mean c1 + c2,   c1 = W (1 + s),  c2 = W b + bias.
+@pytest.mark.parametrize("stress", range(len(FOLD_STRESS)))
+def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
+    """LN fold (csrc/gemm.hpp fold_*; dit.py:319-321 and :323 -> :270 -> :136): the residual GEMM leaves (x - m)(1 + s) as 16-bit operands
+    (m = the row's mean at the previous LayerNorm) plus per-row slice statistics, a tiny kernel merges them into rstd and
+    rstd (mean - m), the QKV / FF1 GEMM finishes the LN in its epilogue:
+        (LN(x)(1 + s) + b) W^T + bias = rstd (((x - m)(1 + s)) W^T) - rstd (mean - m) c1 + c2,   c1 = W (1 + s),  c2 = W b + bias.
     Both staged kernels (tile 4 = 256x256, 14 = role-split 128x256), ragged last row tile, masked rows.  Checked piece by piece:
-    x bit-identical to the plain launch, x16 the exact rounding of x (1 + s), the row sums and the constants against fp64, and the
-    consumer outputs against an fp64 evaluation of the folded formula on the SAME operands (sharp: one 16-bit rounding) as well as
-    against the exact LN-modulate + GEMM (the precision claim)."""
-    r = rng(4100 + tile)
+    x bit-identical to the plain launch, x16 the exact rounding of (x - m)(1 + s), the slice statistics, the row factors and the
+    constants against fp64, and the consumer outputs against an fp64 evaluation of the folded formula on the SAME operands (sharp: one
+    16-bit rounding) as well as against the exact LN-modulate + GEMM NEXT TO the unfolded path (ln_modulate kernel + plain GEMM) on the
+    same inputs: row means of 0.5 / 10 / 100 sigma, four channels at 1e3 sigma -- the folded error must stay within 2x the unfolded one
+    whatever the mean is (the round-4 formulation, m = 0, is 10x / 100x worse at 10 / 100 sigma: profiles/r05/ln_fold_numerics_study.jsonl)."""
+    mu_sig, outliers, drift = FOLD_STRESS[stress]
+    r = rng(4100 + tile + 17 * stress)
     Bq, Nq, H, D, FF = 8, 937, 16, 1024, 2048
     M = Bq * Nq
     eps_op = 2.0 ** -8 if op_dtype() == torch.bfloat16 else 2.0 ** -11
     a = randn(r, M, D)
     wo, bo, gate, x0 = randn(r, D, D, scale=D ** -0.5), randn(r, D, scale=0.1), randn(r, D), randn(r, M, D)
-    x0 += 0.5 * randn(r, M, 1) + 0.3 * randn(r, 1, D)                      # row means and column offsets: the cancellation the fold must survive
+    if outliers:
+        x0[:, 5:9] *= 1.0e3                                               # massive-activation channels
+    x0 += 0.3 * randn(r, 1, D)                                             # column offsets
+    sig0 = x0.std(-1, unbiased=False, keepdim=True)
+    x0 += mu_sig * sig0 * torch.where(randn(r, M, 1) < 0, -1.0, 1.0)      # row means of mu_sig sigma, either sign
     keep = torch.from_numpy((r.random(M) > 0.3).astype(np.uint8))
     sv = torch.stack([randn(r, D, scale=0.3), randn(r, D, scale=0.3)])     # two modulation vectors: the second one is used (strides)
     bv = torch.stack([randn(r, D, scale=0.3), randn(r, D, scale=0.3)])
@@ -897,49 +911,59 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
     try:
         E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(wo_hi), P(None), P(bo_d), P(gate_d), P(keep_d), P(x_plain), M, D, D, D, D, D, 1,
                                           stream()), "resid_gate plain")
-        E.check(lib.f5_debug_set_op_fold_producer(P(sv_d[1]), P(x16), P(stats)))
+        sync()
+        # the shift a forward would hold: the row's mean at the previous LayerNorm = the new mean minus what this update moved it by
+        xnew = x_plain.cpu()
+        m_prev = (xnew.double().mean(-1) - drift * xnew.double().std(-1, unbiased=False) * torch.where(randn(r, M) < 0, -1.0, 1.0).double()).float()
+        shift_d = m_prev.to(DEV).clone()
+        E.check(lib.f5_debug_set_op_fold_producer(P(sv_d[1]), P(x16), P(stats), P(shift_d)))
         try:
             E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(wo_hi), P(None), P(bo_d), P(gate_d), P(keep_d), P(x), M, D, D, D, D, D, 1,
                                               stream()), "resid_gate fold producer")
         finally:
-            E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None)))
+            E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None), P(None)))
         sync()
-        # the operand-range flag: x (1 + s) is the one fp16 operand without a natural bound -- a value beyond +-65 504 must raise bit 0
-        # of the flag word (fp16 build only; bf16 has the range), ordinary data must leave it alone
-        flag = torch.zeros(4, dtype=torch.int32, device=DEV)
-        xbig = (x0 * 3.0e4).to(DEV).clone()
-        for xin, want in ((x0.to(DEV).clone(), 0), (xbig, 1 if op_dtype() == torch.float16 else 0)):
-            flag.zero_()
-            E.check(lib.f5_debug_set_op_fold_overflow_flag(P(flag)))
-            E.check(lib.f5_debug_set_op_fold_producer(P(sv_d[1]), P(torch.zeros_like(x16)), P(torch.zeros_like(stats))))
-            try:
-                x16_tmp, stats_tmp = torch.zeros_like(x16), torch.zeros_like(stats)
-                E.check(lib.f5_debug_set_op_fold_producer(P(sv_d[1]), P(x16_tmp), P(stats_tmp)))
-                E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(wo_hi), P(None), P(bo_d), P(gate_d), P(keep_d), P(xin), M, D, D, D, D, D, 1,
-                                                  stream()), "resid_gate fold producer (range flag)")
-                sync()
-            finally:
-                E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None)))
-                E.check(lib.f5_debug_set_op_fold_overflow_flag(P(None)))
-            assert flag.cpu().tolist() == [want, 0, 0, 0], (flag.cpu().tolist(), want)
+        if stress == 0:
+            # the operand-range flag: (x - m)(1 + s) is the one fp16 operand without a natural bound -- a value beyond +-65 504 must raise
+            # bit 0 of the flag word (fp16 build only; bf16 has the range), ordinary data must leave it alone
+            flag = torch.zeros(4, dtype=torch.int32, device=DEV)
+            xbig = (x0 * 3.0e4).to(DEV).clone()
+            for xin, want in ((x0.to(DEV).clone(), 0), (xbig, 1 if op_dtype() == torch.float16 else 0)):
+                flag.zero_()
+                E.check(lib.f5_debug_set_op_fold_overflow_flag(P(flag)))
+                try:
+                    x16_tmp, stats_tmp = torch.zeros_like(x16), torch.zeros_like(stats)
+                    E.check(lib.f5_debug_set_op_fold_producer(P(sv_d[1]), P(x16_tmp), P(stats_tmp), P(None)))
+                    E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(wo_hi), P(None), P(bo_d), P(gate_d), P(keep_d), P(xin), M, D, D, D, D, D, 1,
+                                                      stream()), "resid_gate fold producer (range flag)")
+                    sync()
+                finally:
+                    E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None), P(None)))
+                    E.check(lib.f5_debug_set_op_fold_overflow_flag(P(None)))
+                assert flag.cpu().tolist() == [want, 0, 0, 0], (flag.cpu().tolist(), want)
         assert torch.equal(x, x_plain), "the fold producer changed the residual stream"
         xc = x.cpu()
-        want16 = (xc * (1.0 + s1)).to(op_dtype())
-        assert torch.equal(x16.cpu(), want16), "x16 is not the rounding of x (1 + s)"
-        xs = xc.double().reshape(M, D // 64, 64)
+        dsh = xc - m_prev[:, None]                                           # fp32, as the kernel subtracts
+        want16 = (dsh * (1.0 + s1)).to(op_dtype())
+        assert torch.equal(x16.cpu(), want16), "x16 is not the rounding of (x - m)(1 + s)"
+        ds = dsh.double().reshape(M, D // 64, 64)
         st = stats.cpu().double().permute(1, 0, 2)
-        assert float((st[..., 0] - xs.sum(-1)).abs().max()) <= 1e-5 * float(xs.abs().sum(-1).max())
-        assert float((st[..., 1] - (xs * xs).sum(-1)).abs().max()) <= 1e-5 * float((xs * xs).sum(-1).max())
+        assert float((st[..., 0] - ds.sum(-1)).abs().max()) <= 1e-5 * float(ds.abs().sum(-1).max())
+        m2_ref = ((ds - ds.mean(-1, keepdim=True)) ** 2).sum(-1)
+        assert float((st[..., 1] - m2_ref).abs().max()) <= 2e-5 * float(m2_ref.max())
         rowf = torch.full((M + 8, 2), float("nan"), device=DEV)
-        E.check(lib.f5_op_fold_rows(P(stats), D // 64, M, P(rowf), stream()), "fold_rows")
+        E.check(lib.f5_op_fold_rows(P(stats), D // 64, M, P(rowf), P(shift_d), stream()), "fold_rows")
         sync()
         x64 = xc.double()
         mean, var = x64.mean(-1, keepdim=True), x64.var(-1, unbiased=False, keepdim=True)
         rstd = (var + 1e-6).rsqrt()
+        mean_d = mean - m_prev.double()[:, None]
         rf = rowf.cpu().double()
         assert bool(torch.isnan(rf[M:]).all())
-        assert float((rf[:M, 0:1] - rstd).abs().max()) <= 1e-5 * float(rstd.max())
-        assert float((rf[:M, 1:2] - rstd * mean).abs().max()) <= 1e-5 * float((rstd * mean).abs().max() + 1.0)
+        assert float((rf[:M, 0:1] / rstd - 1.0).abs().max()) <= 2e-5, "rstd"
+        assert float((rf[:M, 1:2] - rstd * mean_d).abs().max()) <= 2e-5 * float((rstd * mean_d).abs().max() + 1.0)
+        # fold_rows leaves the row's mean behind: the next producer's shift
+        assert float((shift_d.cpu().double()[:, None] - mean).abs().max()) <= 2e-6 * float(mean.abs().max() + var.sqrt().max())
         # --- constants, for both consumers
         w1, bias1 = randn(r, FF, D, scale=D ** -0.5), randn(r, FF, scale=0.1)
         wq, biasq = randn(r, 3 * D, D, scale=D ** -0.5), randn(r, 3 * D, scale=0.1)
@@ -960,16 +984,25 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
                 assert float((c2[v, :Nn].cpu().double() - r2).abs().max()) <= 2e-5 * max(1.0, float(r2.abs().max())), nm
             assert bool(torch.isnan(c1[:, Nn:]).all()) and bool(torch.isnan(c2[:, Nn:]).all())
             consts[nm] = (c1, c2, w64)
-        # --- the folded formula in fp64 on the operands the consumers see, and the exact LN-modulate + projection
+        # --- the folded formula in fp64 on the operands the consumers see, the exact LN-modulate + projection, and the UNFOLDED path
         h_exact = (x64 - mean) * rstd * (1.0 + s1.double()) + b1.double()
+        h16 = torch.zeros((M, D), dtype=op_dtype(), device=DEV)
+        E.check(lib.f5_op_ln_modulate(P(x), P(sv_d[1]), P(bv_d[1]), P(h16), P(None), M, D, stream()), "ln_modulate (unfolded path)")
+        sync()
 
         def folded(nm, bias):
             c1, c2, w64 = consts[nm]
-            return rstd * (want16.double() @ w64.T) - rstd * mean * c1[1, :w64.shape[0]].cpu().double() + c2[1, :w64.shape[0]].cpu().double()
+            return rstd * (want16.double() @ w64.T) - rstd * mean_d * c1[1, :w64.shape[0]].cpu().double() + c2[1, :w64.shape[0]].cpu().double()
+
+        def rel_l1(got, ref):
+            return float((got.double() - ref).abs().mean()) / float(ref.pow(2).mean().sqrt())
 
         # FF1 + GELU-tanh
         out16 = torch.zeros((M, FF), dtype=op_dtype(), device=DEV)
+        out16_unf = torch.zeros((M, FF), dtype=op_dtype(), device=DEV)
         c1, c2, w64 = consts["ff1"]
+        E.check(lib.f5_op_gemm(P(h16), P(None), P(w1_hi), P(None), P(bias1_d), P(None), P(out16_unf), P(None), M, FF, D, D, D, FF, 1, 2, stream()),
+                "gemm gelu unfolded")
         E.check(lib.f5_debug_set_op_fold_consumer(P(rowf), P(c1[1]), P(c2[1])))
         try:
             E.check(lib.f5_op_gemm(P(x16), P(None), P(w1_hi), P(None), P(None), P(None), P(out16), P(None), M, FF, D, D, D, FF, 1, 2, stream()),
@@ -977,10 +1010,12 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
             sync()
             sharp = F.gelu(folded("ff1", bias1), approximate="tanh")
             exact = F.gelu(h_exact @ w64.T + bias1.double(), approximate="tanh")
-            mx, _, _ = report(f"LN fold FF1 tile={tile}: vs the folded formula in fp64", out16.float().cpu(), sharp)
+            mx, _, _ = report(f"LN fold FF1 tile={tile} stress={FOLD_STRESS[stress]}: vs the folded formula in fp64", out16.float().cpu(), sharp)
             assert mx <= 2.5 * eps_op * max(1.0, float(sharp.abs().max()))
-            mx, _, l1 = report(f"LN fold FF1 tile={tile}: vs exact LN-modulate + GEMM", out16.float().cpu(), exact)
-            assert mx <= 2.5e-2 * max(1.0, float(exact.abs().max()))
+            e_fold, e_unf = rel_l1(out16.float().cpu(), exact), rel_l1(out16_unf.float().cpu(), exact)
+            print(f"[ln_fold stress] tile={tile} |mu|/sigma={mu_sig} outliers={outliers} drift={drift}: FF1 mean|err|/rms folded {e_fold:.3e} "
+                  f"unfolded {e_unf:.3e} ratio {e_fold / e_unf:.2f}")
+            assert e_fold <= 2.0 * e_unf + 1e-6, (e_fold, e_unf)
             # --- QKV + RoPE + V^T, transposed q / k tiles, q pre-multiplied (as sample() runs it)
             npad = (Nq + 63) // 64 * 64
             cos_t, sin_t = torch.empty((Nq, 32), device=DEV), torch.empty((Nq, 32), device=DEV)
@@ -989,11 +1024,15 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
             E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), Nq, 64, C.c_float(QPRE), stream()))
             qk = torch.zeros((M, 2 * D), dtype=op_dtype(), device=DEV)
             vt = torch.zeros((Bq * H, 64, npad), dtype=op_dtype(), device=DEV)
+            qk_unf, vt_unf = torch.zeros_like(qk), torch.zeros_like(vt)
             c1, c2, w64 = consts["qkv"]
-            E.check(lib.f5_debug_set_op_fold_consumer(P(rowf), P(c1[1]), P(c2[1])))
             E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
             E.check(lib.f5_debug_set_op_q_premul(C.c_float(QPRE)))
             try:
+                E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(None), P(None)))
+                E.check(lib.f5_op_qkv_rope(P(h16), P(None), P(wq_hi), P(None), P(biasq_d), P(cos_t), P(sin_t), P(qk_unf), P(None), P(vt_unf), P(None),
+                                           Bq, Nq, npad, H, D, 1, stream()), "qkv_rope unfolded")
+                E.check(lib.f5_debug_set_op_fold_consumer(P(rowf), P(c1[1]), P(c2[1])))
                 E.check(lib.f5_op_qkv_rope(P(x16), P(None), P(wq_hi), P(None), P(None), P(cos_t), P(sin_t), P(qk), P(None), P(vt), P(None),
                                            Bq, Nq, npad, H, D, 1, stream()), "qkv_rope folded")
                 sync()
@@ -1003,17 +1042,27 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile):
         finally:
             E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(None), P(None)))
         freqs = O.rotary_freqs(64, Nq).double()
-        got_q = qk.float().cpu()[:, :D].reshape(Bq, Nq, H, 64).transpose(1, 2) / QPRE
-        got_k = qk.float().cpu()[:, D:].reshape(Bq, Nq, H, 64).transpose(1, 2)
-        got_v = vt.float().cpu().reshape(Bq, H, 64, npad)[..., :Nq].transpose(-1, -2)
+
+        def unpack(qk_, vt_):
+            gq = qk_.float().cpu()[:, :D].reshape(Bq, Nq, H, 64).transpose(1, 2) / QPRE
+            gk = qk_.float().cpu()[:, D:].reshape(Bq, Nq, H, 64).transpose(1, 2)
+            gv = vt_.float().cpu().reshape(Bq, H, 64, npad)[..., :Nq].transpose(-1, -2)
+            return gq, gk, gv
+
+        got, got_unf = unpack(qk, vt), unpack(qk_unf, vt_unf)
         for label, qkv in (("folded formula", folded("qkv", biasq)), ("exact LN", h_exact @ w64.T + biasq.double())):
             q, k, v = [t.reshape(Bq, Nq, H, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
             q, k = O.apply_rotary_pos_emb(q, freqs), O.apply_rotary_pos_emb(k, freqs)
-            for nm, g, rf in (("q", got_q, q), ("k", got_k, k), ("v", got_v, v)):
-                mx, _, _ = report(f"LN fold QKV tile={tile} {nm} vs {label}", g, rf)
-                rot = 0.0 if nm == "v" else 2.0 * Nq * 2.0 ** -23
-                tol = 2.5 * eps_op if label == "folded formula" else 2.5e-2
-                assert mx <= (tol + rot) * max(1.0, float(rf.abs().max())), (nm, label)
+            for nm, g, gu, rf_ in (("q", got[0], got_unf[0], q), ("k", got[1], got_unf[1], k), ("v", got[2], got_unf[2], v)):
+                if label == "folded formula":
+                    mx, _, _ = report(f"LN fold QKV tile={tile} {nm} vs {label}", g, rf_)
+                    rot = 0.0 if nm == "v" else 2.0 * Nq * 2.0 ** -23
+                    assert mx <= (2.5 * eps_op + rot) * max(1.0, float(rf_.abs().max())), (nm, label)
+                else:
+                    e_fold, e_unf = rel_l1(g, rf_), rel_l1(gu, rf_)
+                    print(f"[ln_fold stress] tile={tile} |mu|/sigma={mu_sig}: {nm} mean|err|/rms folded {e_fold:.3e} unfolded {e_unf:.3e} "
+                          f"ratio {e_fold / e_unf:.2f}")
+                    assert e_fold <= 2.0 * e_unf + 1e-6, (nm, e_fold, e_unf)
         assert float(vt.float().cpu().reshape(Bq, H, 64, npad)[..., Nq:].abs().max()) == 0.0
     finally:
         E.check(lib.f5_debug_set_gemm_tile(0))
@@ -1029,11 +1078,11 @@ def test_ln_fold_fields_fail_loudly_on_small_tile_launches(lib):
     x = randn(r, M, D).to(DEV)
     x16 = torch.zeros((M, D), dtype=op_dtype(), device=DEV)
     stats = torch.zeros((D // 64, M, 2), device=DEV)
-    E.check(lib.f5_debug_set_op_fold_producer(P(sc), P(x16), P(stats)))
+    E.check(lib.f5_debug_set_op_fold_producer(P(sc), P(x16), P(stats), P(None)))
     try:
         rc = lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(w_hi), P(None), P(None), P(gate), P(None), P(x), M, D, D, D, D, D, 1, stream())
     finally:
-        E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None)))
+        E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None), P(None)))
     sync()
     assert rc != 0 and "LN fold" in lib.f5_last_error().decode()
 
