@@ -93,7 +93,8 @@ def generate(
     launches at M = 2 x (sum of frames) instead of one set per sentence.  It is NOT bit-compatible with the loop: in a batch the
     key-padding mask exists (cfm.py:333-336), and GRN (convnext_v2.py:16) and the conv position embedding (dit.py:251) see the padding
     up to the longest sentence, exactly as the reference's own `sample()` behaves for a batch; what it equals is `sample()` of that
-    batch (tests/test_model_gpu.py::test_generate_batch_sentences)."""
+    batch (tests/test_model_gpu.py::test_generate_batch_sentences), each element vocoded on its own frames (the padded tail of a
+    shorter sentence never reaches the vocoder)."""
     if f5tts is None:
         f5tts = F5TTS.from_pretrained(model_name, quantization_bits=quantization_bits)
     if getattr(f5tts, "_vocoder", None) is None:
@@ -144,12 +145,18 @@ def generate(
             durs = torch.full((len(sentences),), int(estimated_duration(audio, ref_audio_text, generation_text, speed) * FRAMES_PER_SEC))
         else:
             durs = None                                               # duration predictor, per element (cfm.py:307-308)
-        waves, _ = f5tts.sample(cond, text=texts, duration=durs, steps=steps, method=method, speed=speed, cfg_strength=cfg_strength,
-                                sway_sampling_coef=sway_sampling_coef, seed=seed)
+        # mel frames out of sample() (vocoder detached for the call), then every sentence is vocoded ON ITS OWN FRAMES: frames past a
+        # shorter sentence's duration hold unconstrained ODE state, and a vocoder with a receptive field (Vocos: a k = 7 ConvNeXt stack)
+        # would leak them into the last ~0.25 s of that sentence before the trim
+        voc = f5tts._vocoder
+        try:
+            f5tts._vocoder = None
+            mel, _ = f5tts.sample(cond, text=texts, duration=durs, steps=steps, method=method, speed=speed, cfg_strength=cfg_strength,
+                                  sway_sampling_coef=sway_sampling_coef, seed=seed)
+        finally:
+            f5tts._vocoder = voc
         frames = f5tts.last_durations                                 # per-element frame counts after the clamps of cfm.py:317-318
-        waves = waves.reshape(len(sentences), -1)
-        edge = max(frames) * HOP_LENGTH - waves.shape[1]              # a vocoder's own edge loss (Vocos: one hop), the same for every element
-        wave = torch.cat([waves[i, audio.shape[0]:int(frames[i]) * HOP_LENGTH - edge] for i in range(len(sentences))], dim=0)
+        wave = torch.cat([voc(mel[i:i + 1, :int(frames[i])]).reshape(-1)[audio.shape[0]:] for i in range(len(sentences))], dim=0)
     else:
         output = []
         for sentence_text in sentences:

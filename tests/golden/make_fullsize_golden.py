@@ -9,6 +9,9 @@ the oracle's answer is stored.  Takes ~5-10 minutes of CPU (27.4 TFLOP); the GPU
 
     python tests/golden/make_fullsize_golden.py            # writes tests/golden/full_b1_euler32.npz (~0.9 MB)
     python tests/golden/make_fullsize_golden.py --emulate f16   # prints the drift the fp16-operand mode should show
+    python tests/golden/make_fullsize_golden.py --method midpoint --points 16   # BASELINE configs[4]'s solver on the same utterance:
+                                                                               # writes tests/golden/full_b1_midpoint16.npz (`out` only)
+    python tests/golden/make_fullsize_golden.py --method midpoint --points 16 --emulate mxfp8   # expected drift of the mxfp8 mode
 
 Stored: `out` = the final mel where(cond_mask, cond, x1) (937, 100) fp32, `traj_8/16/24` = trajectory states after 8 / 16 / 24
 updates (drift by depth), `cond281` = the oracle's mel front-end output for the reference audio (281, 100).
@@ -42,7 +45,9 @@ def inputs(i: int = 0):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--emulate", default=None, choices=[None, "bf16", "f16"], help="report operand-rounding drift instead of writing")
+    ap.add_argument("--emulate", default=None, choices=[None, "bf16", "f16", "mxfp8"], help="report operand-rounding drift instead of writing")
+    ap.add_argument("--method", default="euler", choices=["euler", "midpoint", "rk4"])
+    ap.add_argument("--points", type=int, default=ODE_POINTS)
     ap.add_argument("--ln-fold", action="store_true", help="numerics study: LN-modulate folded algebraically into the consumer GEMMs (oracle ln_fold)")
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     ns = ap.parse_args()
@@ -57,8 +62,18 @@ def main():
     orc = O.DiTOracle(F5TTS_335M, w, **kw)
     t0 = time.time()
     out, traj = O.sample(orc, torch.from_numpy(cond)[None], torch.from_numpy(text)[None], N_FRAMES, y0=torch.from_numpy(y0)[None],
-                         steps=ODE_POINTS, method="euler", cfg_strength=2.0, sway_sampling_coef=-1.0)
+                         steps=ns.points, method=ns.method, cfg_strength=2.0, sway_sampling_coef=-1.0)
     print(f"oracle sample: {time.time() - t0:.1f} s, out {tuple(out.shape)}, |out| mean {float(out.abs().mean()):.4f}")
+    if (ns.method, ns.points) != ("euler", ODE_POINTS):
+        alt = os.path.join(HERE, f"full_b1_{ns.method}{ns.points}.npz")
+        if ns.emulate is None:
+            np.savez_compressed(alt, out=out[0].numpy().astype(np.float32))
+            print("wrote", alt, os.path.getsize(alt), "bytes")
+        else:
+            g = np.load(alt)
+            print(f"[{ns.emulate}{' + ln_fold' if ns.ln_fold else ''}] {ns.points}-point {ns.method}: mel L1 vs fp32 oracle, out: "
+                  f"{float(np.abs(out[0].numpy() - g['out']).mean()):.3e}")
+        return
     if ns.emulate is None:
         np.savez_compressed(OUT, out=out[0].numpy().astype(np.float32), traj_8=traj[8, 0].numpy().astype(np.float32),
                             traj_16=traj[16, 0].numpy().astype(np.float32), traj_24=traj[24, 0].numpy().astype(np.float32),

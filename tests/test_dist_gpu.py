@@ -26,7 +26,7 @@ def _inputs(cfg, B, N, seed=3):
     return cond, text, durations, torch.from_numpy(y0)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     try:
         import torch.distributed as dist
         from f5_tts_mlx_amd.cfm import F5TTS
@@ -35,8 +35,14 @@ def _worker(rank, world, port, q):
         from f5_tts_mlx_amd.weights import TINY, synthetic_weights
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        dev = "cuda:0"
+        # gloo: both ranks on the one GPU of the test box; nccl (= RCCL): one rank per device, as the 8-GPU job runs
+        dev = "cuda:0" if backend == "gloo" else f"cuda:{rank}"
+        if backend == "nccl":
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         cfg = TINY
         B, N = 6, 120
         cond, text, durations, y0 = _inputs(cfg, B, N)
@@ -75,11 +81,16 @@ def _worker(rank, world, port, q):
         q.put((rank, False, traceback.format_exc()[-1500:] + repr(exc)))
 
 
-def test_two_ranks_real_engine_shards_equal_single_process_batch():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_real_engine_shards_equal_single_process_batch(backend):
+    """gloo: two ranks share the test box's one GPU.  nccl: the same protocol over RCCL with one rank per device -- runs wherever two
+    devices are visible (the driver's multi-GPU node), skips on a one-GPU box."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (RCCL refuses two ranks on one device)")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 23000 + (os.getpid() % 3000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 23000 + (os.getpid() % 3000) + (7 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}

@@ -10,11 +10,41 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TXT = os.path.join(ROOT, "tests", "golden", "ref_text_tokens.json")
 RNG = os.path.join(ROOT, "tests", "golden", "mlx_rng.npz")
 VOC = os.path.join(ROOT, "tests", "golden", "mlx_vocos.npz")
 
 need_rng = pytest.mark.skipif(not os.path.exists(RNG), reason="tests/golden/mlx_rng.npz absent: run tools/make_mlx_goldens.py where mlx is installed")
 need_voc = pytest.mark.skipif(not os.path.exists(VOC), reason="tests/golden/mlx_vocos.npz absent: run tools/make_mlx_goldens.py where mlx / vocos_mlx are installed")
+
+
+need_txt = pytest.mark.skipif(not os.path.exists(TXT), reason="tests/golden/ref_text_tokens.json absent: run tools/make_mlx_goldens.py --only-text where jieba + pypinyin are installed")
+
+
+@need_txt
+def test_text_to_tokens_matches_the_reference_with_real_jieba():
+    """the text -> token path (utils.py:139-173) is an index path: bit-exact against the reference's own function run
+    with the REAL jieba / pypinyin.  Single-byte strings go through the package's `_ascii_segments` here (no jieba in this image) and
+    must give the recorded tokens AND the recorded jieba segmentation; strings that need jieba / pypinyin are compared where those are
+    importable and must raise (not guess) where they are not."""
+    from f5_tts_mlx_amd import utils as U
+    g = json.load(open(TXT, encoding="utf-8"))
+    have_backends = U._text_backends()[0] is not None
+    n_ascii = n_other = 0
+    for text, toks, segs in zip(g["texts"], g["tokens"], g["segments"]):
+        t2 = text.translate(U._QUOTES).translate(U._OOV)
+        if len(t2.encode("utf-8")) == len(t2):
+            assert U._ascii_segments(t2) == list(segs), text          # the emulation against jieba's own segmentation
+            assert U.convert_char_to_pinyin([text]) == [toks], text
+            n_ascii += 1
+        elif have_backends:
+            assert U.convert_char_to_pinyin([text]) == [toks], text
+            n_other += 1
+        else:
+            with pytest.raises(RuntimeError, match="jieba"):
+                U.convert_char_to_pinyin([text])
+            n_other += 1
+    assert n_ascii >= 15 and n_other >= 10
 
 
 def _cases(g):
@@ -32,6 +62,13 @@ def test_the_generator_script_is_self_consistent():
     ns = {}
     exec(compile(ast.Module([n for n in tree.body if isinstance(n, ast.Assign)], []), "cases", "exec"), ns)
     assert any(s >= 2 ** 32 for s, _ in ns["RNG_CASES"]) and any(d % 2 for _, d in ns["RNG_CASES"])
+    # the text section: ASCII / punctuation-heavy, CJK and mixed strings, and the package handles every single-byte one
+    from f5_tts_mlx_amd import utils as U
+    texts = ns["TEXT_CASES"]
+    single = [t for t in texts if len(t.translate(U._QUOTES).translate(U._OOV).encode("utf-8")) == len(t.translate(U._QUOTES).translate(U._OOV))]
+    assert len(texts) >= 40 and len(single) >= 15 and len(texts) - len(single) >= 15
+    for t in single:
+        assert "".join(U._ascii_segments(t.translate(U._QUOTES).translate(U._OOV))) == t.translate(U._QUOTES).translate(U._OOV)
     assert all(b * n * 100 > 0 for b, n, _ in ns["MEL_CASES"])
 
 
