@@ -107,11 +107,26 @@ __device__ inline float f5_silu(float x) { return x / (1.0f + __expf(-x)); }
 // tanh-approximated GELU (nn.GELU(approx="tanh"), dit.py:94,309):  0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),
 // u = sqrt(2/pi) (x + 0.044715 x^3).  One v_exp_f32 + one v_rcp_f32 instead of a libm tanhf (~40 instructions);
 // relative error ~2e-7 (rcp + exp2 ulp), exact limits (exp -> inf gives 0, exp -> 0 gives x).
+// Evaluated as x / (1 + exp2(x (C0 + C1 x^2))), C0 = -2 log2(e) sqrt(2/pi), C1 = 0.044715 C0: mul, fma, mul, exp2, add, rcp, mul.
+// f5_gelu_tanh2 is the same arithmetic on TWO elements with packed-f32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32):
+// bit-identical per element to the scalar form.  A wave issues one VALU instruction per ~5.4 cycles whatever its width
+// (tools/probes/valu_rate.hip: v_fma_f32 and v_pk_fma_f32 both 5.4, v_exp_f32 / v_rcp_f32 9.5), and the GEMM epilogues are bound by
+// exactly that issue rate (profiles/r05): two elements per instruction is half the arithmetic issue time.
+typedef float f5_v2f __attribute__((ext_vector_type(2)));
+#define F5_GELU_C0 (-2.3022081983f)
+#define F5_GELU_C1 (-0.10294324f)
 __device__ inline float f5_gelu_tanh(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * u);   // exp(-2u)
+    const float p = __builtin_fmaf(x * x, F5_GELU_C1, F5_GELU_C0);
+    const float t = __builtin_amdgcn_exp2f(x * p);                      // exp(-2u)
     return x * __builtin_amdgcn_rcpf(1.0f + t);
+}
+__device__ __forceinline__ f5_v2f f5_gelu_tanh2(f5_v2f x) {
+    const f5_v2f c1 = {F5_GELU_C1, F5_GELU_C1}, c0 = {F5_GELU_C0, F5_GELU_C0}, one = {1.0f, 1.0f};
+    const f5_v2f a = x * __builtin_elementwise_fma(x * x, c1, c0);
+    f5_v2f t = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    t = t + one;
+    const f5_v2f r = {__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+    return x * r;
 }
 __device__ inline float f5_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 // Mish (nn.Mish, dit.py:35,37): x tanh(softplus(x)); with w = e^x: tanh(log(1+w)) = (w^2 + 2w) / (w^2 + 2w + 2)

@@ -62,7 +62,9 @@ __device__ unsigned long long f5_probe_ts[F5_PROBE_MAXWG * 8];
 
 // QT (EPI_QKV_ROPE with pair-major rotation tables): q / k column tiles accumulated transposed (staged_epilogue_tr_rope), V tiles
 // straight
-template <int EPI, bool QT>
+// FOLD: the LN-fold consumer (F5GemmArgs::fold_*) as its own instantiation: its requests are issued and pinned on every path of the
+// kernel (gemm_dev.hpp fold_prefetch_pin), the plain kernels carry none of it
+template <int EPI, bool QT, bool FOLD>
 __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles_n, int nfull, int tiles_mf) {
     __shared__ __attribute__((aligned(16))) op16_t smem[2 * 4 * V2_HALF_ELEMS];   // [A0,A1,B0,B1][ring buffer][128*64]
 
@@ -177,6 +179,21 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // LN fold: what the epilogue needs from memory is requested here, ahead of the operand loads (gemm_dev.hpp fold_prefetch_pin)
+    static_assert(!FOLD || EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH, "fold consumers");
+    constexpr bool fold = FOLD;
+    const int row0 = m0 + wm * 128, col0 = n0 + wn * 64;
+    // 16-bit row-major outputs: the tile is accumulated TRANSPOSED (operands swapped in every MFMA) for staged_epilogue_tr.  Both
+    // loop copies end in their own epilogue: no join with 128 live accumulator registers.
+    constexpr bool TR_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
+    const bool tr_path = (TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel);       // workgroup-uniform
+    FoldPre fpre;
+    fold_prefetch_clear(fpre);
+    if (fold) {
+        if (tr_path) fold_prefetch_tr<4>(p, fpre, row0, col0, lane);
+        else fold_prefetch_v<4>(p, fpre, row0, col0, lane);
+    }
+
     // ---- prologue: K tile 0 (4 halves) + the B halves of K tile 1; running state = (segment, K offset) of tile tt+1 (A halves)
     // and tile tt+2 (B halves); segment 0 = A.hi W.hi, 1 = A.lo W.hi, 2 = A.hi W.lo (bf16x3)
     int a_seg = 0, a_k0 = 0, b_seg = 0, b_k0 = 0;
@@ -193,6 +210,10 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         b_seg = a_seg;
         b_k0 = a_k0;
     }
+    if (fold) {                        // K tile 0 and the (older) fold requests waited for in full and pinned BEFORE tile 1's B halves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // are issued: those have most of a K tile to land either way
+        fold_prefetch_pin(fpre);
+    }
     if (1 < T) {
         const op16_t* Wp1 = b_seg == 2 ? p.W[1] : p.W[0];
         G256_ISSUE_B(1, 0, Wp1, b_k0);
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
             b_k0 = 0;
             ++b_seg;
         }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (!fold) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -279,14 +300,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
 
     op16_t* stage = smem + wave * 8192;                 // this wave's private 16 KB of epilogue staging
     float* fl = reinterpret_cast<float*>(stage + 6144); // its last 4 KB: row factors of a folded LN-modulate (the staged tiles use <= 9 KB)
-    const bool fold = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH) && p.fold_rowf != nullptr;
-    const int row0 = m0 + wm * 128, col0 = n0 + wn * 64;
-    // 16-bit row-major outputs: the tile is accumulated TRANSPOSED (operands swapped in every MFMA) for staged_epilogue_tr.  Both
-    // loop copies end in their own epilogue: no join with 128 live accumulator registers.
-    constexpr bool TR_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
-    FoldPre fpre;                                       // (FOLD epilogues: their operands are requested before the K loop)
-    if ((TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel)) {       // workgroup-uniform
-        if (fold) fold_prefetch_tr<4>(p, fpre, row0, col0, lane);
+    if (tr_path) {
         for (int tt = 0; tt < T; tt += 2) {
             G256_KSTEP(0, tt, true);
             if (tt + 1 < T) G256_KSTEP(1, tt + 1, true);
@@ -308,7 +322,6 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
         F5_PROBE_TS(4, 4);
         return;
     }
-    if (QT && fold) fold_prefetch_v<4>(p, fpre, row0, col0, lane);
     for (int tt = 0; tt < T; tt += 2) {
         G256_KSTEP(0, tt, false);
         if (tt + 1 < T) G256_KSTEP(1, tt + 1, false);
@@ -360,10 +373,14 @@ static int launch256(const F5GemmArgs& a, hipStream_t stream) {
     ab.nband = (f5_gemm_nband > 0 && tiles_n > f5_gemm_nband && tiles_n % f5_gemm_nband == 0) ? f5_gemm_nband : 0;
     // staged_epilogue_tr reads the bias as 16-byte quads: an unaligned bias vector takes the straight-order path
     if (a.bias != nullptr && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) ab.debug_flags |= 16384;
+    constexpr bool CAN_FOLD = EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH;
+    const bool fold = CAN_FOLD && ab.fold_rowf != nullptr;     // (f5_launch_gemm has checked the fold's preconditions: transposed q / k tiles)
     if (EPI == EPI_QKV_ROPE && ab.rope_cos_tk != nullptr) {
-        hipLaunchKernelGGL((f5_gemm256_kernel<EPI, EPI == EPI_QKV_ROPE>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        if (fold) hipLaunchKernelGGL((f5_gemm256_kernel<EPI, EPI == EPI_QKV_ROPE, CAN_FOLD>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        else hipLaunchKernelGGL((f5_gemm256_kernel<EPI, EPI == EPI_QKV_ROPE, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
     } else {
-        hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        if (fold) hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false, CAN_FOLD>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        else hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
     }
     F5_LAUNCH_CHECK();
     return 0;

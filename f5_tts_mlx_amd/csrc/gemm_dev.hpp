@@ -22,6 +22,18 @@ __device__ __forceinline__ void f5_probe_sink(const T& v) {
     asm volatile("" ::"v"(v));
 }
 
+// ---- packed-f32 epilogue arithmetic (round 5).  The staged epilogues are bound by the VALU ISSUE rate of their two waves per SIMD (one
+// instruction per ~5.4 cycles and wave whatever its width, tools/probes/valu_rate.hip), so their per-element arithmetic -- the LN-fold
+// factors, GELU's polynomial, the rotation, the bias -- runs on element PAIRS with v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same
+// IEEE operations per element, half the instructions.  A scalar that is broadcast to both halves goes through f5_bc2 (its own
+// register: the compiler then broadcasts the LOW half, op_sel_hi = 0); the form whose low result reads a HIGH half (op_sel = 1) is the
+// one that misbehaves next to MFMAs (build.sh, tests/test_isa.py) and must not appear: the ISA test scans every operand for it.
+__device__ __forceinline__ f5_f32x2 f5_bc2(float s) {
+    asm volatile("" : "+v"(s));      // volatile: a plain asm is hoisted above the K loop together with its operand -- a value requested
+    return f5_f32x2{s, s};           // before the loop (FoldPre) then gets its vmcnt(0) INSIDE the loop (tests/test_isa.py caught it)
+}
+__device__ __forceinline__ f5_f32x2 f5_fma2(f5_f32x2 a, f5_f32x2 b, f5_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 __device__ __forceinline__ int swz_off(int row, int chunk) {
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
@@ -120,8 +132,8 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                         const float partner = __shfl_xor(v, 1, 64);
                         if (rowok && colok[nb]) {
                             if (c < 2 * p.dmodel) {
-                                const float o = (c & 1) ? (v * rc[ri][nb] + partner * rs[ri][nb])
-                                                        : (v * rc[ri][nb] - partner * rs[ri][nb]);
+                                // (explicit product + fma: the same two roundings as the transposed tiles, whatever the compiler contracts)
+                                const float o = __builtin_fmaf((c & 1) ? partner : -partner, rs[ri][nb], v * rc[ri][nb]);
                                 op16_t h, l;
                                 f5_split(o, h, l);
                                 p.out_bf[0][(size_t)row * p.ldob + c] = h;
@@ -204,6 +216,21 @@ __device__ __forceinline__ void fold_prefetch_tr(const F5GemmArgs& p, FoldPre& f
     f.c[0] = p.fold_c1[col0 + lane];
     f.c[1] = p.fold_c2[col0 + lane];
 }
+// The requests are issued BEFORE the prologue's operand loads and pinned right behind the wait for the first K tile (which they are
+// older than): no register load is pending while the K loop runs.  Left pending across the loop (round 4), the compiler guards every
+// register it believes such a load may still write -- a changed register allocation was enough to put a `s_waitcnt vmcnt(0)` in front
+// of an address temporary INSIDE the loop: every K step drained the operand ring (tests/test_isa.py flags such a wait).  All fields are
+// defined on every path (a field loaded on one path and undefined on the other escapes the pin: the phi is a different register).
+__device__ __forceinline__ void fold_prefetch_pin(FoldPre& f) {
+    asm volatile("" : "+v"(f.rr[0]), "+v"(f.rr[1]), "+v"(f.rr[2]), "+v"(f.rr[3]), "+v"(f.c[0]), "+v"(f.c[1]), "+v"(f.c[2]), "+v"(f.c[3]));
+}
+__device__ __forceinline__ void fold_prefetch_clear(FoldPre& f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f.rr[i] = f5_f32x2{0.0f, 0.0f};
+        f.c[i] = 0.0f;
+    }
+}
 template <int MBW>
 __device__ __forceinline__ void fold_prefetch_v(const F5GemmArgs& p, FoldPre& f, int row0, int col0, int lane) {
     const f5_f32x2* rf = reinterpret_cast<const f5_f32x2*>(p.fold_rowf);
@@ -250,10 +277,13 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
             c1col[nb] = 0.0f;
         }
     }
-    if (FOLD) {                                          // the row factors requested before the K loop, spread to the wave through LDS
-#pragma unroll
-        for (int i = 0; i < (32 * MBW + 63) / 64; ++i)
-            if (i * 64 + lane < 32 * MBW) *reinterpret_cast<f5_f32x2*>(&fl[2 * (i * 64 + lane)]) = pre->rr[i];
+    if (FOLD) {                                          // the row factors requested before the K loop, spread to the wave through LDS,
+#pragma unroll                                           // planar: fl[row] = rstd, fl[32 MBW + row] = rstd (mean - m): four consecutive rows
+        for (int i = 0; i < (32 * MBW + 63) / 64; ++i)   // of either are one 16-byte read = two register PAIRS for the packed fold
+            if (i * 64 + lane < 32 * MBW) {
+                fl[i * 64 + lane] = pre->rr[i][0];
+                fl[32 * MBW + i * 64 + lane] = pre->rr[i][1];
+            }
         __builtin_amdgcn_wave_barrier();
     }
     const bool is_v = VONLY || ((EPI == EPI_QKV_ROPE) && (colbase >= 2 * p.dmodel));   // VONLY: the q / k tiles went elsewhere
@@ -288,6 +318,21 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
                     }
                 }
             }
+            // bias + GELU on register PAIRS (two consecutive rows of the lane's column), in place: packed-f32 arithmetic, see f5_bc2
+            if (EPI != EPI_QKV_ROPE) {
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    const f5_f32x2 bv = f5_bc2(bcol[nb]);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f5_f32x2 t = f5_f32x2{acc[mb][nb][r], acc[mb][nb][r + 1]} + bv;
+                        if (EPI == EPI_GELU_TANH) t = f5_gelu_tanh2(t);
+                        if (EPI == EPI_GELU_ERF_BF16) t = f5_f32x2{f5_gelu_erf(t[0]), f5_gelu_erf(t[1])};
+                        acc[mb][nb][r] = t[0];
+                        acc[mb][nb][r + 1] = t[1];
+                    }
+                }
+            }
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
 #pragma unroll
@@ -296,13 +341,11 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
                     const int lrow = ri + 8 * rg + 4 * hi;
 #pragma unroll
                     for (int nb = 0; nb < NBW; ++nb) {
-                        float v = acc[mb][nb][r] + bcol[nb];
-                        if (EPI == EPI_GELU_TANH) v = f5_gelu_tanh(v);
-                        if (EPI == EPI_GELU_ERF_BF16) v = f5_gelu_erf(v);
+                        float v = EPI != EPI_QKV_ROPE ? acc[mb][nb][r] : acc[mb][nb][r] + bcol[nb];
                         if (EPI == EPI_QKV_ROPE) {
                             const float partner = __shfl_xor(v, 1, 64);
                             const float c = rc[rg][ri][nb & (PAR - 1)], sn = rs[rg][ri][nb & (PAR - 1)];
-                            v = (lcol & 1) ? (v * c + partner * sn) : (v * c - partner * sn);
+                            v = __builtin_fmaf((lcol & 1) ? partner : -partner, sn, v * c);   // even column v c - partner s, odd v c + partner s
                         }
                         op16_t h, l;
                         f5_split(v, h, l);
@@ -345,20 +388,26 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
                             float v[4];
+                            const f32x16& ac = acc[mq * MP + mb][nb];
+                            const f5_f32x2 a01 = {ac[rg * 4 + 0], ac[rg * 4 + 1]}, a23 = {ac[rg * 4 + 2], ac[rg * 4 + 3]};
+                            f5_f32x2 v01, v23;
                             if (FOLD) {
-                                // rows (mq*MP + mb)*32 + rg*8 + 4*hi + [0, 4): their (rstd, rstd*mean) pairs are 32 contiguous bytes
-                                const float* fr = fl + 2 * ((mq * MP + mb) * 32 + rg * 8 + 4 * hi);
-                                const f32x4 f01 = *reinterpret_cast<const f32x4*>(fr);
-                                const f32x4 f23 = *reinterpret_cast<const f32x4*>(fr + 4);
-                                const float d = bcol[nb], c = c1col[nb];
-                                v[0] = f01[0] * acc[mq * MP + mb][nb][rg * 4 + 0] + (d - f01[1] * c);
-                                v[1] = f01[2] * acc[mq * MP + mb][nb][rg * 4 + 1] + (d - f01[3] * c);
-                                v[2] = f23[0] * acc[mq * MP + mb][nb][rg * 4 + 2] + (d - f23[1] * c);
-                                v[3] = f23[2] * acc[mq * MP + mb][nb][rg * 4 + 3] + (d - f23[3] * c);
+                                // rows (mq*MP + mb)*32 + rg*8 + 4*hi + [0, 4): their rstd / rstd (mean - m) quads (planar scratch)
+                                const int r4 = (mq * MP + mb) * 32 + rg * 8 + 4 * hi;
+                                const f32x4 rs4 = *reinterpret_cast<const f32x4*>(fl + r4);
+                                const f32x4 rm4 = *reinterpret_cast<const f32x4*>(fl + 32 * MBW + r4);
+                                const f5_f32x2 dv = f5_bc2(bcol[nb]), ncv = f5_bc2(-c1col[nb]);
+                                v01 = f5_fma2(f5_f32x2{rs4[0], rs4[1]}, a01, f5_fma2(f5_f32x2{rm4[0], rm4[1]}, ncv, dv));
+                                v23 = f5_fma2(f5_f32x2{rs4[2], rs4[3]}, a23, f5_fma2(f5_f32x2{rm4[2], rm4[3]}, ncv, dv));
                             } else {
-#pragma unroll
-                                for (int ri = 0; ri < 4; ++ri) v[ri] = acc[mq * MP + mb][nb][rg * 4 + ri] + bcol[nb];
+                                const f5_f32x2 bv = f5_bc2(bcol[nb]);
+                                v01 = a01 + bv;
+                                v23 = a23 + bv;
                             }
+                            v[0] = v01[0];
+                            v[1] = v01[1];
+                            v[2] = v23[0];
+                            v[3] = v23[1];
                             const u32x2 pk = part == 0 ? u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])}
                                                        : u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
                             const int tok = mb * 32 + rg * 8 + 4 * hi;
@@ -451,32 +500,47 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
         const int rowblk = row0 + mb * 32;
         f5_f32x2 rr = {1.0f, 0.0f};
         if (FOLD) rr = rrv[mb];
+        const f5_f32x2 r0v = f5_bc2(rr[0]), nr1v = f5_bc2(-rr[1]);       // the lane's row factors, broadcast to both halves of a pair
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                float v[4];
                 const f32x4 c1q = FOLD ? c1r[nb][rg] : f32x4{0.f, 0.f, 0.f, 0.f}, c2q = b4[nb][rg];
+                f5_f32x2 v[2];                                           // features (rg*4 + 0, 1) and (rg*4 + 2, 3) of this token
 #pragma unroll
-                for (int ri = 0; ri < 4; ++ri) {
-                    v[ri] = FOLD ? rr[0] * acc[mb][nb][rg * 4 + ri] + (c2q[ri] - rr[1] * c1q[ri]) : acc[mb][nb][rg * 4 + ri] + b4[nb][rg][ri];
-                    if (EPI == EPI_GELU_TANH && !F5_PROBE_NOMATH(p)) v[ri] = f5_gelu_tanh(v[ri]);
-                    if (EPI == EPI_GELU_ERF_BF16) v[ri] = f5_gelu_erf(v[ri]);
+                for (int h = 0; h < 2; ++h) {
+                    const f5_f32x2 a = {acc[mb][nb][rg * 4 + 2 * h], acc[mb][nb][rg * 4 + 2 * h + 1]};
+                    const f5_f32x2 c2h = {c2q[2 * h], c2q[2 * h + 1]};
+                    if (FOLD) {
+                        const f5_f32x2 c1h = {c1q[2 * h], c1q[2 * h + 1]};
+                        v[h] = f5_fma2(r0v, a, f5_fma2(nr1v, c1h, c2h));  // rstd acc + (c2 - rstd (mean - m) c1)
+                    } else {
+                        v[h] = a + c2h;
+                    }
+                    if (EPI == EPI_GELU_TANH && !F5_PROBE_NOMATH(p)) v[h] = f5_gelu_tanh2(v[h]);
+                    if (EPI == EPI_GELU_ERF_BF16) v[h] = f5_f32x2{f5_gelu_erf(v[h][0]), f5_gelu_erf(v[h][1])};
                 }
                 const int so = lcol * LD + nb * 32 + rg * 8 + hi * 4;
-                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])};
-                if (two) *reinterpret_cast<u32x2*>(&rl[so]) = u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(v[0][0], v[0][1]), f5_pack2(v[1][0], v[1][1])};
+                if (two) *reinterpret_cast<u32x2*>(&rl[so]) = u32x2{f5_pack2_lo(v[0][0], v[0][1]), f5_pack2_lo(v[1][0], v[1][1])};
             }
         __builtin_amdgcn_wave_barrier();
+        // read the staged rows back in ONE batch (inside the `grow < M` blocks every read was waited for on its own in front of its
+        // store: four LDS round trips per 32-row block), then store
+        u32x4 back[32 / RPI];
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) back[i] = *reinterpret_cast<const u32x4*>(&rh[(i * RPI + lane / CPR) * LD + (lane % CPR) * 8]);
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) asm volatile("" : "+v"(back[i]));
 #pragma unroll
         for (int i = 0; i < 32 / RPI; ++i) {
             const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
             const int grow = rowblk + lrow;
             if (F5_PROBE_NOSTORE(p)) {
-                f5_probe_sink(*reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]));
+                f5_probe_sink(back[i]);
             } else if (grow < p.M) {
                 const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
-                *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
+                *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = back[i];
                 if (two) *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
             }
         }
@@ -520,6 +584,7 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
         const int n = row % p.seq_len;
         f5_f32x2 rr = {1.0f, 0.0f};
         if (FOLD) rr = rrv[mb];
+        const f5_f32x2 nr1v = f5_bc2(-rr[1]);
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
             // one batch of loads per 32-feature block: 16 rotation factors + 4 bias quads (the accumulators leave ~90 free VGPRs)
@@ -540,44 +605,54 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
                 }
                 if (FOLD) {
                     const f32x4 c1q = *reinterpret_cast<const f32x4*>(&fl[c - colbase]), c2q = *reinterpret_cast<const f32x4*>(&fl[W + c - colbase]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) b4[rg][e] = c2q[e] - rr[1] * c1q[e];
+                    const f5_f32x2 lo = f5_fma2(nr1v, f5_f32x2{c1q[0], c1q[1]}, f5_f32x2{c2q[0], c2q[1]});
+                    const f5_f32x2 hi2 = f5_fma2(nr1v, f5_f32x2{c1q[2], c1q[3]}, f5_f32x2{c2q[2], c2q[3]});
+                    b4[rg] = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
                 } else {
                     b4[rg] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
-            const float rs_ = FOLD ? rr[0] : 1.0f;
+            const f5_f32x2 rsv = f5_bc2(FOLD ? rr[0] : 1.0f);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                float a0 = acc[mb][nb][rg * 4 + 0], a1 = acc[mb][nb][rg * 4 + 1], a2 = acc[mb][nb][rg * 4 + 2], a3 = acc[mb][nb][rg * 4 + 3];
+                // fold / bias on pairs (packed), then the rotation: the pair (2i, 2i + 1) is one register pair -- its cos product is
+                // one packed multiply, the two sin terms need the halves crossed and stay scalar fmas (a packed form would read a
+                // high half into a low result: the select that must not sit next to MFMAs)
+                f5_f32x2 a01 = {acc[mb][nb][rg * 4 + 0], acc[mb][nb][rg * 4 + 1]}, a23 = {acc[mb][nb][rg * 4 + 2], acc[mb][nb][rg * 4 + 3]};
+                const f5_f32x2 b01 = {b4[rg][0], b4[rg][1]}, b23 = {b4[rg][2], b4[rg][3]};
                 if (FOLD) {
-                    a0 *= rs_;
-                    a1 *= rs_;
-                    a2 *= rs_;
-                    a3 *= rs_;
+                    a01 = f5_fma2(rsv, a01, b01);
+                    a23 = f5_fma2(rsv, a23, b23);
+                } else {
+                    a01 = a01 + b01;
+                    a23 = a23 + b23;
                 }
-                a0 += b4[rg][0];
-                a1 += b4[rg][1];
-                a2 += b4[rg][2];
-                a3 += b4[rg][3];
-                // same expressions as the straight tile: even column v*c - partner*s, odd column v*c + partner*s
-                const float o0 = a0 * c0[rg] - a1 * s0[rg], o1 = a1 * c0[rg] + a0 * s0[rg];
-                const float o2 = a2 * c1[rg] - a3 * s1[rg], o3 = a3 * c1[rg] + a2 * s1[rg];
+                // the same two roundings as the straight tile: even column fma(-partner, s, v c), odd column fma(partner, s, v c)
+                const f5_f32x2 t01 = a01 * f5_bc2(c0[rg]), t23 = a23 * f5_bc2(c1[rg]);
+                const float o0 = __builtin_fmaf(-a01[1], s0[rg], t01[0]), o1 = __builtin_fmaf(a01[0], s0[rg], t01[1]);
+                const float o2 = __builtin_fmaf(-a23[1], s1[rg], t23[0]), o3 = __builtin_fmaf(a23[0], s1[rg], t23[1]);
                 const int so = lcol * LD + nb * 32 + rg * 8 + hi * 4;
                 *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(o0, o1), f5_pack2(o2, o3)};
                 if (two) *reinterpret_cast<u32x2*>(&rl[so]) = u32x2{f5_pack2_lo(o0, o1), f5_pack2_lo(o2, o3)};
             }
         }
         __builtin_amdgcn_wave_barrier();
+        // read the staged rows back in ONE batch (inside the `grow < M` blocks every read was waited for on its own in front of its
+        // store: four LDS round trips per 32-row block), then store
+        u32x4 back[32 / RPI];
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) back[i] = *reinterpret_cast<const u32x4*>(&rh[(i * RPI + lane / CPR) * LD + (lane % CPR) * 8]);
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) asm volatile("" : "+v"(back[i]));
 #pragma unroll
         for (int i = 0; i < 32 / RPI; ++i) {
             const int lrow = i * RPI + lane / CPR, chunk = lane % CPR;
             const int grow = rowblk + lrow;
             if (F5_PROBE_NOSTORE(p)) {
-                f5_probe_sink(*reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]));
+                f5_probe_sink(back[i]);
             } else if (grow < p.M) {
                 const size_t off = (size_t)grow * p.ldob + colbase + chunk * 8;
-                *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = *reinterpret_cast<const u32x4*>(&rh[lrow * LD + chunk * 8]);
+                *reinterpret_cast<u32x4*>(p.out_bf[0] + off) = back[i];
                 if (two) *reinterpret_cast<u32x4*>(p.out_bf[1] + off) = *reinterpret_cast<const u32x4*>(&rl[lrow * LD + chunk * 8]);
             }
         }

@@ -34,7 +34,10 @@ namespace F5_NS {
         __builtin_amdgcn_sched_barrier(0);     \
     }
 
-template <int EPI, bool QT>
+// FOLD: the LN-fold consumer (F5GemmArgs::fold_*) as its own instantiation -- its requests are issued and pinned on EVERY path of the
+// kernel (a request under a run-time condition leaves the compiler's wait bookkeeping "pending" on the other path, and it then guards the
+// registers inside the K loop: gemm_dev.hpp fold_prefetch_pin), and the plain kernels carry none of it
+template <int EPI, bool QT, bool FOLD>
 __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int tiles_n, int ntiles, int tiles_m) {
     constexpr int AH = 64 * BK;                 // elements of an A half (64 rows)
     constexpr int BH = 128 * BK;                // elements of a B half (128 rows)
@@ -163,13 +166,31 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // ---- prologue: steps 0 and 1 (slots 0, 1); step 0 must have landed
+    // LN fold: what the epilogue needs from memory is requested here, ahead of the operand loads (gemm_dev.hpp fold_prefetch_pin)
+    static_assert(!FOLD || EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH, "fold consumers");
+    constexpr bool fold = FOLD;
+    const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
+    constexpr bool TR_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
+    const bool tr_path = (TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel);       // workgroup-uniform
+    FoldPre fpre;
+    fold_prefetch_clear(fpre);
+    if (fold) {                                         // (waves past the last row read clamped rows and never use them)
+        if (tr_path) fold_prefetch_tr<2>(p, fpre, row0, col0, lane);
+        else fold_prefetch_v<2>(p, fpre, row0, col0, lane);
+    }
+
+    // ---- prologue: steps 0 and 1 (slots 0, 1); step 0 must have landed.  With the fold, step 0 (and the requests above, which are
+    // older) is waited for in full and pinned before step 1 is issued: step 1 has a whole K step to land either way
     RS_ISSUE_A(0);
     RS_ISSUE_B(0);
+    if (fold) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fold_prefetch_pin(fpre);
+    }
     if (1 < T) {
         RS_ISSUE_A(SLOT);
         RS_ISSUE_B(SLOT);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (!fold) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -222,12 +243,7 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
 
     op16_t* stage = smem + wave * 4608;                 // 9 KB of private epilogue staging per wave (32 x (64 + 8) hi + lo)
     float* fl = reinterpret_cast<float*>(smem + 8 * 4608) + wave * 128;     // behind the eight stages: row factors of a folded LN-modulate
-    const bool fold = (EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH) && p.fold_rowf != nullptr;
-    const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
-    constexpr bool TR_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
-    FoldPre fpre;                                       // (FOLD epilogues: their operands are requested before the K loop)
-    if ((TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel)) {       // workgroup-uniform
-        if (fold && active) fold_prefetch_tr<2>(p, fpre, row0, col0, lane);
+    if (tr_path) {
         for (int tt = 0; tt < T; ++tt) RS_STEP(tt, true);
         if (wm == 0) RS_BARRIER();                      // group 0 waits for group 1's last MATRIX segment: the ring is dead
         if ((p.debug_flags & 1) || !active) return;
@@ -241,7 +257,6 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
         else staged_epilogue_tr<EPI, 2, 2>(p, acc, stage, row0, col0, lane);
         return;
     }
-    if (QT && fold && active) fold_prefetch_v<2>(p, fpre, row0, col0, lane);
     for (int tt = 0; tt < T; ++tt) RS_STEP(tt, false);
     if (wm == 0) RS_BARRIER();
     if (p.debug_flags & 1) {
@@ -277,10 +292,14 @@ static int launch_rs128(const F5GemmArgs& a, hipStream_t stream) {
     const int ntiles = tiles_m * tiles_n;
     F5GemmArgs ab = a;
     if (a.bias != nullptr && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) ab.debug_flags |= 16384;
+    constexpr bool CAN_FOLD = EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH;
+    const bool fold = CAN_FOLD && ab.fold_rowf != nullptr;     // (f5_launch_gemm has checked the fold's preconditions: transposed q / k tiles)
     if (EPI == EPI_QKV_ROPE && ab.rope_cos_tk != nullptr) {
-        hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, EPI == EPI_QKV_ROPE>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        if (fold) hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, EPI == EPI_QKV_ROPE, CAN_FOLD>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        else hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, EPI == EPI_QKV_ROPE, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
     } else {
-        hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        if (fold) hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, false, CAN_FOLD>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        else hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, false, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
     }
     F5_LAUNCH_CHECK();
     return 0;

@@ -12,7 +12,7 @@ m = DiT.from_config(F5TTS_335M, precision="f16", device=dev)
 m.load_weights(synthetic_weights(F5TTS_335M, seed=42))
 f5 = F5TTS(transformer=m)
 res = {}
-for B in (8, 32):
+for B in (1, 8, 32):
     cond, text, y0, _ = bench.synth_batch(B, 0, dev)
     kw = dict(duration=bench.N_FRAMES, steps=32, method="euler", cfg_strength=2.0, sway_sampling_coef=-1.0, use_graph=True)
     ts = []
