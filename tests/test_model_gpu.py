@@ -1316,9 +1316,15 @@ def test_real_checkpoint_tooling_on_a_synthetic_directory(tmp_path):
     import real_checkpoint_parity as RP
     wl, _ = RP.load_checkpoint(str(mdir))
     assert set(wl) >= {k for k in w if "inv_freq" not in k} and all(np.array_equal(wl[k], w[k]) for k in w if k in wl)
-    res = RP.run(str(mdir), steps=3, seconds=1.0, precisions=("f16", "bf16x3"))
+    res = RP.run(str(mdir), steps=3, seconds=1.0, precisions=("f16", "bf16x3"), batch=4)
     print(json.dumps({k: v for k, v in res.items() if k != "operand_peaks"}), "\n", json.dumps(res["operand_peaks"], indent=0)[:1500])
     assert res["mel_l1"]["bf16x3"] <= 1e-4 and res["mel_l1"]["f16"] <= MEL_L1_TOL and all(res["finite"].values())
+    # round 5: what the LN fold would meet on this checkpoint, and the fold forced on next to the fold off at batch 4
+    st = res["layer_norm_statistics"]
+    assert st["row_mean_over_sigma_max"] > 0 and st["mean_drift_over_sigma_max"] >= 0 and res["ln_fold_operand_peak_estimate"] < 65504.0 / 8
+    lf = res["ln_fold"]["f16"]
+    assert lf["fold_on"]["finite"] and not lf["fold_on"]["fell_back"] and lf["operand_range_fallbacks"] == 0 and lf["fold_on"]["ln_fold_after"] == 1
+    assert lf["fold_on"]["mel_l1_vs_oracle"] <= MEL_L1_TOL and lf["fold_off"]["mel_l1_vs_oracle"] <= MEL_L1_TOL
     assert res["largest_operand"] < 65504.0 / 8 and any("attention q" in k for k in res["operand_peaks"]) and any("ff.ff.layers.2" in k for k in res["operand_peaks"])
     env = dict(os.environ, F5_WEIGHTS=str(mdir))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--ode-points", "3", "--no-sub", "--no-cpu-baseline"],

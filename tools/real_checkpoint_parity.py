@@ -8,7 +8,13 @@ weights -- no checkpoint is reachable offline.  Where one is, this tool answers 
      RoPE'd q and k, v, attention output into the out-projection, GELU output into FF2, conv-pos input, text-path pwconv inputs) --
      the f16 mode saturates at +-65 504 (op16.hpp f5_sat); anything within ~2x of that means: run this checkpoint in bf16x3 / bf16.
 
-    python tools/real_checkpoint_parity.py /path/to/F5-TTS-dir [--steps 5] [--seconds 6.0] [--precisions f16,bf16,bf16x3]
+  3. (round 5) what the LN fold (engine option "ln_fold", default on from 22 000 rows) would meet: per LayerNorm of the fp32 oracle run
+     the largest row mean in units of the row's sigma, the largest MOVE of a row mean since the previous LayerNorm (what the shifted
+     operand still carries; DESIGN.md section 3: the folded error stays within 2x the unfolded one up to ~1 sigma of drift) and the largest
+     |x - previous mean| (times |1 + scale| it must stay below 65 504 in f16); and, with --batch B >= 4, the engine with the fold
+     FORCED ON next to the fold off on B copies of the utterance, with the count of operand-range fallbacks.
+
+    python tools/real_checkpoint_parity.py /path/to/F5-TTS-dir [--steps 5] [--seconds 6.0] [--precisions f16,bf16,bf16x3] [--batch 4]
 
 The directory is what F5TTS.from_pretrained reads: model_v1.safetensors (upstream or MLX key names) + vocab.txt.  The oracle is test
 infrastructure: this tool is a checker, nothing on the product path imports it.  tests/test_model_gpu.py runs it on a synthetic
@@ -50,6 +56,23 @@ def recording_oracle(cfg, weights):
         def __init__(self, *a, **k):
             super().__init__(*a, **k)
             self.peaks, self._pending = {}, 0
+            self.ln = dict(row_mean_over_sigma_max=0.0, mean_drift_over_sigma_max=0.0, shifted_abs_max=0.0, adaln_one_plus_scale_abs_max=0.0)
+            self._prev_mean = None
+
+        def layer_norm(self, x, weight=None, bias=None, eps=1e-6):
+            if weight is None and x.shape[-1] == self.cfg.dim:      # the block / final adaLN LayerNorms of the residual stream
+                mu = x.mean(-1, keepdim=True)
+                sig = x.std(-1, unbiased=False, keepdim=True) + 1e-12
+                self.ln["row_mean_over_sigma_max"] = max(self.ln["row_mean_over_sigma_max"], float((mu.abs() / sig).max()))
+                if self._prev_mean is not None and self._prev_mean.shape == mu.shape:
+                    self.ln["mean_drift_over_sigma_max"] = max(self.ln["mean_drift_over_sigma_max"], float(((mu - self._prev_mean).abs() / sig).max()))
+                    self.ln["shifted_abs_max"] = max(self.ln["shifted_abs_max"], float((x - self._prev_mean).abs().max()))
+                self._prev_mean = mu
+            return O.DiTOracle.layer_norm(x, weight, bias, eps)
+
+        def forward(self, *a, **k):
+            self._prev_mean = None
+            return super().forward(*a, **k)
 
         def _note(self, site, x):
             v = float(x.abs().max())
@@ -65,6 +88,9 @@ def recording_oracle(cfg, weights):
             if lowp:
                 self._note("A operand of " + re.sub(r"\.\d+\.", ".N.", name), x)
             y = super().linear(x, name, lowp)
+            if name.endswith("attn_norm.linear"):            # (shift, scale, gate) x 2: the scales are chunks 1 and 4
+                ch = y.chunk(6, dim=1)
+                self.ln["adaln_one_plus_scale_abs_max"] = max(self.ln["adaln_one_plus_scale_abs_max"], float((1 + ch[1]).abs().max()), float((1 + ch[4]).abs().max()))
             if name.endswith(".attn.to_v"):
                 self._pending = 3
             return y
@@ -78,7 +104,7 @@ def recording_oracle(cfg, weights):
 
 
 def run(path: str, steps: int = 5, seconds: float = 6.0, precisions=("f16", "bf16", "bf16x3"), device: str = "cuda:0", wav: str | None = None,
-        text: str = "Some call me nature, others call me mother nature.") -> dict:
+        text: str = "Some call me nature, others call me mother nature.", batch: int = 1) -> dict:
     import dataclasses
     from oracle import f5_oracle as O   # checker only
     from f5_tts_mlx_amd.cfm import F5TTS
@@ -104,6 +130,11 @@ def run(path: str, steps: int = 5, seconds: float = 6.0, precisions=("f16", "bf1
     res = dict(checkpoint=os.path.abspath(path), frames=int(duration), ref_frames=int(n_ref), ode_points=steps, forwards=2 * (steps - 1),
                oracle_mel_abs_mean=float(ref.abs().mean()), mel_l1={}, operand_peaks={k: round(v, 3) for k, v in sorted(orc.peaks.items())})
     worst = max(orc.peaks.values())
+    res["layer_norm_statistics"] = {k: round(v, 4) for k, v in orc.ln.items()}
+    res["ln_fold_operand_peak_estimate"] = orc.ln["shifted_abs_max"] * orc.ln["adaln_one_plus_scale_abs_max"]
+    res["ln_fold_verdict"] = ("the folded operand (x - m)(1 + s) stays below 65504 / 8 and the row means move by <= 1 sigma between LayerNorms: "
+                              "the fold is as accurate as the unfolded path here" if (res["ln_fold_operand_peak_estimate"] * 8 <= F16_MAX and orc.ln["mean_drift_over_sigma_max"] <= 1.0)
+                              else "check the ln_fold lines below: large operand or fast-moving row means")
     res["largest_operand"] = worst
     res["f16_headroom"] = F16_MAX / worst
     res["verdict"] = ("f16 operands have >= 8x headroom on this input" if worst * 8 <= F16_MAX else
@@ -118,6 +149,28 @@ def run(path: str, steps: int = 5, seconds: float = 6.0, precisions=("f16", "bf1
         res.setdefault("finite", {})[prec] = bool(torch.isfinite(out).all())
         del m
         torch.cuda.empty_cache()
+    if batch >= 4:
+        # the LN fold needs the staged GEMM kernels (batch >= 4 at this size): B copies of the utterance, fold forced on vs off
+        import warnings
+        condb, y0b, charsb = cond.repeat(batch, 1, 1), y0.repeat(batch, 1, 1), chars * batch
+        res["ln_fold"] = {}
+        for prec in [p_ for p_ in precisions if p_ in ("f16", "bf16")]:
+            m = DiT.from_config(cfg, precision=prec, device=device)
+            m.load_weights(weights)
+            m.engine.range_check = "sync"
+            row = {}
+            for opt in (0, 1):
+                m.engine.set_option("ln_fold", opt)
+                with warnings.catch_warnings(record=True) as wlist:
+                    warnings.simplefilter("always")
+                    out, _ = F5TTS(transformer=m, vocab_char_map=vocab).sample(condb, charsb, duration=duration, y0=y0b, use_graph=False, **kw)
+                    torch.cuda.synchronize()
+                row["fold_on" if opt else "fold_off"] = dict(mel_l1_vs_oracle=float((out[0].cpu() - ref[0]).abs().mean()), finite=bool(torch.isfinite(out).all()),
+                                                             fell_back=bool(wlist), ln_fold_after=m.engine.get_option("ln_fold"))
+            row["operand_range_fallbacks"] = m.engine.range_events
+            res["ln_fold"][prec] = row
+            del m
+            torch.cuda.empty_cache()
     return res
 
 
@@ -128,5 +181,6 @@ if __name__ == "__main__":
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--precisions", default="f16,bf16,bf16x3")
     ap.add_argument("--wav", default=None)
+    ap.add_argument("--batch", type=int, default=1, help=">= 4: also run B copies with the LN fold forced on / off (engine option ln_fold)")
     a = ap.parse_args()
-    print(json.dumps(run(a.path, a.steps, a.seconds, tuple(a.precisions.split(",")), wav=a.wav), indent=1))
+    print(json.dumps(run(a.path, a.steps, a.seconds, tuple(a.precisions.split(",")), wav=a.wav, batch=a.batch), indent=1))
