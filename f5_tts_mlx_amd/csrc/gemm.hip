@@ -792,32 +792,50 @@ __global__ __launch_bounds__(256) void f5_fold_consts_kernel(const op16_t* __res
     }
 }
 
-// Slice statistics -> row factors.  A slice carries (sum d, sum (d - its own mean)^2) of 64 values d = x - m; the slices are merged
-// one after the other with Chan's update (mean += delta 64 / n, M2 += M2_slice + delta^2 n_old 64 / n): every term is a sum of
-// squares, nothing of the size of mean^2 is ever subtracted (the round-4 kernel computed E[x^2] - E[x]^2 from one-pass sums).
+// Slice statistics -> row factors.  A slice carries (sum d, sum (d - its own mean)^2) of 64 values d = x - m; the row's statistics are
+// the group form of Chan's merge -- mean = sum of the slice sums / n, M2 = sum of the slice M2 + 64 sum (slice mean - mean)^2: every
+// term is a sum of squares, nothing of the size of mean^2 is ever subtracted (the round-4 kernel computed E[x^2] - E[x]^2 from one-pass
+// sums).  NS = 16 (dim 1024): all slice loads of a row are independent and issued together.
+template <int NS>
 __global__ __launch_bounds__(256) void f5_fold_rows_kernel(const float* __restrict__ stats, int ld, int nslice, int M, float eps,
                                                            float* __restrict__ rowf, float* __restrict__ row_shift) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     const f5_f32x2* sp = reinterpret_cast<const f5_f32x2*>(stats) + m;
     const float shift0 = row_shift != nullptr ? row_shift[m] : 0.0f;
-    float mean = 0.0f, m2 = 0.0f;
-#pragma unroll 8
-    for (int i = 0; i < nslice; ++i) {                  // slice order: deterministic
-        const f5_f32x2 t = sp[(size_t)i * ld];
-        const float delta = t[0] * (1.0f / 64.0f) - mean;
-        const float inv = 1.0f / (float)(i + 1);        // 64 / n
-        mean += delta * inv;
-        m2 += t[1] + delta * delta * (64.0f * (float)i * inv);
+    float mean, m2 = 0.0f;
+    const float inv_n = 1.0f / (64.0f * (float)nslice);
+    if (NS > 0) {
+        f5_f32x2 t[NS > 0 ? NS : 1];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) t[i] = sp[(size_t)i * ld];
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s += t[i][0];          // slice order: deterministic
+        mean = s * inv_n;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const float dm = t[i][0] * (1.0f / 64.0f) - mean;
+            m2 += t[i][1] + 64.0f * dm * dm;
+        }
+    } else {
+        float s = 0.0f;
+        for (int i = 0; i < nslice; ++i) s += sp[(size_t)i * ld][0];
+        mean = s * inv_n;
+        for (int i = 0; i < nslice; ++i) {
+            const f5_f32x2 t = sp[(size_t)i * ld];
+            const float dm = t[0] * (1.0f / 64.0f) - mean;
+            m2 += t[1] + 64.0f * dm * dm;
+        }
     }
-    const float var = m2 / (64.0f * (float)nslice);
-    const float rstd = rsqrtf(var + eps);
+    const float rstd = rsqrtf(m2 * inv_n + eps);
     reinterpret_cast<f5_f32x2*>(rowf)[m] = f5_f32x2{rstd, rstd * mean};
     if (row_shift != nullptr) row_shift[m] = shift0 + mean;
 }
 int f5_launch_fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, float* row_shift, hipStream_t stream) {
     F5_REQUIRE(stats && rowf && nslice >= 1 && M >= 1 && ld >= M, "fold_rows: bad arguments");
-    hipLaunchKernelGGL(f5_fold_rows_kernel, dim3(f5_cdiv(M, 256)), dim3(256), 0, stream, stats, ld, nslice, M, eps, rowf, row_shift);
+    if (nslice == 16) hipLaunchKernelGGL(f5_fold_rows_kernel<16>, dim3(f5_cdiv(M, 256)), dim3(256), 0, stream, stats, ld, nslice, M, eps, rowf, row_shift);
+    else hipLaunchKernelGGL(f5_fold_rows_kernel<0>, dim3(f5_cdiv(M, 256)), dim3(256), 0, stream, stats, ld, nslice, M, eps, rowf, row_shift);
     F5_LAUNCH_CHECK();
     return 0;
 }

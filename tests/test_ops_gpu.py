@@ -964,6 +964,15 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
         assert float((rf[:M, 1:2] - rstd * mean_d).abs().max()) <= 2e-5 * float((rstd * mean_d).abs().max() + 1.0)
         # fold_rows leaves the row's mean behind: the next producer's shift
         assert float((shift_d.cpu().double()[:, None] - mean).abs().max()) <= 2e-6 * float(mean.abs().max() + var.sqrt().max())
+        # the generic slice count (the 16-slice case above is the unrolled instantiation): the first 8 slices as a 512-wide row, no shift
+        rowf8 = torch.zeros((M, 2), device=DEV)
+        E.check(lib.f5_op_fold_rows(P(stats), 8, M, P(rowf8), P(None), stream()), "fold_rows (8 slices)")
+        sync()
+        d8 = dsh.double()[:, :512]
+        m8, v8 = d8.mean(-1, keepdim=True), d8.var(-1, unbiased=False, keepdim=True)
+        r8 = (v8 + 1e-6).rsqrt()
+        assert float((rowf8.cpu().double()[:, 0:1] / r8 - 1.0).abs().max()) <= 2e-5
+        assert float((rowf8.cpu().double()[:, 1:2] - r8 * m8).abs().max()) <= 2e-5 * float((r8 * m8).abs().max() + 1.0)
         # --- constants, for both consumers
         w1, bias1 = randn(r, FF, D, scale=D ** -0.5), randn(r, FF, scale=0.1)
         wq, biasq = randn(r, 3 * D, D, scale=D ** -0.5), randn(r, 3 * D, scale=0.1)

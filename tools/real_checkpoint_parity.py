@@ -163,7 +163,11 @@ def run(path: str, steps: int = 5, seconds: float = 6.0, precisions=("f16", "bf1
                 m.engine.set_option("ln_fold", opt)
                 with warnings.catch_warnings(record=True) as wlist:
                     warnings.simplefilter("always")
-                    out, _ = F5TTS(transformer=m, vocab_char_map=vocab).sample(condb, charsb, duration=duration, y0=y0b, use_graph=False, **kw)
+                    try:
+                        out, _ = F5TTS(transformer=m, vocab_char_map=vocab).sample(condb, charsb, duration=duration, y0=y0b, use_graph=False, **kw)
+                    except RuntimeError as exc:                 # ln_fold = 1 where the block GEMMs do not run on the staged kernels
+                        row["fold_on"] = dict(cannot_run=str(exc)[-160:], rows=2 * batch * int(duration))
+                        continue
                     torch.cuda.synchronize()
                 row["fold_on" if opt else "fold_off"] = dict(mel_l1_vs_oracle=float((out[0].cpu() - ref[0]).abs().mean()), finite=bool(torch.isfinite(out).all()),
                                                              fell_back=bool(wlist), ln_fold_after=m.engine.get_option("ln_fold"))
