@@ -585,34 +585,24 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
         f5_f32x2 rr = {1.0f, 0.0f};
         if (FOLD) rr = rrv[mb];
         const f5_f32x2 nr1v = f5_bc2(-rr[1]);
-        // the rotation factors of the whole 32-token block (both 32-feature halves: 2 x 16 registers) in ONE batch of loads: one memory
-        // round trip per block instead of one per half
-        float fc0[NBW][4], fc1[NBW][4], fs0[NBW][4], fs1[NBW][4];
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int j0 = ((colbase + nb * 32 + rg * 8 + hi * 4) & 63) >> 1;
-                if (F5_PROBE_NOMATH(p)) {
-                    fc0[nb][rg] = fc1[nb][rg] = 1.0f;
-                    fs0[nb][rg] = fs1[nb][rg] = 0.0f;
-                } else {
-                    fc0[nb][rg] = ct[(size_t)j0 * p.rope_ldt + n];
-                    fc1[nb][rg] = ct[(size_t)(j0 + 1) * p.rope_ldt + n];
-                    fs0[nb][rg] = st[(size_t)j0 * p.rope_ldt + n];
-                    fs1[nb][rg] = st[(size_t)(j0 + 1) * p.rope_ldt + n];
-                }
-            }
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-            const float* c0 = fc0[nb];
-            const float* c1 = fc1[nb];
-            const float* s0 = fs0[nb];
-            const float* s1 = fs1[nb];
+            // one batch of loads per 32-feature block: 16 rotation factors + 4 bias quads (the accumulators leave ~90 free VGPRs)
+            float c0[4], c1[4], s0[4], s1[4];
             f32x4 b4[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int c = colbase + nb * 32 + rg * 8 + hi * 4;
+                const int j0 = (c & 63) >> 1;
+                if (F5_PROBE_NOMATH(p)) {
+                    c0[rg] = c1[rg] = 1.0f;
+                    s0[rg] = s1[rg] = 0.0f;
+                } else {
+                    c0[rg] = ct[(size_t)j0 * p.rope_ldt + n];
+                    c1[rg] = ct[(size_t)(j0 + 1) * p.rope_ldt + n];
+                    s0[rg] = st[(size_t)j0 * p.rope_ldt + n];
+                    s1[rg] = st[(size_t)(j0 + 1) * p.rope_ldt + n];
+                }
                 if (FOLD) {
                     const f32x4 c1q = *reinterpret_cast<const f32x4*>(&fl[c - colbase]), c2q = *reinterpret_cast<const f32x4*>(&fl[W + c - colbase]);
                     const f5_f32x2 lo = f5_fma2(nr1v, f5_f32x2{c1q[0], c1q[1]}, f5_f32x2{c2q[0], c2q[1]});

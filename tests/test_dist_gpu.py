@@ -1,6 +1,6 @@
 """The multi-GPU protocol with the REAL engine in more than one process: two ranks share the one GPU of the
 test box and talk over gloo (RCCL refuses two ranks on one device; the collective is the only thing that differs from the 8-GPU
-job).  Rank 0 owns the weights, the arena travels by ONE broadcast, rank 1 marks it loaded and finalises, every rank samples
+job); where two devices are visible the same protocol also runs over nccl (= RCCL), one rank per device.  Rank 0 owns the weights, the arena travels by ONE broadcast, rank 1 marks it loaded and finalises, every rank samples
 its shard of a RAGGED batch padded to the GLOBAL maximum duration (`dist.shard_batch`), rank 0 gathers -- and the gathered
 result must equal the single-process batch bit for bit."""
 import os

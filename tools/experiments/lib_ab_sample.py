@@ -12,11 +12,11 @@ m = DiT.from_config(F5TTS_335M, precision="f16", device=dev)
 m.load_weights(synthetic_weights(F5TTS_335M, seed=42))
 f5 = F5TTS(transformer=m)
 res = {}
-for B in (1, 8, 32):
+for B in [int(b) for b in os.environ.get("F5_AB_BATCHES", "1,8,32").split(",")]:
     cond, text, y0, _ = bench.synth_batch(B, 0, dev)
     kw = dict(duration=bench.N_FRAMES, steps=32, method="euler", cfg_strength=2.0, sway_sampling_coef=-1.0, use_graph=True)
     ts = []
-    for rep in range(3):
+    for rep in range(int(os.environ.get("F5_AB_REPS", "3"))):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out, _ = f5.sample(cond, text, y0=y0, **kw)
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
