@@ -194,7 +194,8 @@ __device__ __forceinline__ void glds16(const op16_t* gptr, op16_t* lds_wave_base
 }
 
 // ---- LN-modulate folded into the consumer GEMM (F5GemmArgs::fold_*)
-// What a FOLD epilogue needs from memory, requested BEFORE the K loop (10 registers through the loop): a one-workgroup-per-CU kernel
+// What a FOLD epilogue needs from memory, requested BEFORE the K loop -- since round 5 ahead of the prologue's operand loads and pinned
+// behind the first K tile's wait, see fold_prefetch_pin -- (10 registers through the loop): a one-workgroup-per-CU kernel
 // has nothing to hide a load round trip at the head of its epilogue behind -- requested there it cost 1 us per tile (round 4:
 // +8 us on the FF1 launch of batch 32, +4 on QKV).  Transposed tiles (lane = token): rr[mb] = row factors of the lane's token in each
 // 32-row block, c[0] / c[1] = c1 / c2 of column col0 + lane.  Straight V tiles (lane = feature, rows in registers): rr[i] = row factors
