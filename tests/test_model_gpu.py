@@ -1004,12 +1004,13 @@ def test_f16_range_stress_with_the_ln_fold_active():
     """VERDICT r4 "next" #2(a), model level: the outlier-weight stress of the test above at batch 12 x 937 frames, where the LN fold is
     ACTIVE by default (22 488 rows), against `bf16x3` (fp32-class, never folds), with the fold off next to it: the folded path must stay
     finite, inside the gate wherever the unfolded f16 path is, and no further from `bf16x3` than 1.5x the unfolded path + 1e-4.  Also
-    carries a residual-stream offset: the conv-pos / input-projection bias is raised so that row means sit at tens of sigma (what the
-    round-4 formulation lost precision on, profiles/r05/ln_fold_numerics_study.jsonl)."""
+    carries a residual-stream offset: the input-projection bias is raised by 30, which puts the row means of the residual stream at
+    ~11 sigma in every block (checked with the oracle: 3.1 sigma for +8, proportional) -- what the round-4 formulation lost a factor
+    ~10 of operand precision on (profiles/r05/ln_fold_numerics_study.jsonl)."""
     import bench
     cfg = F5TTS_335M
     base = synthetic_weights(cfg, seed=42)
-    base["transformer.input_embed.proj.bias"] = base["transformer.input_embed.proj.bias"] + 8.0      # row means of ~10 sigma at block 0
+    base["transformer.input_embed.proj.bias"] = base["transformer.input_embed.proj.bias"] + 30.0     # row means of ~11 sigma in every block
     cond, text, y0, _ = bench.synth_batch(12, 0, DEV)
     r = np.random.default_rng(11)
     N = 937
