@@ -6,6 +6,9 @@ utterance), solved by the fp32 CPU oracle (oracle/f5_oracle.py, pinned to the re
                              the key-padding mask exists and keeps every key).  The oracle's batch elements do not interact at equal
                              durations, so the first B rows are also the oracle's answer for the batch of the first B utterances
                              (B = 2, 4, 8): one file serves the batch-2 ... 16 tests of the mid-size GEMM dispatch.
+  full_b32_euler5.npz        bench.py's utterances 0..31 = BASELINE configs[2]'s batch (the configuration the roofline is quoted on) at the
+                             same 5-point solve: rows 16..31 are solved here, rows 0..15 are taken from full_b16_euler5.npz (the
+                             same oracle call on the same inputs; the elements of an equal-duration batch do not interact).
   full_b8_ragged_euler5.npz  a RAGGED batch of 8: durations 937 ... 500, text padded with -1 by a different amount per utterance
                              (cfm.py:317-336, dit.py:160-173: key mask, attention output rows zeroed at padded positions, GRN and
                              conv-pos over the padded length).
@@ -13,7 +16,7 @@ utterance), solved by the fp32 CPU oracle (oracle/f5_oracle.py, pinned to the re
 Inputs are regenerated from the seeds; only the oracle's final mels are stored, rounded to 17 significant bits (relative 4e-6:
 two orders below the 1e-3 gate, and the file compresses to a third).  ~25 + 10 minutes of CPU on 8 cores:
 
-    python tests/golden/make_batch_golden.py [--which b16|ragged|all]
+    python tests/golden/make_batch_golden.py [--which b16|b32|ragged|all]     (b32: another ~25 minutes, needs the b16 file)
 """
 import argparse
 import os
@@ -70,7 +73,7 @@ def mel_of(waves: np.ndarray) -> np.ndarray:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="all", choices=["b16", "ragged", "all"])
+    ap.add_argument("--which", default="all", choices=["b16", "b32", "ragged", "all"])
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     ns = ap.parse_args()
     torch.set_num_threads(ns.threads)
@@ -91,6 +94,22 @@ def main():
         out = np.concatenate(outs)
         np.savez_compressed(os.path.join(HERE, "full_b16_euler5.npz"), out=round_mantissa(out), points=np.int32(POINTS))
         print("wrote full_b16_euler5.npz", out.shape, float(np.abs(out).mean()))
+    if ns.which in ("b32", "all"):
+        first = np.load(os.path.join(HERE, "full_b16_euler5.npz"))["out"]
+        items = [utterance(i) for i in range(16, 32)]
+        cond = mel_of(np.stack([it[0] for it in items]))
+        text = np.stack([it[1] for it in items])
+        y0 = np.stack([it[2] for it in items])
+        outs = [first]
+        t0 = time.time()
+        for c0 in range(0, 16, 4):
+            sl = slice(c0, c0 + 4)
+            out, _ = O.sample(orc, torch.from_numpy(cond[sl]), torch.from_numpy(text[sl]), N_FRAMES, y0=torch.from_numpy(y0[sl]), **KW)
+            outs.append(round_mantissa(out.numpy().astype(np.float32)))
+            print(f"b32: utterances {16 + c0}..{16 + c0 + 3} done, {time.time() - t0:.0f} s", flush=True)
+        out = np.concatenate(outs)
+        np.savez_compressed(os.path.join(HERE, "full_b32_euler5.npz"), out=out, points=np.int32(POINTS))
+        print("wrote full_b32_euler5.npz", out.shape, float(np.abs(out).mean()))
     if ns.which in ("ragged", "all"):
         waves, text, y0, dur = ragged_inputs()
         cond = mel_of(waves)
