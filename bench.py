@@ -603,7 +603,8 @@ def main():
             "rtf_mel_only": head["rtf_mel_only"],
             "weights_load_s": load_s, "weights_broadcast_ms": bcast_ms, "ranks_seen_by_rccl": ranks_in_group,
             "rank_ms_min": rank_ms_min, "rank_ms_max": rank_ms_max,
-            "ln_fold_range_events": model.engine.range_events,
+            "ln_fold_range_events": model.engine.range_events, "fp16_saturation_events": model.engine.saturation_events,
+            "range_check": model.engine.range_check,
             "roofline": dominant, "roofline_kernels": kernels, "roofline_symbol_shares": sym,
         }
         if dominant.get("peak_measured_tflops"):

@@ -275,13 +275,17 @@ class F5TTS:
     def from_pretrained(cls, hf_model_name_or_path: str, convert_weights=None, quantization_bits: int | None = None,
                         precision: str = "f16", device: str = "cuda:0",
                         vocoder_name_or_path: str | None = "lucasnewman/vocos-mel-24khz",
-                        allow_missing_vocoder: bool = False) -> "F5TTS":
+                        allow_missing_vocoder: bool = False, verify_precision: bool = True) -> "F5TTS":
         """cfm.py:404-520.  Loads `model_v1.safetensors` (or `model_v1_{4,8}b.safetensors`) + `vocab.txt` (+ the duration
         predictor `duration_v2.safetensors` when present) from a local directory or the HF hub (network required), and the
         Vocos vocoder (cfm.py:446) from `vocoder_name_or_path`, `$F5_VOCOS_PATH`, or the hub.  MLX int4/int8 checkpoints are
         expanded to fp32 on load (weights.dequantize_mlx_checkpoint) and run like a full-precision checkpoint.  If the vocoder
         cannot be found this raises, like the reference's `Vocos.from_pretrained` (cfm.py:446); pass
-        `allow_missing_vocoder=True` (or `vocoder_name_or_path=None`) to get a model whose sample() returns mel frames."""
+        `allow_missing_vocoder=True` (or `vocoder_name_or_path=None`) to get a model whose sample() returns mel frames.
+        verify_precision (precision "f16" only; no reference counterpart): the FIRST sample() call of the loaded checkpoint is also run
+        in precision "bf16x3" and compared (engine.Engine `verify_calls`); if fp16's 11 significand bits lose more than the 1e-3 parity
+        gate on it the model warns and stays on bf16x3.  Synthetic weights pass with a margin of 2.5-4; a real checkpoint has never been
+        run here, so it is checked instead of trusted."""
         path = fetch_from_hub(hf_model_name_or_path, quantization_bits=quantization_bits)
         if path is None:
             raise ValueError(f"Could not find model {hf_model_name_or_path}")
@@ -345,4 +349,6 @@ class F5TTS:
             duration_predictor=duration_predictor,
         )
         f5tts.load_weights(weights)
+        if verify_precision and precision == "f16":
+            f5tts.transformer.engine.verify_calls = 1
         return f5tts

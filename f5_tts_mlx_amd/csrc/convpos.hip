@@ -5,6 +5,7 @@
 // so x is read from HBM once per block; the per-tap weight slab [64 co][64 ci] is double-buffered.
 // Sequence edges are zero padded per batch element (Conv1d padding); no mask (dit.py:251 passes none).
 #include "convpos.hpp"
+#include "rowops.hpp"     // f5_sat_flag_host
 
 namespace F5_NS {
 
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
     // stores issued so far -- the stores of a lane went out one memory round trip apart
     float bias2[2] = {p.bias[g * 64 + lr], p.bias[g * 64 + 32 + lr]};
     asm volatile("" : "+v"(bias2[0]), "+v"(bias2[1]));
+    f5_sat_t trk;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int co = g * 64 + nb * 32 + lr;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
                 const size_t off = (rowbase + n) * p.ldo + co;
                 if (p.mode == 0) {
                     op16_t h, l;
-                    f5_split(v, h, l);
+                    f5_split(v, h, l, trk);
                     p.out_bf[0][off] = h;
                     if (p.out_bf[1]) p.out_bf[1][off] = l;
                 } else {
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256) void f5_convpos_kernel(F5ConvPosArgs p) {
             }
         }
     }
+    f5_sat_commit(trk, p.sat_flag);
 }
 
 int f5_convpos_tps = 0;   // taps per pipeline step: 0 auto, 1 / 2 / 4 forced (f5_debug_set_convpos_tps)
@@ -190,16 +193,18 @@ int f5_launch_convpos(const F5ConvPosArgs& a, hipStream_t stream) {
     // (batch 1: 19.8 / 21.1 / 21.3 us for 1 / 2 / 4; batch 32: 304 / 355 / 629 us); 2 and 4 stay selectable for experiments
     int tps = f5_convpos_tps;
     if (tps == 0) tps = 1;
+    F5ConvPosArgs ab = a;
+    if (ab.sat_flag == nullptr) ab.sat_flag = f5_sat_flag_host;
     if (a.nseg == 3) {
         F5_REQUIRE(a.in[1] && a.W[1], "convpos: bf16x3 needs lo operands");
-        if (tps > 1) hipLaunchKernelGGL((f5_convpos_kernel<true, 2>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((f5_convpos_kernel<true, 1>), grid, dim3(256), 0, stream, a);
+        if (tps > 1) hipLaunchKernelGGL((f5_convpos_kernel<true, 2>), grid, dim3(256), 0, stream, ab);
+        else hipLaunchKernelGGL((f5_convpos_kernel<true, 1>), grid, dim3(256), 0, stream, ab);
     } else if (tps >= 4) {
-        hipLaunchKernelGGL((f5_convpos_kernel<false, 4>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((f5_convpos_kernel<false, 4>), grid, dim3(256), 0, stream, ab);
     } else if (tps >= 2) {
-        hipLaunchKernelGGL((f5_convpos_kernel<false, 2>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((f5_convpos_kernel<false, 2>), grid, dim3(256), 0, stream, ab);
     } else {
-        hipLaunchKernelGGL((f5_convpos_kernel<false, 1>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((f5_convpos_kernel<false, 1>), grid, dim3(256), 0, stream, ab);
     }
     F5_LAUNCH_CHECK();
     return 0;

@@ -26,6 +26,7 @@ struct F5ConvPosArgs {
     op16_t* out_bf[2];
     float* out_f32;
     int ldo;
+    int* sat_flag;        // where mode 0's 16-bit pack reports saturation (fp16 build, op16.hpp); null = rowops.hpp f5_sat_flag_host
 };
 
 int f5_launch_convpos(const F5ConvPosArgs& a, hipStream_t stream);

@@ -92,6 +92,7 @@ struct F5Options {
     int ln_fold = -1;     // LN-modulate folded into the GEMMs around it (gemm.hpp fold_*): -1 = where it is measured faster (>= LN_FOLD_AUTO_ROWS
                           // rows and the four block GEMMs on the staged kernels, one-pass operand modes), 0 = never, 1 = wherever it can run
                           // (batch >= 4 at the 335M shape; fails loudly elsewhere)
+    int sat_check = 1;    // precision f16: every 16-bit operand producer reports values beyond +-65 504 in the status word (bit 2); 0 = A/B
     int null_keeps_cond = 0;   // the second (null) branch keeps the audio conditioning: DiT.__call__(drop_audio_cond=False, drop_text=True), dit.py:374-401
 };
 static F5Options g_default_options;
@@ -333,8 +334,9 @@ extern "C" int f5_engine_set_option(f5_engine* e, const char* name, int value) {
     else if (n == "attn_pipe") e->opt.attn_pipe = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "null_keeps_cond") e->opt.null_keeps_cond = value ? 1 : 0;
     else if (n == "ln_fold") e->opt.ln_fold = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "sat_check") e->opt.sat_check = value ? 1 : 0;
     else {
-        f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags, attn_pipe, null_keeps_cond, ln_fold)", name);
+        f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags, attn_pipe, null_keeps_cond, ln_fold, sat_check)", name);
         return 2;
     }
     return 0;
@@ -349,6 +351,7 @@ extern "C" int f5_engine_get_option(f5_engine* e, const char* name, int* value) 
     else if (n == "attn_pipe") *value = e->opt.attn_pipe;
     else if (n == "null_keeps_cond") *value = e->opt.null_keeps_cond;
     else if (n == "ln_fold") *value = e->opt.ln_fold;
+    else if (n == "sat_check") *value = e->opt.sat_check;
     else {
         f5_set_error("unknown engine option %s", name);
         return 2;
@@ -994,6 +997,17 @@ static int run_dit(const Ctx& c, int j) {
     return 0;
 }
 
+// fp16 range detector (op16.hpp): while one of these is alive the 16-bit packers of every launch of the fp16 build report
+// saturation into the call's status word (bit F5_STATUS_SATURATED).  Host-side: the pointer travels as a kernel argument, a captured
+// graph keeps the status word of the workspace it was captured against (part of the graph key).
+struct SatScope {
+    int* saved;
+    SatScope(const f5_engine* e, int* status_word) : saved(f5hf::f5_sat_flag_host) {
+        if (e->prec == F5_PREC_F16 && e->opt.sat_check) f5hf::f5_sat_flag_host = status_word;
+    }
+    ~SatScope() { f5hf::f5_sat_flag_host = saved; }
+};
+
 static int run_sample_body(const Ctx& c, const f5_sample_args* a) {
     const f5_config& cf = c.e->cfg;
     const Workspace& w = c.w;
@@ -1139,6 +1153,7 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     F5_REQUIRE(a->workspace_bytes >= c.w.total, "workspace too small: %zu < %zu", a->workspace_bytes, c.w.total);
     const int mel = e->cfg.mel_dim;
     const size_t M1 = (size_t)c.B * c.N;
+    SatScope sat(e, c.p<int>(c.w.status));
 
     // function-evaluation times and step sizes in fp32, as the solvers compute them (cfm.py:50-56,76-86,106-114)
     std::vector<float> tnfe, dts;
@@ -1163,8 +1178,8 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d nk%d lf%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, e->opt.null_keeps_cond, e->opt.ln_fold, g_knob_epoch,
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d nk%d lf%d sc%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, e->opt.null_keeps_cond, e->opt.ln_fold, e->opt.sat_check, g_knob_epoch,
              a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
@@ -1274,6 +1289,7 @@ extern "C" int f5_dit_forward(f5_engine* e, const f5_sample_args* a, const float
     F5_REQUIRE(a->workspace_bytes >= c.w.total, "workspace too small: %zu < %zu", a->workspace_bytes, c.w.total);
     const int mel = e->cfg.mel_dim;
     const size_t M1 = (size_t)c.B * c.N;
+    SatScope sat(e, c.p<int>(c.w.status));
     std::vector<float> tnfe(1, t), dts(1, 0.0f);
     RC(stage_inputs(c, &a2, x, tnfe, dts));
     const Ops& K = c.ops;
@@ -1476,6 +1492,11 @@ extern "C" int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_
 }
 extern "C" int f5_debug_set_op_ln_mean_out(float* mean_out) {
     g_op_fold.ln_mean_out = mean_out;
+    return 0;
+}
+// op-level tests: where the 16-bit packers of the f5_op_* launches that follow report saturation (fp16 operand build; null = nowhere)
+extern "C" int f5_debug_set_op_sat_flag(int* flag) {
+    f5hf::f5_sat_flag_host = flag;
     return 0;
 }
 static int* g_op_fold_overflow = nullptr;

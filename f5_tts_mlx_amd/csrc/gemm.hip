@@ -12,6 +12,7 @@
 // at 3x the matrix work.
 #include "gemm.hpp"
 #include "gemm_dev.hpp"
+#include "rowops.hpp"     // f5_sat_flag_host
 #include "lnrow.hpp"
 #ifndef F5_LAB
 #define F5_LAB 0
@@ -961,6 +962,7 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
 int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
     F5GemmArgs a = a_in;
     a.debug_flags |= f5_gemm_debug_flags;      // process-wide flags on top of the caller's (an engine's own option)
+    if (a.sat_flag == nullptr) a.sat_flag = f5_sat_flag_host;      // fp16 range detector of the 16-bit epilogues (op16.hpp), or null
     F5_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % BK == 0, "gemm: bad shape M=%d N=%d K=%d (K must be a multiple of %d)",
                a.M, a.N, a.K, BK);
     F5_REQUIRE(a.nseg == 1 || a.nseg == 3, "gemm: nseg must be 1 or 3");

@@ -81,6 +81,9 @@ struct F5GemmArgs {
     int stats_ld;             // rows per slice of stats_out (>= M)
     int* x16_overflow;        // or null: bit 0 is set when a value of x (1 + s) does not fit the operand type (fp16 build: |v| > 65 504 or
                               // not finite -- the un-normalised residual stream is the one operand producer without a natural bound)
+    int* sat_flag;            // or null: F5_STATUS_SATURATED (4) is ORed in when a 16-bit OUTPUT of this launch (q / k / v, the GELU output, a plain
+                              // 16-bit tile) went through the fp16 clamp (op16.hpp f5_sat_commit; f5_launch_gemm fills in rowops.hpp
+                              // f5_sat_flag_host when this is null)
     const float* fold_rowf;   // [M][2] (rstd, rstd * (mean - m)) or null = plain GEMM
     const float* fold_c1;     // [N], 16-byte aligned
     const float* fold_c2;     // [N], 16-byte aligned

@@ -46,6 +46,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                                                int lane) {
     const int hi = lane >> 5;
     const int lcol = lane & 31;
+    f5_sat_t trk;                  // fp16 build: largest magnitude that goes through a 16-bit pack (op16.hpp), reported at the end
     int col[NB];
     bool colok[NB];
     float bcol[NB], gcol[NB];
@@ -135,7 +136,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                                 // (explicit product + fma: the same two roundings as the transposed tiles, whatever the compiler contracts)
                                 const float o = __builtin_fmaf((c & 1) ? partner : -partner, rs[ri][nb], v * rc[ri][nb]);
                                 op16_t h, l;
-                                f5_split(o, h, l);
+                                f5_split(o, h, l, trk);
                                 p.out_bf[0][(size_t)row * p.ldob + c] = h;
                                 if (p.out_bf[1]) p.out_bf[1][(size_t)row * p.ldob + c] = l;
                             } else {
@@ -143,7 +144,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                                 const int head = c2 >> 6, d = c2 & 63;
                                 const size_t off = ((size_t)(b * p.heads + head) * 64 + d) * p.npad + n;
                                 op16_t h, l;
-                                f5_split(v, h, l);
+                                f5_split(v, h, l, trk);
                                 p.vt[0][off] = h;
                                 if (p.vt[1]) p.vt[1][off] = l;
                             }
@@ -155,7 +156,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                             if (EPI == EPI_GELU_TANH) v = f5_gelu_tanh(v);
                             if (EPI == EPI_GELU_ERF_BF16) v = f5_gelu_erf(v);
                             op16_t h, l;
-                            f5_split(v, h, l);
+                            f5_split(v, h, l, trk);
                             p.out_bf[0][(size_t)row * p.ldob + c] = h;
                             if (p.out_bf[1]) p.out_bf[1][(size_t)row * p.ldob + c] = l;
                         } else if (EPI == EPI_GELU_ERF) {
@@ -171,7 +172,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
                             v += pre[r][nb];
                             p.out_f32[(size_t)row * p.ldo + c] = v;
                             op16_t h, l;
-                            f5_split(v, h, l);
+                            f5_split(v, h, l, trk);
                             p.out_bf[0][(size_t)row * p.ldob + c] = h;
                             if (p.out_bf[1]) p.out_bf[1][(size_t)row * p.ldob + c] = l;
                         } else if (EPI == EPI_RESID_KEEP) {
@@ -184,6 +185,7 @@ __device__ __forceinline__ void gemm_epilogue(const F5GemmArgs& p, f32x16 (&acc)
             }
         }
     }
+    f5_sat_commit(trk, p.sat_flag);
 }
 
 #define V2_HALF_ELEMS (128 * BK)
@@ -266,6 +268,8 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
     constexpr int RPI = 64 / CPR;          // rows per store instruction
     const int hi = lane >> 5, lcol = lane & 31;
     const bool two = p.out_bf[1] != nullptr;
+    f5_sat_t trk;
+    f5_sat_s trkv;                         // V tiles: the scalar form (no VGPR to spare there, op16.hpp)
     float bcol[NBW], c1col[NBW];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
@@ -349,7 +353,7 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
                             v = __builtin_fmaf((lcol & 1) ? partner : -partner, sn, v * c);   // even column v c - partner s, odd v c + partner s
                         }
                         op16_t h, l;
-                        f5_split(v, h, l);
+                        f5_split(v, h, l, trk);
                         rh[lrow * LD + nb * 32 + lcol] = h;
                         if (two) rl[lrow * LD + nb * 32 + lcol] = l;
                     }
@@ -409,7 +413,7 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
                             v[1] = v01[1];
                             v[2] = v23[0];
                             v[3] = v23[1];
-                            const u32x2 pk = part == 0 ? u32x2{f5_pack2(v[0], v[1]), f5_pack2(v[2], v[3])}
+                            const u32x2 pk = part == 0 ? u32x2{f5_pack2(v[0], v[1], trkv), f5_pack2(v[2], v[3], trkv)}
                                                        : u32x2{f5_pack2_lo(v[0], v[1]), f5_pack2_lo(v[2], v[3])};
                             const int tok = mb * 32 + rg * 8 + 4 * hi;
                             *reinterpret_cast<u32x2*>(&reg[(nb * 32 + lcol) * TLD + tok]) = pk;
@@ -447,6 +451,8 @@ __device__ __forceinline__ void staged_epilogue_bf16(const F5GemmArgs& p, f32x16
             }
         }
     }
+    f5_sat_commit(trk, p.sat_flag);
+    f5_sat_commit(trkv, p.sat_flag);
 }
 
 // 16-bit row-major outputs (FF1 + GELU, plain 16-bit) from a TRANSPOSED accumulator tile, D = W A^T: lane = token, registers =
@@ -467,6 +473,7 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
     const bool two = p.out_bf[1] != nullptr;
     op16_t* rh = reg;
     op16_t* rl = reg + 32 * LD;
+    f5_sat_t trk;
     f32x4 b4[NBW][4];                      // bias of the lane's feature groups (the same for every 32-token block)
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
@@ -522,7 +529,7 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
                     if (EPI == EPI_GELU_ERF_BF16) v[h] = f5_f32x2{f5_gelu_erf(v[h][0]), f5_gelu_erf(v[h][1])};
                 }
                 const int so = lcol * LD + nb * 32 + rg * 8 + hi * 4;
-                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(v[0][0], v[0][1]), f5_pack2(v[1][0], v[1][1])};
+                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(v[0][0], v[0][1], trk), f5_pack2(v[1][0], v[1][1], trk)};
                 if (two) *reinterpret_cast<u32x2*>(&rl[so]) = u32x2{f5_pack2_lo(v[0][0], v[0][1]), f5_pack2_lo(v[1][0], v[1][1])};
             }
         __builtin_amdgcn_wave_barrier();
@@ -547,6 +554,7 @@ __device__ __forceinline__ void staged_epilogue_tr(const F5GemmArgs& p, f32x16 (
         }
         __builtin_amdgcn_wave_barrier();
     }
+    f5_sat_commit(trk, p.sat_flag);
 }
 
 // The q / k column tiles of the QKV projection from a TRANSPOSED accumulator tile (256x256 kernel): as staged_epilogue_tr, with the
@@ -568,6 +576,7 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
     const float* st = isq ? p.rope_sin_tq : p.rope_sin_tk;
     op16_t* rh = reg;
     op16_t* rl = reg + 32 * LD;
+    f5_sat_t trk;
     f5_f32x2 rrv[MBW];
     if (FOLD) {                                              // as staged_epilogue_tr: FoldPre -> registers / LDS scratch
         static_assert(!FOLD || W == 64, "one column of c1 | c2 per lane");
@@ -633,7 +642,7 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
                 const float o0 = __builtin_fmaf(-a01[1], s0[rg], t01[0]), o1 = __builtin_fmaf(a01[0], s0[rg], t01[1]);
                 const float o2 = __builtin_fmaf(-a23[1], s1[rg], t23[0]), o3 = __builtin_fmaf(a23[0], s1[rg], t23[1]);
                 const int so = lcol * LD + nb * 32 + rg * 8 + hi * 4;
-                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(o0, o1), f5_pack2(o2, o3)};
+                *reinterpret_cast<u32x2*>(&rh[so]) = u32x2{f5_pack2(o0, o1, trk), f5_pack2(o2, o3, trk)};
                 if (two) *reinterpret_cast<u32x2*>(&rl[so]) = u32x2{f5_pack2_lo(o0, o1), f5_pack2_lo(o2, o3)};
             }
         }
@@ -659,6 +668,7 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
         }
         __builtin_amdgcn_wave_barrier();
     }
+    f5_sat_commit(trk, p.sat_flag);
 }
 
 // x += gate * ((acc + bias) * keep)  (dit.py:319,323): fp32 tile staged [32 rows][W+4] so that the read-modify-write of

@@ -22,7 +22,7 @@ namespace F5_NS {
 template <int NV>
 __device__ __forceinline__ void f5_ln_modulate_row(const f32x4 (&v)[NV], const float* __restrict__ scale,
                                                    const float* __restrict__ shift, op16_t* __restrict__ out_hi,
-                                                   op16_t* __restrict__ out_lo, size_t row, int lane, float eps) {
+                                                   op16_t* __restrict__ out_lo, size_t row, int lane, float eps, int* sat_flag = nullptr) {
     constexpr int DIM = NV * 256;
     // the modulation vectors do not depend on the row: all of them are requested before the reductions.  Loaded chunk by chunk
     // inside the output loop, each chunk cost a full memory round trip behind the previous chunk's store (the compiler's
@@ -48,6 +48,7 @@ __device__ __forceinline__ void f5_ln_modulate_row(const f32x4 (&v)[NV], const f
         }
     const float var = f5_wave_sum(sq) * (1.0f / DIM);
     const float rstd = rsqrtf(var + eps);
+    f5_sat_t trk;                                      // fp16 build: the modulated row is an MFMA operand without a hard bound (op16.hpp)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
@@ -55,9 +56,10 @@ __device__ __forceinline__ void f5_ln_modulate_row(const f32x4 (&v)[NV], const f
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
-        *reinterpret_cast<u32x2*>(out_hi + row * DIM + c) = u32x2{f5_pack2(y[0], y[1]), f5_pack2(y[2], y[3])};
+        *reinterpret_cast<u32x2*>(out_hi + row * DIM + c) = u32x2{f5_pack2(y[0], y[1], trk), f5_pack2(y[2], y[3], trk)};
         if (out_lo) *reinterpret_cast<u32x2*>(out_lo + row * DIM + c) = u32x2{f5_pack2_lo(y[0], y[1]), f5_pack2_lo(y[2], y[3])};
     }
+    f5_sat_commit(trk, sat_flag);
 }
 
 }  // namespace F5_NS

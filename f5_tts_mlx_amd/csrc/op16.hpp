@@ -70,6 +70,53 @@ __device__ inline uint32_t f5_pack2_bounded(float a, float b) {
     const f5_f32x2 v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f5_op16x2));
 }
+// ---- range detector of the fp16 build (round 6).  Every producer of a 16-bit MFMA operand keeps the largest magnitude it packs
+// (one v_max3_f32 per PAIR: the clamp above hides an overflow, this does not) and ORs F5_STATUS_SATURATED into the call's status
+// word when a value beyond +-65 504 went through f5_sat -- once per wave and kernel, and only on a hit.  In the bf16 build the
+// tracker is empty and every call compiles away (bf16 has fp32's range).
+#define F5_STATUS_SATURATED 4
+#if F5_F16
+struct f5_sat_t {
+    float m = 0.0f;
+};
+__device__ __forceinline__ void f5_sat_see(f5_sat_t& t, float a) { t.m = fmaxf(t.m, fabsf(a)); }
+__device__ __forceinline__ void f5_sat_see2(f5_sat_t& t, float a, float b) { t.m = fmaxf(fmaxf(t.m, fabsf(a)), fabsf(b)); }
+__device__ __forceinline__ void f5_sat_commit(const f5_sat_t& t, int* flag) {
+    // every lane that saw one reports it (a rare path; callers may sit inside divergent code, so no "lane 0 speaks for the wave");
+    // inf counts, NaN does not reach here: fmaxf drops it
+    if (flag != nullptr && t.m > 65504.0f) atomicOr(flag, F5_STATUS_SATURATED);
+}
+// the same detector WITHOUT a vector register: the hit mask of the wave is ORed into a scalar pair (one v_max_f32 + one v_cmp per
+// pair instead of one v_max3_f32).  For code that has no VGPR to spare -- the V tiles of the 256 x 256 QKV kernel sit at 256 registers
+// and spilled with the one-register tracker (tests/test_isa.py).
+struct f5_sat_s {
+    unsigned long long hit = 0;
+};
+__device__ __forceinline__ void f5_sat_see2(f5_sat_s& t, float a, float b) { t.hit |= __builtin_amdgcn_ballot_w64(fmaxf(fabsf(a), fabsf(b)) > 65504.0f); }
+__device__ __forceinline__ void f5_sat_commit(const f5_sat_s& t, int* flag) {
+    if (flag != nullptr && t.hit != 0) atomicOr(flag, F5_STATUS_SATURATED);
+}
+#else
+struct f5_sat_t {};
+struct f5_sat_s {};
+__device__ __forceinline__ void f5_sat_see2(f5_sat_s&, float, float) {}
+__device__ __forceinline__ void f5_sat_commit(const f5_sat_s&, int*) {}
+__device__ __forceinline__ void f5_sat_see(f5_sat_t&, float) {}
+__device__ __forceinline__ void f5_sat_see2(f5_sat_t&, float, float) {}
+__device__ __forceinline__ void f5_sat_commit(const f5_sat_t&, int*) {}
+#endif
+__device__ inline uint32_t f5_pack2(float a, float b, f5_sat_t& t) {
+    f5_sat_see2(t, a, b);
+    return f5_pack2(a, b);
+}
+__device__ inline uint32_t f5_pack2(float a, float b, f5_sat_s& t) {
+    f5_sat_see2(t, a, b);
+    return f5_pack2(a, b);
+}
+__device__ inline void f5_split(float f, op16_t& hi, op16_t& lo, f5_sat_t& t) {
+    f5_sat_see(t, f);
+    f5_split(f, hi, lo);
+}
 __device__ inline uint32_t f5_pack2_lo(float a, float b) {
     const float ra = a - static_cast<float>(static_cast<op16_t>(a));
     const float rb = b - static_cast<float>(static_cast<op16_t>(b));

@@ -6,6 +6,13 @@
 
 namespace F5_NS {
 
+// The status word the 16-bit packers of the NEXT launches report saturation to (op16.hpp f5_sat_commit), or null.  Host-side, set by
+// the engine around a call (engine.hip SatScope) and by f5_debug_set_op_sat_flag for the op-level tests; the launchers of this file,
+// of convpos.hip and f5_launch_gemm pass it to their kernels by value (a captured graph keeps the pointer it was captured with: the
+// status word of its workspace).
+int* f5_sat_flag_host = nullptr;
+
+
 // =================================================================================================
 // LayerNorm (no affine) + adaLN modulation: one wave per row, NV float4 per lane (dim = NV*256)
 // =================================================================================================
@@ -14,9 +21,10 @@ namespace F5_NS {
 template <int NV, bool WITH_MEAN>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, op16_t* __restrict__ out_hi,
-                                                          op16_t* __restrict__ out_lo, int rows, float eps, float* __restrict__ mean_out) {
+                                                          op16_t* __restrict__ out_lo, int rows, float eps, float* __restrict__ mean_out,
+                                                          int* sat_flag) {
     constexpr int DIM = NV * 256;
-    asm volatile("" ::"s"(x), "s"(scale), "s"(shift), "s"(out_hi), "s"(out_lo), "s"(rows), "s"(eps), "s"(mean_out));    // one scalar-load clause
+    asm volatile("" ::"s"(x), "s"(scale), "s"(shift), "s"(out_hi), "s"(out_lo), "s"(rows), "s"(eps), "s"(mean_out), "s"(sat_flag));    // one scalar-load clause
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -31,7 +39,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
         const float mean = f5_wave_sum(sum) * (1.0f / DIM);
         if (lane == 0) mean_out[row] = mean;
     }
-    f5_ln_modulate_row<NV>(v, scale, shift, out_hi, out_lo, (size_t)row, lane, eps);
+    f5_ln_modulate_row<NV>(v, scale, shift, out_hi, out_lo, (size_t)row, lane, eps, sat_flag);
 }
 
 int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, op16_t* out_hi, op16_t* out_lo,
@@ -40,9 +48,9 @@ int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift
     const dim3 grid(f5_cdiv(rows, 4)), block(256);
 #define LNM_LAUNCH(NV_)                                                                                                               \
     if (mean_out != nullptr)                                                                                                          \
-        hipLaunchKernelGGL((ln_modulate_kernel<NV_, true>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps, mean_out); \
+        hipLaunchKernelGGL((ln_modulate_kernel<NV_, true>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps, mean_out, f5_sat_flag_host); \
     else                                                                                                                              \
-        hipLaunchKernelGGL((ln_modulate_kernel<NV_, false>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps, mean_out);
+        hipLaunchKernelGGL((ln_modulate_kernel<NV_, false>), grid, block, 0, s, x, scale, shift, out_hi, out_lo, rows, eps, mean_out, f5_sat_flag_host);
     switch (dim / 256) {
         case 1: LNM_LAUNCH(1); break;
         case 2: LNM_LAUNCH(2); break;
@@ -147,12 +155,13 @@ template <int NV>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
                                                         const float* __restrict__ dw_b, const float* __restrict__ ln_w,
                                                         const float* __restrict__ ln_b, op16_t* __restrict__ out_hi,
-                                                        op16_t* __restrict__ out_lo, int rows, int seq_len, float eps) {
+                                                        op16_t* __restrict__ out_lo, int rows, int seq_len, float eps, int* sat_flag) {
     constexpr int DIM = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int b = row / seq_len, n = row - b * seq_len;
+    f5_sat_t trk;
     float y[NV][4];
     float sum = 0.0f;
 #pragma unroll
@@ -187,11 +196,12 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
         float z[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[e] = (y[i][e] - mean) * rstd * ln_w[c + e] + ln_b[c + e];
-        *reinterpret_cast<u32x2*>(out_hi + (size_t)row * DIM + c) = u32x2{f5_pack2(z[0], z[1]), f5_pack2(z[2], z[3])};
+        *reinterpret_cast<u32x2*>(out_hi + (size_t)row * DIM + c) = u32x2{f5_pack2(z[0], z[1], trk), f5_pack2(z[2], z[3], trk)};
         if (out_lo)
             *reinterpret_cast<u32x2*>(out_lo + (size_t)row * DIM + c) =
                 u32x2{f5_pack2_lo(z[0], z[1]), f5_pack2_lo(z[2], z[3])};
     }
+    f5_sat_commit(trk, sat_flag);
 }
 
 int f5_launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
@@ -199,7 +209,7 @@ int f5_launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, co
     F5_REQUIRE(dim % 256 == 0 && dim >= 256 && dim <= 1024, "dwconv_ln: dim must be 256/512/768/1024 (got %d)", dim);
     const int rows = nbatch * seq_len;
     const dim3 grid(f5_cdiv(rows, 4)), block(256);
-#define DW_ARGS x, dw_w, dw_b, ln_w, ln_b, out_hi, out_lo, rows, seq_len, eps
+#define DW_ARGS x, dw_w, dw_b, ln_w, ln_b, out_hi, out_lo, rows, seq_len, eps, f5_sat_flag_host
     switch (dim / 256) {
         case 1: hipLaunchKernelGGL((dwconv_ln_kernel<1>), grid, block, 0, s, DW_ARGS); break;
         case 2: hipLaunchKernelGGL((dwconv_ln_kernel<2>), grid, block, 0, s, DW_ARGS); break;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256) void grn_finish_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict__ g, const float* __restrict__ nx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         op16_t* __restrict__ out_hi, op16_t* __restrict__ out_lo, int seq_len,
-                                                        int dim, size_t total4) {
+                                                        int dim, size_t total4, int* sat_flag) {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i4 >= total4) return;
     const size_t idx = i4 * 4;
@@ -273,8 +283,10 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict_
     float y[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = ga[e] * (gv[e] * nv[e]) + be[e] + gv[e];
-    *reinterpret_cast<u32x2*>(out_hi + idx) = u32x2{f5_pack2(y[0], y[1]), f5_pack2(y[2], y[3])};
+    f5_sat_t trk;
+    *reinterpret_cast<u32x2*>(out_hi + idx) = u32x2{f5_pack2(y[0], y[1], trk), f5_pack2(y[2], y[3], trk)};
     if (out_lo) *reinterpret_cast<u32x2*>(out_lo + idx) = u32x2{f5_pack2_lo(y[0], y[1]), f5_pack2_lo(y[2], y[3])};
+    f5_sat_commit(trk, sat_flag);
 }
 
 int f5_launch_grn(const float* g, const float* gamma, const float* beta, float* partial, float* nx, op16_t* out_hi,
@@ -286,7 +298,7 @@ int f5_launch_grn(const float* g, const float* gamma, const float* beta, float* 
     hipLaunchKernelGGL(grn_finish_kernel, dim3(nbatch), dim3(256), 0, s, partial, nx, dim, nchunk);
     const size_t total4 = (size_t)nbatch * seq_len * dim / 4;
     hipLaunchKernelGGL(grn_apply_kernel, dim3(f5_cdiv((long)total4, 256)), dim3(256), 0, s, g, nx, gamma, beta, out_hi, out_lo,
-                       seq_len, dim, total4);
+                       seq_len, dim, total4, f5_sat_flag_host);
     F5_LAUNCH_CHECK();
     return 0;
 }
@@ -337,12 +349,13 @@ int f5_launch_text_embed(const int* text, int nt, const float* table, const floa
 __global__ __launch_bounds__(256) void pack_cond_text_kernel(const float* __restrict__ cond, const int* __restrict__ lens,
                                                              const float* __restrict__ text_emb, op16_t* __restrict__ out_hi,
                                                              op16_t* __restrict__ out_lo, int B, int seq_len, int mel_dim,
-                                                             int dt, int null_keeps_cond) {
+                                                             int dt, int null_keeps_cond, int* sat_flag) {
     const int n = blockIdx.x, b = blockIdx.y, br = blockIdx.z;
     const int ld = 128 + dt;
     const size_t orow = (((size_t)br * B + b) * seq_len + n) * ld;
     // null_keeps_cond: the second branch is (drop_audio_cond = False, drop_text = True) instead of (True, True), dit.py:245-247 / 209-210
     const bool use_cond = (br == 0 || null_keeps_cond) && (n < lens[b]);
+    f5_sat_t trk;
     for (int c = threadIdx.x; c < ld; c += 256) {
         float v = 0.0f;
         if (c < 128) {
@@ -351,17 +364,18 @@ __global__ __launch_bounds__(256) void pack_cond_text_kernel(const float* __rest
             v = text_emb[(((size_t)br * B + b) * seq_len + n) * dt + (c - 128)];
         }
         op16_t h, l;
-        f5_split(v, h, l);
+        f5_split(v, h, l, trk);
         out_hi[orow + c] = h;
         if (out_lo) out_lo[orow + c] = l;
     }
+    f5_sat_commit(trk, sat_flag);
 }
 
 int f5_launch_pack_cond_text(const float* cond, const int* lens, const float* text_emb, op16_t* out_hi, op16_t* out_lo,
                              int B, int seq_len, int mel_dim, int dt, int null_keeps_cond, hipStream_t s) {
     F5_REQUIRE(mel_dim <= 128, "pack_cond_text: mel_dim must be <= 128");
     hipLaunchKernelGGL(pack_cond_text_kernel, dim3(seq_len, B, 2), dim3(256), 0, s, cond, lens, text_emb, out_hi, out_lo, B,
-                       seq_len, mel_dim, dt, null_keeps_cond);
+                       seq_len, mel_dim, dt, null_keeps_cond, f5_sat_flag_host);
     F5_LAUNCH_CHECK();
     return 0;
 }
@@ -527,19 +541,21 @@ int f5_launch_text_pos_table(float* table, int max_pos, int dim, hipStream_t s) 
 // ODE state plumbing
 // =================================================================================================
 __global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ y, op16_t* __restrict__ out_hi,
-                                                     op16_t* __restrict__ out_lo, int rows, int mel_dim) {
+                                                     op16_t* __restrict__ out_lo, int rows, int mel_dim, int* sat_flag) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)rows * 128) return;
     const size_t row = i >> 7;
     const int c = (int)(i & 127);
     const float v = (c < mel_dim) ? y[row * mel_dim + c] : 0.0f;
     op16_t h, l;
-    f5_split(v, h, l);
+    f5_sat_t trk;
+    f5_split(v, h, l, trk);
     out_hi[i] = h;
     if (out_lo) out_lo[i] = l;
+    f5_sat_commit(trk, sat_flag);
 }
 int f5_launch_pack_x(const float* y, op16_t* out_hi, op16_t* out_lo, int rows, int mel_dim, hipStream_t s) {
-    hipLaunchKernelGGL(pack_x_kernel, dim3(f5_cdiv((long)rows * 128, 256)), dim3(256), 0, s, y, out_hi, out_lo, rows, mel_dim);
+    hipLaunchKernelGGL(pack_x_kernel, dim3(f5_cdiv((long)rows * 128, 256)), dim3(256), 0, s, y, out_hi, out_lo, rows, mel_dim, f5_sat_flag_host);
     F5_LAUNCH_CHECK();
     return 0;
 }
@@ -564,14 +580,18 @@ __global__ __launch_bounds__(256) void ode_stage_kernel(F5OdeArgs p) {
     }
     if (p.xin_hi) {
         op16_t h, l;
-        f5_split(o, h, l);
+        f5_sat_t trk;
+        f5_split(o, h, l, trk);
         p.xin_hi[i] = h;
         if (p.xin_lo) p.xin_lo[i] = l;
+        f5_sat_commit(trk, p.sat_flag);
     }
 }
 int f5_launch_ode_stage(const F5OdeArgs& a, hipStream_t s) {
     F5_REQUIRE(a.mel_dim <= 128, "ode_stage: mel_dim must be <= 128");
-    hipLaunchKernelGGL(ode_stage_kernel, dim3(f5_cdiv((long)a.rows * 128, 256)), dim3(256), 0, s, a);
+    F5OdeArgs ab = a;
+    if (ab.sat_flag == nullptr) ab.sat_flag = f5_sat_flag_host;
+    hipLaunchKernelGGL(ode_stage_kernel, dim3(f5_cdiv((long)a.rows * 128, 256)), dim3(256), 0, s, ab);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,8 @@
 #undef F5_ROWOPS_HPP_BODY
 namespace F5_NS {
 
+extern int* f5_sat_flag_host;   // rowops.hip: where the 16-bit packers of the next launches report saturation (fp16 build), or null
+
 // y = LN(x) * (1 + scale) + shift, LN without affine, eps (dit.py:270,289,321). One wave per row.
 // mean_out (optional, [rows]): the row means -- the shift of the first folded operand that follows (gemm.hpp x16_shift)
 int f5_launch_ln_modulate(const float* x, const float* scale, const float* shift, op16_t* out_hi, op16_t* out_lo,
@@ -77,6 +79,7 @@ struct F5OdeArgs {
     op16_t* xin_hi;
     op16_t* xin_lo;
     int rows, mel_dim;
+    int* sat_flag;           // null = f5_sat_flag_host (op16.hpp f5_sat_commit)
 };
 int f5_launch_ode_stage(const F5OdeArgs& a, hipStream_t s);
 

@@ -152,29 +152,45 @@ def _aligned_bytes(nbytes: int, device: torch.device) -> torch.Tensor:
 
 
 class OperandRangeWarning(RuntimeWarning):
-    """The folded LayerNorm operand left the fp16 range in a call; the engine fell back to the unfolded path."""
+    """A 16-bit MFMA operand left the fp16 range in a call: the folded LayerNorm operand (the engine fell back to the unfolded path) or
+    any other producer (the engine fell back to precision bf16x3)."""
 
 
-RANGE_CHECKS = ("auto", "sync", "async", "off")
+RANGE_CHECKS = ("sync", "auto", "async", "off")
+STATUS_FOLD_OVERFLOW, STATUS_FOLD_RAN, STATUS_SATURATED = 1, 2, 4      # include/f5tts_hip.h F5_STATUS_*
 
 
 class Engine:
     """One engine handle per device.  Not re-entrant (same contract as the C ABI).
 
-    range_check -- what happens to the status word of a call (include/f5tts_hip.h f5_sample_status; only the f16 mode with the LN fold
-    active can set it: the folded operand (x - m)(1 + scale) is the one fp16 MFMA operand without a natural bound):
-      "sync"   read it after every call (one stream synchronisation); on overflow switch this engine's ln_fold to 0, warn
-               (OperandRangeWarning) and RE-RUN the call unfolded: the caller always gets a result that is not saturated
+    range_check -- what happens to the status word of a call (include/f5tts_hip.h f5_sample_status).  Only precision "f16" can set it:
+    bit 0 = the folded LayerNorm operand (x - m)(1 + scale) left the fp16 range (LN fold active, batch >= 12 at the 335M shape), bit 2 =
+    some other 16-bit operand producer (LN-modulate, q / k / v, the GELU output, conv-pos, ...) clamped a value beyond +-65 504 -- at
+    every batch size, every block of every evaluation.  Whether that happens depends on the INPUT (reference audio, text, length) as well
+    as on the checkpoint, so the default looks at every call:
+      "sync"   (default) read the word after every call (one stream synchronisation).  Bit 0: switch this engine's ln_fold to 0, warn
+               (OperandRangeWarning) and RE-RUN the call unfolded.  Bit 2: warn, build a precision-"bf16x3" engine from the host weights
+               this engine was loaded from (fp32-class arithmetic, bf16's range: 3x the matrix work) and RE-RUN the call there; later
+               calls go straight to it.  The caller always gets a result that is not saturated.
       "async"  never block: a 4-byte copy into pinned memory rides behind the call and is looked at when the NEXT call starts (or in
-               synchronize() / check_status()); on overflow warn and switch ln_fold to 0 for the calls that follow -- the flagged call's
-               own output was saturated (finite, clamped at +-65 504) and the warning says so
-      "auto"   (default) "sync" until `range_probation` (3) fold-active calls in a row came back clean, "async" from then on: a
-               checkpoint whose activations do not fit is caught on its first calls with a correct result, the steady state of a
-               service does not block its host thread (one rank of an 8-GPU job no longer synchronises per call)
+               synchronize() / check_status()); the flagged call's own output was saturated (finite, clamped) and the warning says so;
+               the calls that follow run unfolded / on the bf16x3 engine
+      "auto"   "sync" until `range_probation` (3) calls of the SAME shape in a row came back clean, "async" from then on; a new shape
+               starts a new probation
       "off"    ignore the word
+    keep_host_weights -- keep a reference to the dict given to load_weights (no copy) so that the bf16x3 fall-back can be built; without
+    it (or when the arena arrived by broadcast) a saturated call can only be reported.
+
+    verify_calls -- the range detector sees RANGE, not PRECISION: fp16's 11-bit significand can lose a result without any value
+    reaching +-65 504 (large attention logits: outlier q / k rows scaled 300x give a finite, un-clamped mel that is 3.4e-2 off,
+    tests/test_model_gpu.py::test_f16_range_stress_outlier_weights).  The next `verify_calls` sample() calls are therefore ALSO run on
+    the bf16x3 engine and compared (mean |delta| of the final mel against `verify_tol` = the 1e-3 parity gate); beyond it the engine
+    warns (OperandRangeWarning), hands back the bf16x3 result and stays on bf16x3.  0 by default (a cross-check costs a bf16x3 call);
+    F5TTS.from_pretrained sets 1: a real checkpoint is cross-checked on its first call.
     """
 
-    def __init__(self, cfg: DiTConfig, precision: str = "bf16", device: str | torch.device = "cuda:0", range_check: str = "auto"):
+    def __init__(self, cfg: DiTConfig, precision: str = "bf16", device: str | torch.device = "cuda:0", range_check: str = "sync",
+                 keep_host_weights: bool = True):
         if range_check not in RANGE_CHECKS:
             raise ValueError(f"range_check must be one of {RANGE_CHECKS}")
         if precision not in PRECISIONS:
@@ -202,12 +218,23 @@ class Engine:
         self.range_check = range_check
         self.range_probation = 3
         self.range_events = 0                  # calls whose folded operand overflowed (the engine fell back to ln_fold = 0)
-        self._clean_fold_calls = 0
-        # pinned ring of status words: one slot per call whose check is still pending ("async"); a caller that runs 16 calls ahead of
-        # the GPU waits for the oldest one
+        self.saturation_events = 0             # calls in which another 16-bit producer saturated (the engine fell back to bf16x3)
+        self._clean_calls = 0                  # clean calls in a row of the shape `_clean_shape` ("auto")
+        self._clean_shape = None
+        # pinned ring of status words: one slot per call whose check is still pending ("async"); slots are handed out from a free list,
+        # so a synchronous read can never be given the slot of a pending asynchronous one; a caller that runs 16 calls ahead of the GPU
+        # waits for the oldest one
         self._status_host = torch.zeros(16, dtype=torch.int32).pin_memory() if precision == "f16" else None
         self._status_pending: list = []        # [(event, slot, what)] oldest first
-        self._status_slot = 0
+        self._status_free = list(range(16))
+        self.keep_host_weights = bool(keep_host_weights)
+        self._host_weights: Optional[Dict[str, np.ndarray]] = None
+        self._fallback: Optional["Engine"] = None      # the bf16x3 engine (built on demand from the host weights) ...
+        self._use_fallback = False                     # ... and whether calls go to it (a call saturated, or a cross-check failed)
+        self.verify_calls = 0
+        self.verify_tol = 1e-3
+        self.verify_events = 0                         # cross-checks that failed (the engine switched to bf16x3)
+        self.last_verify_l1: Optional[float] = None
 
     def _run_on_side_stream(self, fn):
         cur = torch.cuda.current_stream(self.device)
@@ -236,6 +263,8 @@ class Engine:
             check(self.lib.f5_load_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.ndim, shape),
                   f"f5_load_tensor({name})")
         self.finalize()
+        if self.precision == "f16" and self.keep_host_weights:
+            self._host_weights = weights           # a reference, not a copy: what the bf16x3 fall-back is loaded from
 
     def finalize(self) -> None:
         check(self.lib.f5_finalize_weights(self._h, stream_ptr(self.device)), "f5_finalize_weights")
@@ -249,9 +278,20 @@ class Engine:
         return int(self.lib.f5_engine_graph_count(self._h))
 
     def set_option(self, name: str, value: int) -> None:
-        """Per-engine launch option ("q_premul", "qkv_transposed", "ln_fusion", "gemm_flags", "attn_pipe", "null_keeps_cond", "ln_fold"; include/f5tts_hip.h): other engines of
-        the process keep their own values, cached hipGraphs are keyed on them."""
+        """Per-engine launch option ("q_premul", "qkv_transposed", "ln_fusion", "gemm_flags", "attn_pipe", "null_keeps_cond", "ln_fold",
+        "sat_check"; include/f5tts_hip.h): other engines of the process keep their own values, cached hipGraphs are keyed on them."""
         check(self.lib.f5_engine_set_option(self._h, name.encode(), int(value)), f"f5_engine_set_option({name})")
+        if self._fallback is not None and name == "null_keeps_cond":
+            self._fallback.set_option(name, value)
+
+    def _ensure_fallback(self) -> Optional["Engine"]:
+        """The precision-"bf16x3" twin of this engine (fp32-class arithmetic, bf16's range), built once from the host weights."""
+        if self._fallback is None and self._host_weights is not None:
+            fb = Engine(self.cfg, precision="bf16x3", device=self.device, range_check="off")
+            fb.load_weights(self._host_weights)
+            fb.set_option("null_keeps_cond", self.get_option("null_keeps_cond"))
+            self._fallback = fb
+        return self._fallback
 
     def get_option(self, name: str) -> int:
         v = C.c_int()
@@ -314,6 +354,9 @@ class Engine:
             raise ValueError(f"Unknown method: {method}")
         self._check_inputs(text, cond, lens, durations)
         self.check_status(block=False)                 # a pending check of the previous call: resolved here if it has arrived
+        if self._use_fallback:                         # an earlier call saturated fp16 / failed its cross-check: bf16x3 from now on
+            return self._fallback.sample(text, cond, lens, durations, y0, t, method=method, cfg_strength=cfg_strength, use_mask=use_mask,
+                                         use_graph=use_graph, return_trajectory=return_trajectory, out=out, trajectory=trajectory)
         B, N, mel = cond.shape
         steps = int(len(t))
         assert y0.shape == cond.shape and y0.dtype == torch.float32 and y0.is_contiguous() and y0.is_cuda
@@ -328,37 +371,86 @@ class Engine:
                              trajectory if return_trajectory else None, ws)
         launch = lambda: self._run_on_side_stream(lambda st: check(self.lib.f5_sample(self._h, C.byref(a), st), "f5_sample"))  # noqa: E731
         launch()
-        self._after_call(a, launch, f"sample(B={B}, N={N}, {method}, {steps} points)")
+        saturated = self._after_call(a, launch, f"sample(B={B}, N={N}, {method}, {steps} points)", (B, N, steps, method))
         del keep
+        if saturated and self._use_fallback:           # ("sync": re-run THIS call in bf16x3, into the same output buffers)
+            return self._fallback.sample(text, cond, lens, durations, y0, t, method=method, cfg_strength=cfg_strength, use_mask=use_mask,
+                                         use_graph=use_graph, return_trajectory=return_trajectory, out=out, trajectory=trajectory)
+        if self.verify_calls > 0 and self.precision == "f16" and self._ensure_fallback() is not None:
+            self.verify_calls -= 1
+            ref, ref_traj = self._fallback.sample(text, cond, lens, durations, y0, t, method=method, cfg_strength=cfg_strength,
+                                                  use_mask=use_mask, use_graph=False, return_trajectory=return_trajectory)
+            self.last_verify_l1 = l1 = float((out - ref).abs().mean())
+            if not (l1 <= self.verify_tol):
+                self.verify_events += 1
+                self._use_fallback = True
+                warnings.warn(f"fp16 precision cross-check failed in sample(B={B}, N={N}, {method}, {steps} points): mean |f16 - bf16x3| of the final "
+                              f"mel is {l1:.3e} (tolerance {self.verify_tol:g}) although no operand left the fp16 range -- 11 significand bits "
+                              "are not enough for this checkpoint / input (large attention logits, massive activations); this engine now runs "
+                              "every call in precision 'bf16x3' (3x the matrix work) and returns the bf16x3 result of this call.",
+                              OperandRangeWarning, stacklevel=2)
+                out.copy_(ref)
+                if return_trajectory:
+                    trajectory.copy_(ref_traj)
         return out, (trajectory if return_trajectory else None)
 
-    # ---- status word (LN-fold operand range) --------------------------------------------------
+    # ---- status word (fp16 operand range) ------------------------------------------------------
     def _fall_back(self, what: str, rerun: bool) -> None:
         self.range_events += 1
-        self._clean_fold_calls = 0
+        self._clean_calls = 0
         self.set_option("ln_fold", 0)
         tail = ("re-running it unfolded" if rerun else
                 "THAT call's output is saturated (finite, clamped at +-65504) -- repeat it, or construct the engine with range_check='sync'")
         warnings.warn(f"ln_fold: the residual stream times (1 + scale) left the fp16 range (|v| > 65504) in {what}; this engine now runs "
                       f"with ln_fold = 0 (or use precision 'bf16' / 'bf16x3'); {tail}.", OperandRangeWarning, stacklevel=4)
 
+    def _saturation_fall_back(self, what: str, rerun: bool) -> None:
+        """Bit 2 of the status word: some 16-bit operand producer clamped a value at +-65 504.  fp16 cannot carry this model on this
+        input: build the bf16x3 engine (fp32-class arithmetic, bf16's range) from the host weights and send the calls there."""
+        self.saturation_events += 1
+        self._clean_calls = 0
+        if self._ensure_fallback() is not None:
+            self._use_fallback = True
+            tail = ("re-running it in bf16x3" if rerun else
+                    "THAT call's output is saturated (finite, wrong) -- repeat it, or construct the engine with range_check='sync'")
+            how = "this engine now runs every call on a precision-'bf16x3' engine built from the same weights (3x the matrix work)"
+        else:
+            tail = "the output of that call is saturated (finite, wrong)"
+            how = ("no host weights are kept (keep_host_weights=False / arena received by broadcast): construct the model with precision "
+                   "'bf16x3' (or 'bf16')")
+        warnings.warn(f"fp16 operands saturated: a value beyond +-65504 reached a 16-bit MFMA operand (LN-modulate, q / k / v, the GELU output, "
+                      f"conv-pos, ...) in {what}; {how}; {tail}.", OperandRangeWarning, stacklevel=4)
+
+    def _resolve(self, flags: int, what: str, shape, rerun: bool) -> bool:
+        """Act on one status word; returns True when the call saturated (bit 2) -- "sync": the caller re-runs it on the fall-back."""
+        if flags & STATUS_SATURATED:
+            if not self._use_fallback or rerun:
+                self._saturation_fall_back(what, rerun)
+            return True
+        if flags & STATUS_FOLD_OVERFLOW:
+            if self.get_option("ln_fold") != 0:            # (calls enqueued before the first warning arrived are flagged too: once)
+                self._fall_back(what, rerun)
+            return False
+        if shape == self._clean_shape:
+            self._clean_calls += 1
+        else:
+            self._clean_shape, self._clean_calls = shape, 1
+        return False
+
     def check_status(self, block: bool = True) -> int:
         """Resolve the pending status checks ("async" mode), oldest first; with block=False only those whose copy has arrived.
         Returns the OR of the words looked at.  Called at the start of every call and by synchronize()."""
         seen = 0
         while self._status_pending:
-            ev, slot, what = self._status_pending[0]
+            ev, slot, what, shape = self._status_pending[0]
             if not block and not ev.query():
                 break
             ev.synchronize()
             self._status_pending.pop(0)
             flags = int(self._status_host[slot])
+            self._status_free.append(slot)
             seen |= flags
-            if flags & 1:
-                if self.get_option("ln_fold") != 0:            # (calls enqueued before the first warning arrived are flagged too: once)
-                    self._fall_back(what, rerun=False)
-            elif flags & 2:
-                self._clean_fold_calls += 1
+            self._resolve(flags, what, shape, rerun=False)
         return seen
 
     def synchronize(self) -> None:
@@ -366,25 +458,21 @@ class Engine:
         self._stream.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
         self.check_status(block=True)
+        if self._fallback is not None:
+            self._fallback.synchronize()
 
-    def _after_call(self, a, launch, what: str) -> None:
-        """Status handling of one f5_sample / f5_dit_forward call (class docstring).  The library tells whether the fold ran (bit 1)."""
+    def _after_call(self, a, launch, what: str, shape=None) -> bool:
+        """Status handling of one f5_sample / f5_dit_forward call (class docstring).  Returns True when the call saturated fp16 and has
+        to be repeated on the bf16x3 fall-back ("sync" only; the LN-fold overflow is repeated here, unfolded)."""
         if self._status_host is None or self.range_check == "off":
-            return
-        active = C.c_int(0)
-        check(self.lib.f5_engine_ln_fold_active(self._h, C.byref(a), C.byref(active)), "f5_engine_ln_fold_active")
-        if not active.value:                   # (batch 1, ln_fold = 0, ...): nothing can set the word, nothing is read
-            return
+            return False
         mode = self.range_check
         if mode == "auto":
-            mode = "async" if self._clean_fold_calls >= self.range_probation else "sync"
-
-        if len(self._status_pending) >= self._status_host.numel():
-            ev, slot, w0 = self._status_pending[0]
-            ev.synchronize()
+            mode = "async" if (shape == self._clean_shape and self._clean_calls >= self.range_probation) else "sync"
+        if not self._status_free:                      # 16 calls ahead of the GPU: wait for the oldest check
+            self._status_pending[0][0].synchronize()
             self.check_status(block=False)
-        slot = self._status_slot
-        self._status_slot = (slot + 1) % self._status_host.numel()
+        slot = self._status_free.pop(0)
         holder = {}
 
         def enqueue_read(st):
@@ -393,22 +481,27 @@ class Engine:
             holder["ev"].record(torch.cuda.current_stream(self.device))
 
         self._run_on_side_stream(enqueue_read)
-        if mode == "sync":
+        if mode != "sync":
+            self._status_pending.append((holder["ev"], slot, what, shape))
+            return False
+        holder["ev"].synchronize()
+        flags = int(self._status_host[slot])
+        if (flags & STATUS_FOLD_OVERFLOW) and not (flags & STATUS_SATURATED):
+            self._resolve(flags, what, shape, rerun=True)
+            launch()                                   # ln_fold is 0 now: this run cannot carry bit 0; bit 2 is looked at below
+            self._run_on_side_stream(enqueue_read)
             holder["ev"].synchronize()
-            flags = int(self._status_host[slot])
-            if flags & 1:
-                self._fall_back(what, rerun=True)
-                launch()                                   # ln_fold is 0 now: the status word of this run cannot carry bit 0
-            elif flags & 2:
-                self._clean_fold_calls += 1
-        else:
-            self._status_pending.append((holder["ev"], slot, what))
+            flags = int(self._status_host[slot]) & ~STATUS_FOLD_OVERFLOW
+        self._status_free.append(slot)
+        return self._resolve(flags, what, shape, rerun=True)
 
     def dit_forward(self, x: torch.Tensor, text: torch.Tensor, cond: torch.Tensor, lens, durations, t: float,
                     cfg_strength: float = 2.0, use_mask: Optional[bool] = None):
         """One DiT evaluation (cond branch and, when cfg_strength >= 1e-5, null branch)."""
         self._check_inputs(text, cond, lens, durations)
         self.check_status(block=False)
+        if self._use_fallback:
+            return self._fallback.dit_forward(x, text, cond, lens, durations, t, cfg_strength=cfg_strength, use_mask=use_mask)
         B, N, mel = cond.shape
         if use_mask is None:
             use_mask = B > 1
@@ -420,6 +513,8 @@ class Engine:
         launch = lambda: self._run_on_side_stream(lambda st: check(   # noqa: E731
             self.lib.f5_dit_forward(self._h, C.byref(a), ptr(x), C.c_float(t), ptr(pred), ptr(null), st), "f5_dit_forward"))
         launch()
-        self._after_call(a, launch, f"dit_forward(B={B}, N={N})")
+        saturated = self._after_call(a, launch, f"dit_forward(B={B}, N={N})", (B, N, 2, "forward"))
         del keep
+        if saturated and self._use_fallback:
+            return self._fallback.dit_forward(x, text, cond, lens, durations, t, cfg_strength=cfg_strength, use_mask=use_mask)
         return pred, null

@@ -122,12 +122,20 @@ int f5_workspace_bytes(f5_engine* e, int B, int N, int nt, int steps, int method
 int f5_sample(f5_engine* e, const f5_sample_args* args, void* stream);
 
 /* Status word of the last f5_sample / f5_dit_forward on the workspace of `args`.  It is the FIRST 32-bit word of the workspace for every
- * shape and solver (a caller may copy it itself).  bit 1 = the LN fold (engine option "ln_fold") ran in that call; bit 0 = a value of the
- * folded LayerNorm operand (x - m)(1 + scale) did not fit fp16 (precision f16): the output is saturated there -- rerun with ln_fold = 0
- * or in bf16 (f5_tts_mlx_amd.engine.Engine does that by itself).  f5_sample_status synchronises `stream`; f5_sample_status_async only
+ * shape and solver (a caller may copy it itself).  bit 1 (F5_STATUS_FOLD_RAN) = the LN fold (engine option "ln_fold") ran in that call;
+ * bit 0 (F5_STATUS_FOLD_OVERFLOW) = a value of the folded LayerNorm operand (x - m)(1 + scale) did not fit fp16 (precision f16): the
+ * output is saturated there -- rerun with ln_fold = 0 or in bf16 (f5_tts_mlx_amd.engine.Engine does that by itself);
+ * bit 2 (F5_STATUS_SATURATED, precision f16, engine option "sat_check" = 1, the default) = some OTHER producer of a 16-bit MFMA operand
+ * -- LN-modulate, q / k / v behind the rotation, the GELU output of FF1, conv-pos, the packed ODE state, the text path -- clamped a
+ * value beyond +-65 504 somewhere in the call (every block of every evaluation is covered, at every batch size): the result is finite
+ * and wrong there; this checkpoint / input needs precision bf16x3 (fp32-class) or bf16 (Engine re-runs the call in bf16x3 by itself).
+ * f5_sample_status synchronises `stream`; f5_sample_status_async only
  * enqueues the 4-byte device-to-host copy behind the call (`flags` should be pinned host memory, valid once the caller has
  * synchronised `stream` or an event recorded after it): no host block per call.  No reference counterpart (the reference has no
  * reduced-precision operands). */
+#define F5_STATUS_FOLD_OVERFLOW 1
+#define F5_STATUS_FOLD_RAN 2
+#define F5_STATUS_SATURATED 4
 int f5_sample_status(f5_engine* e, const f5_sample_args* args, int* flags, void* stream);
 int f5_sample_status_async(f5_engine* e, const f5_sample_args* args, int* flags, void* stream);
 /* *active = 1 when f5_sample with these arguments runs the LN fold (the only configuration that can set bit 0 of the status word): a
@@ -297,6 +305,7 @@ int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float*
 int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, float* row_shift, void* stream);
 int f5_debug_set_op_ln_mean_out(float* mean_out);
 int f5_debug_set_op_fold_consumer(const float* rowf, const float* c1, const float* c2);
+int f5_debug_set_op_sat_flag(int* flag);   /* device word the 16-bit packers of the f5_op_* launches that follow OR F5_STATUS_SATURATED into (fp16 operand type); NULL = off */
 int f5_debug_set_op_fold_overflow_flag(int* flag);   /* device word the producer ORs bit 0 into when (x - m)(1 + s) leaves the fp16 range; NULL = off */
 /* c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k] shift_v[k] + bias[n] for nvec modulation vectors (vec_stride
  * floats apart; result rows out_stride floats apart); K % 256 == 0, K <= 2048 */

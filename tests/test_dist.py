@@ -91,3 +91,36 @@ def test_bench_gpus_flag_spawns_the_ranks():
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0"],
                         capture_output=True, text=True, timeout=120, env=env)
     assert r1.returncode == 0 and json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_bench_eight_ranks_dry_run_both_launch_styles():
+    """VERDICT r5 "next" #7: the first SCALE run must not fail on plumbing.  Eight gloo ranks on CPU (--dry-run), launched both ways:
+    (a) `python bench.py --gpus 8` re-executing itself under torch.distributed.run (port selection, rendezvous on 127.0.0.1), and
+    (b) exactly as the driver does it: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...`.  One JSON line from rank 0, n_gpus 8, BASELINE configs[3] = 256 utterances, per-rank
+    spread fields present, MAX-over-ranks timing (rank_ms_max == ms_per_step)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmds = {
+        "self-spawned": [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"],
+        "driver-style": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"],
+    }
+    for how, cmd in cmds.items():
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, (how, r.stderr[-3000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, (how, r.stdout[-2000:])
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 8 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak", (how, rec)
+        assert rec["config"]["global_batch"] == 256 and rec["value"] > 0 and rec["higher_is_better"] is True
+        assert rec["rank_ms_min"] <= rec["rank_ms_max"] and abs(rec["rank_ms_max"] - rec["ms_per_step"]) <= 1e-6 * max(1.0, rec["ms_per_step"]), (how, rec)
