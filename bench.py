@@ -618,9 +618,11 @@ def main():
         if real:
             par = None
         elif args.vocoder:
-            o_mel, _ = F5TTS(transformer=model).sample(cond[:1], text[:1], **dict(kw, y0=y0[:1], use_graph=False))
+            # the SAME batch without the vocoder (same kernels, same LN-fold decision as the timed call): utterance 0 of it
+            o_mel, _ = F5TTS(transformer=model).sample(cond, text, **kw)
             torch.cuda.synchronize()
             par = parity_against_golden(o_mel[0], args)
+            del o_mel
         else:
             par = parity_against_golden(out[0], args)
         if par:
@@ -699,6 +701,37 @@ def main():
                 se = summarize(el / 3 * 1e3, B)
                 se["note"] = "eager launches (no hipGraph): the cost of a shape signature the first time it is seen"
                 sub["b1_eager"] = se
+            # (5) BASELINE configs[4]: MX-fp8 block GEMMs + Vocos in the timed region, 16-point midpoint, batch 32 -- a reduced-precision mode
+            # OUTSIDE the parity gate by design, reported with its distance from the fp32 oracle and against the 5 PF dense fp8 peak
+            if B == 1 and args.precision == "f16" and not real:
+                import argparse as _ap
+                m8 = make_model("mxfp8")
+                m8.load_weights(weights)
+                c32, t32, y32, _ = synth_batch(32, first=0, device=device)
+                kw8 = dict(duration=N_FRAMES, steps=16, method="midpoint", cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y32, use_graph=not args.no_graph)
+                v8 = Vocos(synthetic_vocos_weights(seed=7), precision="bf16", device=device)
+                n8 = 3
+                el, o8 = timed_samples(F5TTS(transformer=m8, vocoder=v8.decode), c32, t32, kw8, n8, 1, barrier)
+                ms8 = el / n8 * 1e3
+                nf8 = 2 * 2 * 15
+                tf8 = 32 * nf8 * fwd_exec / 1e12 / (ms8 * 1e-3)
+                s8 = dict(ms_per_step=ms8, value=32 * N_FRAMES / (ms8 * 1e-3), unit="mel-frames/s", rtf=32 * 10.0 / (ms8 * 1e-3),
+                          whole_path_tflops=tf8, whole_path_frac_of_fp8_peak=tf8 / FP8_PEAK_TFLOPS, timed_iterations=n8,
+                          workload="BASELINE configs[4]: 32 utterances x 10 s, 16-point midpoint (60 forwards), MX-fp8 (e4m3 + E8M0 per 32) QKV / "
+                                   "out-proj / FF1 / FF2 GEMMs, everything else bf16, Vocos vocoder (random-init) in the timed region",
+                          samples_out=int(o8.numel()))
+                om, _ = F5TTS(transformer=m8).sample(c32, t32, **kw8)         # the same batch without the vocoder: utterance 0 vs the golden
+                torch.cuda.synchronize()
+                p8 = parity_against_golden(om[0], _ap.Namespace(method="midpoint", ode_points=16))
+                if p8:
+                    s8.update(p8)
+                    s8["parity_note"] = "reduced-precision mode outside the 1e-3 gate by design (the oracle with the same MX rounding predicts 2.1e-2)"
+                s8["roofline"] = gemm_roofline_f8(device, 32, iters=10)
+                sub["c5_mxfp8"] = s8
+                rec.update(c5_ms_per_step=ms8, c5_value=s8["value"], c5_rtf=s8["rtf"], c5_whole_path_frac_of_fp8_peak=s8["whole_path_frac_of_fp8_peak"],
+                           c5_parity_l1=s8.get("parity_l1"), c5_qkv_gemm_frac_of_fp8_peak=s8["roofline"]["frac"])
+                del m8, v8, c32, t32, y32, o8, om
+                torch.cuda.empty_cache()
             rec["sub"] = sub
         else:
             rec["rtf"] = None if not args.vocoder else head["rtf_mel_only"]
