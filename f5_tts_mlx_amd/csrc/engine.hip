@@ -74,7 +74,8 @@ struct Workspace {
 
 struct GraphEntry {
     std::string key;
-    hipGraphExec_t exec;
+    hipGraphExec_t exec;     // segment 0 (the whole call when the graph is not split)
+    std::vector<hipGraphExec_t> more;   // engine option "graph_split": the further segments (one per ODE step), launched in order
     const void* workspace;   // the captured nodes reference this buffer
     uint64_t stamp;          // last use (LRU)
     hipEvent_t done;         // recorded after every launch: an exec is only destroyed once its last replay has finished
@@ -92,6 +93,8 @@ struct F5Options {
     int ln_fold = -1;     // LN-modulate folded into the GEMMs around it (gemm.hpp fold_*): -1 = where it is measured faster (>= LN_FOLD_AUTO_ROWS
                           // rows and the four block GEMMs on the staged kernels, one-pass operand modes), 0 = never, 1 = wherever it can run
                           // (batch >= 4 at the 335M shape; fails loudly elsewhere)
+    int graph_split = 0;  // 0: a call is ONE hipGraphExec (~5 000 kernel nodes at 32 points); 1: one exec per ODE step (prep rides in the first), launched
+                          // back to back -- the same kernels with the same arguments, 31 replays of ~165 nodes (round-6 probe: does a long exec cost more per node?)
     int sat_check = 1;    // precision f16: every 16-bit operand producer reports values beyond +-65 504 in the status word (bit 2); 0 = A/B
     int null_keeps_cond = 0;   // the second (null) branch keeps the audio conditioning: DiT.__call__(drop_audio_cond=False, drop_text=True), dit.py:374-401
 };
@@ -107,6 +110,7 @@ static void destroy_graph_entry(GraphEntry& g) {
         (void)hipEventDestroy(g.done);
     }
     (void)hipGraphExecDestroy(g.exec);
+    for (hipGraphExec_t x : g.more) (void)hipGraphExecDestroy(x);
 }
 
 struct f5_engine {
@@ -335,6 +339,7 @@ extern "C" int f5_engine_set_option(f5_engine* e, const char* name, int value) {
     else if (n == "null_keeps_cond") e->opt.null_keeps_cond = value ? 1 : 0;
     else if (n == "ln_fold") e->opt.ln_fold = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "sat_check") e->opt.sat_check = value ? 1 : 0;
+    else if (n == "graph_split") e->opt.graph_split = value ? 1 : 0;
     else {
         f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags, attn_pipe, null_keeps_cond, ln_fold, sat_check)", name);
         return 2;
@@ -352,6 +357,7 @@ extern "C" int f5_engine_get_option(f5_engine* e, const char* name, int* value) 
     else if (n == "null_keeps_cond") *value = e->opt.null_keeps_cond;
     else if (n == "ln_fold") *value = e->opt.ln_fold;
     else if (n == "sat_check") *value = e->opt.sat_check;
+    else if (n == "graph_split") *value = e->opt.graph_split;
     else {
         f5_set_error("unknown engine option %s", name);
         return 2;
@@ -1008,7 +1014,8 @@ struct SatScope {
     ~SatScope() { f5hf::f5_sat_flag_host = saved; }
 };
 
-static int run_sample_body(const Ctx& c, const f5_sample_args* a) {
+// steps [i0, i1) of the solve; i0 == 0 also runs the per-call preparation (hoisted tables, text path, first operand pack)
+static int run_sample_body(const Ctx& c, const f5_sample_args* a, int i0 = 0, int i1 = 1 << 30) {
     const f5_config& cf = c.e->cfg;
     const Workspace& w = c.w;
     const int mel = cf.mel_dim;
@@ -1017,14 +1024,16 @@ static int run_sample_body(const Ctx& c, const f5_sample_args* a) {
     const int nfe = (a->steps - 1) * per;
     hipStream_t s = c.s;
     const Ops& K = c.ops;
-    RC(run_prep(c, nfe));
     float* traj = c.p<float>(w.traj);
-    RC(K.pack_x(traj, c.pb(w.xin, 0), c.pb(w.xin, 1), (int)M1, mel, s));
+    if (i0 == 0) {
+        RC(run_prep(c, nfe));
+        RC(K.pack_x(traj, c.pb(w.xin, 0), c.pb(w.xin, 1), (int)M1, mel, s));
+    }
     const float* pred = c.p<float>(w.vel);
     const float* nullp = c.nb == 2 ? pred + M1 * mel : nullptr;
     float* kst = c.p<float>(w.kst);
     float* ytmp = c.p<float>(w.ytmp);
-    for (int i = 0; i + 1 < a->steps; ++i) {
+    for (int i = i0; i + 1 < a->steps && i < i1; ++i) {
         float* y = traj + (size_t)i * M1 * mel;
         float* ynext = traj + (size_t)(i + 1) * M1 * mel;
         F5OdeArgs o;
@@ -1178,8 +1187,8 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d nk%d lf%d sc%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, e->opt.null_keeps_cond, e->opt.ln_fold, e->opt.sat_check, g_knob_epoch,
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d nk%d lf%d sc%d gs%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, e->opt.null_keeps_cond, e->opt.ln_fold, e->opt.sat_check, e->opt.graph_split, g_knob_epoch,
              a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
@@ -1196,13 +1205,13 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
         }
     }
     if (graph) {
-        hipGraphExec_t exec = nullptr;
+        GraphEntry* entry = nullptr;
         for (auto& g : e->graphs)
             if (g.key == key) {
-                exec = g.exec;
+                entry = &g;
                 g.stamp = ++e->clock;
             }
-        if (!exec) {
+        if (!entry) {
             // entries captured against another workspace are dead (the caller re-allocated it); then make room (LRU)
             for (size_t i = 0; i < e->graphs.size();) {
                 if (e->graphs[i].workspace != a->workspace) {
@@ -1219,28 +1228,46 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
                 destroy_graph_entry(e->graphs[lru]);
                 e->graphs.erase(e->graphs.begin() + lru);
             }
-            hipGraph_t graph_h = nullptr;
-            F5_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int rc = run_sample_body(c, a);
-            const hipError_t ec = hipStreamEndCapture(s, &graph_h);
-            if (rc) {
-                if (graph_h) (void)hipGraphDestroy(graph_h);
-                return rc;
+            // segments: the whole call, or (graph_split) one per ODE step
+            const int nseg = (e->opt.graph_split && a->steps > 2) ? a->steps - 1 : 1;
+            std::vector<hipGraphExec_t> execs;
+            auto drop = [&]() {
+                for (hipGraphExec_t x : execs) (void)hipGraphExecDestroy(x);
+            };
+            for (int sg = 0; sg < nseg; ++sg) {
+                hipGraph_t graph_h = nullptr;
+                F5_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                const int rc = nseg == 1 ? run_sample_body(c, a) : run_sample_body(c, a, sg, sg + 1);
+                const hipError_t ec = hipStreamEndCapture(s, &graph_h);
+                if (rc || ec != hipSuccess) {
+                    if (graph_h) (void)hipGraphDestroy(graph_h);
+                    drop();
+                    if (rc) return rc;
+                    F5_HIP_CHECK(ec);
+                }
+                hipGraphExec_t exec = nullptr;
+                const hipError_t ei = hipGraphInstantiate(&exec, graph_h, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph_h);
+                if (ei != hipSuccess) {
+                    drop();
+                    F5_HIP_CHECK(ei);
+                }
+                execs.push_back(exec);
             }
-            F5_HIP_CHECK(ec);
-            F5_HIP_CHECK(hipGraphInstantiate(&exec, graph_h, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph_h);
             hipEvent_t done = nullptr;
             if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) {
-                (void)hipGraphExecDestroy(exec);              // do not leak the instantiated graph
+                drop();                                       // do not leak the instantiated graphs
                 f5_set_error("f5_sample: hipEventCreateWithFlags failed");
                 return 3;
             }
-            e->graphs.push_back({key, exec, a->workspace, ++e->clock, done});
+            GraphEntry ge{key, execs[0], {}, a->workspace, ++e->clock, done};
+            ge.more.assign(execs.begin() + 1, execs.end());
+            e->graphs.push_back(std::move(ge));
+            entry = &e->graphs.back();
         }
-        F5_HIP_CHECK(hipGraphLaunch(exec, s));
-        for (auto& g : e->graphs)
-            if (g.exec == exec) F5_HIP_CHECK(hipEventRecord(g.done, s));
+        F5_HIP_CHECK(hipGraphLaunch(entry->exec, s));
+        for (hipGraphExec_t x : entry->more) F5_HIP_CHECK(hipGraphLaunch(x, s));
+        F5_HIP_CHECK(hipEventRecord(entry->done, s));
     } else {
         RC(run_sample_body(c, a));
     }

@@ -304,6 +304,26 @@ def test_graph_cache_is_bounded_and_auto_mode(tiny_weights):
     assert torch.equal(f5.sample(cond, text, use_graph="auto", **kw)[0], want)                                     # replayed
 
 
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_graph_split_per_ode_step_is_bit_identical(tiny_weights, method):
+    """Engine option graph_split (round-6 probe of the hipGraph replay cost, tools/r6_graph_probe.py): the call captured as one exec
+    per ODE step and replayed back to back returns the bits of the single exec and of the eager launches, for every solver, with a
+    changed guidance scale on the replay (scalars are data, not baked arguments), and counts as ONE entry of the graph cache."""
+    cfg = TINY
+    m = _model(cfg, tiny_weights, "f16")
+    f5 = F5TTS(transformer=m)
+    cond, text, durations, y0 = synth_inputs(cfg, 2, 48, nt=12, n_ref=10, seed=3, ragged=True)
+    kw = dict(duration=torch.tensor(durations), steps=5, method=method, y0=y0)
+    want = {c: f5.sample(cond, text, use_graph=False, cfg_strength=c, **kw)[0].clone() for c in (2.0, 0.7)}
+    for split in (0, 1):
+        m.engine.set_option("graph_split", split)
+        n0 = m.engine.graph_count()
+        for c in (2.0, 0.7, 2.0):
+            assert torch.equal(f5.sample(cond, text, use_graph=True, cfg_strength=c, **kw)[0], want[c]), (split, c)
+        assert m.engine.graph_count() == n0 + 1
+    m.engine.set_option("graph_split", 0)
+
+
 def test_c_abi_weight_broadcast_over_rccl(tiny_weights):
     """f5_broadcast_weights: the contiguous arena goes through ONE ncclBroadcast on a caller-owned RCCL communicator (here a
     1-rank communicator created with ctypes on librccl, the way a non-Python host would own one); the receiving engine is
