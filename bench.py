@@ -260,10 +260,10 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20, peak_meas: di
     # sample() folds softmax_scale * log2(e) into q in the QKV epilogue (single-segment operand modes); time the same kernels
     lib.f5_debug_set_op_q_premul(C.c_float(0.125 * 1.4426950408889634 if nseg == 1 else 0.0))
     # ... and hands the QKV projection the pair-major rotation tables (256x256 kernel: transposed q / k tiles)
-    tt = [torch.empty(32, N_FRAMES, device=dev) for _ in range(4)]
-    E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), N_FRAMES, 64,
+    tt = [torch.empty(64 * N_FRAMES, device=dev) for _ in range(2)]
+    E.check(lib.f5_op_rope_table_g4(P(tt[0]), P(tt[1]), N_FRAMES, 64,
                                    C.c_float(0.125 * 1.4426950408889634 if nseg == 1 else 1.0), st()))
-    E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
+    E.check(lib.f5_debug_set_op_rope_tables_g4(P(tt[0]), P(tt[1])))
     with E.operand_type(precision):
         k_qkv()                                        # q / k / V^T hold real values before attention is timed
         for key, name, fn, flops, shape, alg_bytes in specs:
@@ -276,7 +276,7 @@ def kernel_rooflines(precision: str, dev, B: int, iters: int = 20, peak_meas: di
                             traffic_unit="bytes/launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", algorithmic_bytes=alg_bytes,
                             algorithmic_flops=flops, ln_fold=bool(folded)))
     lib.f5_debug_set_op_q_premul(C.c_float(0.0))
-    E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+    E.check(lib.f5_debug_set_op_rope_tables_g4(P(None), P(None)))
     total = sum(k["avg_launch_ms"] for k in out)
     for k in out:
         k["share_of_block"] = k["avg_launch_ms"] / total

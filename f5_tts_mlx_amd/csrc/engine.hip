@@ -55,7 +55,7 @@ struct Workspace {
     size_t lens, dur2, text, ids, keep, rowkeep;
     size_t tgrid, dt, cfgv, sinus, th, temb, mod;
     size_t rope_cos, rope_sin;
-    size_t rope_t;                 // pair-major q / k rotation tables: 4 x [32][N] floats (cos_q, sin_q, cos_k, sin_k)
+    size_t rope_t;                 // group-major q / k rotation tables (gemm.hpp rope_g4*): 2 x [16][N][4] floats
     size_t cond, traj, ytmp, kst, vel;
     size_t xin[2];
     size_t te[2], tg, grn_partial, grn_nx;
@@ -696,7 +696,7 @@ static int run_prep(const Ctx& c, int nfe) {
         float* t = c.p<float>(w.rope_t);
         const size_t tn = (size_t)32 * c.N;
         const float qf = q_premul_factor(e);
-        RC(f5_launch_rope_table_t(t, t + tn, t + 2 * tn, t + 3 * tn, c.N, c.N, cf.dim_head, qf != 0.0f ? qf : 1.0f, s));
+        RC(f5_launch_rope_table_g4(t, t + 2 * tn, c.N, cf.dim_head, qf != 0.0f ? qf : 1.0f, s));      // q table | k table, 64 N floats each
     }
     RC(f5_launch_rowkeep(c.p<int>(w.dur2), c.p<uint8_t>(w.rowkeep), 2 * c.B, c.N, s));
     for (int p = 0; p < e->np; ++p) RC(K.zero_vt_pad(c.pb(w.vt, p), (size_t)2 * c.B * cf.heads * 64, c.N, c.npad, s));
@@ -934,11 +934,8 @@ static int run_dit(const Ctx& c, int j) {
         if (e->opt.qkv_tr) {                             // pair-major tables (the q pair carries qpre, or 1): used by the 256x256 kernel
             const float* t = c.p<float>(w.rope_t);
             const size_t tn = (size_t)32 * c.N;
-            gq.rope_cos_tq = t;
-            gq.rope_sin_tq = t + tn;
-            gq.rope_cos_tk = t + 2 * tn;
-            gq.rope_sin_tk = t + 3 * tn;
-            gq.rope_ldt = c.N;
+            gq.rope_g4q = t;
+            gq.rope_g4k = t + 2 * tn;
         }
         RC(K.gemm(gq, EPI_QKV_ROPE, s));
 
@@ -1612,15 +1609,14 @@ extern "C" int f5_op_quantize_mx(const float* x, int ldx, void* q, int ldq, void
     return f5_launch_quantize_mx(x, ldx, (uint8_t*)q, ldq, (uint8_t*)scales, rows, cols, (hipStream_t)stream);
 }
 
-// pair-major twins of the rotation tables ([dim_head/2][seq_len], the q pair multiplied by qscale) and an op-level hook that hands
-// them to f5_op_qkv_rope: with all four set (and the q factor of f5_debug_set_op_q_premul folded into the q pair by the caller)
-// the 256x256 kernel accumulates the q / k tiles transposed, as sample() does.  Null = off.
-static const float* g_op_rope_t[4] = {nullptr, nullptr, nullptr, nullptr};
-extern "C" int f5_debug_set_op_rope_tables_t(const float* cos_tq, const float* sin_tq, const float* cos_tk, const float* sin_tk) {
-    g_op_rope_t[0] = cos_tq;
-    g_op_rope_t[1] = sin_tq;
-    g_op_rope_t[2] = cos_tk;
-    g_op_rope_t[3] = sin_tk;
+// group-major twins of the rotation tables ([dim_head/4][seq_len][4] = (cos, cos, sin, sin) of two neighbouring pairs; the q table
+// multiplied by qscale; 16 seq_len dim_head/4 bytes each, 16-byte aligned) and an op-level hook that hands them to f5_op_qkv_rope: with
+// both set (and the q factor of f5_debug_set_op_q_premul folded into the q table by the caller) the staged kernels accumulate the
+// q / k tiles transposed, as sample() does.  Null = off.
+static const float* g_op_rope_t[2] = {nullptr, nullptr};
+extern "C" int f5_debug_set_op_rope_tables_g4(const float* tq, const float* tk) {
+    g_op_rope_t[0] = tq;
+    g_op_rope_t[1] = tk;
     return 0;
 }
 // op-level twin of the engine's q pre-multiplication (run_dit): when set (single-segment operands only), f5_op_qkv_rope scales
@@ -1682,20 +1678,16 @@ extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_
     g.heads = heads;
     g.dmodel = dmodel;
     g.q_premul = nseg == 1 ? g_op_q_premul : 0.0f;
-    g.rope_cos_tq = g_op_rope_t[0];
-    g.rope_sin_tq = g_op_rope_t[1];
-    g.rope_cos_tk = g_op_rope_t[2];
-    g.rope_sin_tk = g_op_rope_t[3];
-    g.rope_ldt = seq_len;
+    g.rope_g4q = g_op_rope_t[0];
+    g.rope_g4k = g_op_rope_t[1];
     g.vt[0] = (op16_t*)vt_hi;
     g.vt[1] = (op16_t*)vt_lo;
     if (g_op_fold.rowf != nullptr) op_fold_consumer(g);
     return g_ops.gemm(g, EPI_QKV_ROPE, (hipStream_t)stream);
 }
 
-extern "C" int f5_op_rope_table_t(float* cos_tq, float* sin_tq, float* cos_tk, float* sin_tk, int seq_len, int dim_head, float qscale,
-                                  void* stream) {
-    return f5_launch_rope_table_t(cos_tq, sin_tq, cos_tk, sin_tk, seq_len, seq_len, dim_head, qscale, (hipStream_t)stream);
+extern "C" int f5_op_rope_table_g4(float* tq, float* tk, int seq_len, int dim_head, float qscale, void* stream) {
+    return f5_launch_rope_table_g4(tq, tk, seq_len, dim_head, qscale, (hipStream_t)stream);
 }
 extern "C" int f5_op_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, void* stream) {
     return f5_launch_rope_table(cos_t, sin_t, seq_len, dim_head, (hipStream_t)stream);

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     // SLP-packed f32 instructions next to other workgroups' MFMAs -- profiles/r03/pk_f32_next_to_mfma_hazard.txt -- which is why
     // this file is built with -fno-slp-vectorize; the 4-wave kernels gain nothing from transposed tiles at the sizes they serve).
     constexpr bool QKV_TR_OK = EPI == EPI_QKV_ROPE && (32 * NB) % 64 == 0 && (NB & (NB - 1)) == 0 && KS == 1 && WM * WN == 8;
-    if (QKV_TR_OK && p.rope_cos_tk != nullptr && n0 + wn * (32 * NB) < 2 * p.dmodel) {
+    if (QKV_TR_OK && p.rope_g4k != nullptr && n0 + wn * (32 * NB) < 2 * p.dmodel) {
         for (int jj = 0; jj < nit; jj += NST) {
             RING_STEP(0, jj, true);
             if (NST > 1 && jj + 1 < nit) RING_STEP(1 % NST, jj + 1, true);
@@ -901,7 +901,7 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
         // tiles: M = 3 x 431 22.4 vs 18.4 us).  f5_gemm_qkv_small_tile: 0 = this rule, 14 = whenever one round, 12 / 13 = lock-step ring.
         // (the role-split QKV epilogue deals row tiles per batch element: it needs whole sequences, other shapes keep the small tiles)
         const bool qkv_rows_ok = EPI != EPI_QKV_ROPE || (a.seq_len > 0 && a.M % a.seq_len == 0);
-        const bool qkv14 = EPI == EPI_QKV_ROPE && sel == 0 && qkv_rows_ok && a.rope_cos_tk != nullptr && t128x256 <= 256 &&
+        const bool qkv14 = EPI == EPI_QKV_ROPE && sel == 0 && qkv_rows_ok && a.rope_g4k != nullptr && t128x256 <= 256 &&
                            (f5_gemm_qkv_small_tile == 14 || (f5_gemm_qkv_small_tile == 0 && t128x256 >= 176));
         // MID sizes (batch 2 ... 16: more than one round of small tiles, too few 256 x 256 tiles to fill the chip twice): the role-split
         // 128 x 256 kernel in several rounds instead of the register-staged 128 x 128 kernel of round 1, which is where the `t128 >= 384`
@@ -917,7 +917,7 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
     if constexpr (EPI == EPI_QKV_ROPE) {
         // batch-1-sized QKV projection with pair-major tables: one round of 8-wave 128 x 256 tiles with transposed q / k wave tiles
         // (f5_gemm_qkv_small_tile = 13 / 12) instead of 64 x 128 register-staged tiles (0)
-        if (sel == 0 && (f5_gemm_qkv_small_tile == 12 || f5_gemm_qkv_small_tile == 13) && a.rope_cos_tk != nullptr && a.N % 256 == 0) {
+        if (sel == 0 && (f5_gemm_qkv_small_tile == 12 || f5_gemm_qkv_small_tile == 13) && a.rope_g4k != nullptr && a.N % 256 == 0) {
             const long t128x256 = (long)f5_cdiv(a.M, 128) * (a.N / 256);
             if (t128x256 <= 256) sel = f5_gemm_qkv_small_tile;
         }
@@ -983,7 +983,7 @@ int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
                        ((reinterpret_cast<uintptr_t>(a.fold_c1) | reinterpret_cast<uintptr_t>(a.fold_c2)) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.fold_rowf) & 7) == 0 && (a.debug_flags & 16384) == 0,
                    "gemm: LN-fold consumer needs EPI_QKV_ROPE / EPI_GELU_TANH, one-pass operands, aligned fold_c1 / fold_c2 / fold_rowf");
-        F5_REQUIRE(epi != EPI_QKV_ROPE || (a.rope_cos_tk && a.dmodel % 256 == 0), "gemm(qkv): the LN fold needs the transposed q / k tiles");
+        F5_REQUIRE(epi != EPI_QKV_ROPE || (a.rope_g4k && a.dmodel % 256 == 0), "gemm(qkv): the LN fold needs the transposed q / k tiles");
         a.bias = nullptr;                             // inside fold_c2
     }
     switch (epi) {
@@ -995,14 +995,15 @@ int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
         case EPI_QKV_ROPE:
             F5_REQUIRE(a.dmodel % 128 == 0 && a.N == 3 * a.dmodel, "gemm(qkv): N must be 3*dmodel, dmodel %% 128 == 0");
             F5_REQUIRE(a.rope_cos && a.rope_sin, "gemm(qkv): token-major rotation tables missing");
-            if (a.rope_cos_tk || a.rope_cos_tq) {
-                // pair-major tables = transposed q / k tiles on the 256x256 kernel: every 256-column tile must lie inside one of the
+            if (a.rope_g4k || a.rope_g4q) {
+                // group-major tables = transposed q / k tiles on the staged kernels: every 256-column tile must lie inside one of the
                 // q | k | v ranges, the bias is read as 16-byte quads; gemm flag 16384 = A/B against the straight tiles
-                F5_REQUIRE(a.rope_cos_tq && a.rope_sin_tq && a.rope_cos_tk && a.rope_sin_tk && a.rope_ldt >= a.seq_len,
-                           "gemm(qkv): pair-major rotation tables incomplete");
+                F5_REQUIRE(a.rope_g4q && a.rope_g4k && ((reinterpret_cast<uintptr_t>(a.rope_g4q) | reinterpret_cast<uintptr_t>(a.rope_g4k)) & 15) == 0 &&
+                               (size_t)a.seq_len * 16 * 16 < (1ull << 31),
+                           "gemm(qkv): group-major rotation tables incomplete / not 16-byte aligned");
                 const bool ok = a.dmodel % 256 == 0 && (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
                                 (f5_gemm_debug_flags & 16384) == 0;
-                if (!ok) a.rope_cos_tq = a.rope_sin_tq = a.rope_cos_tk = a.rope_sin_tk = nullptr;
+                if (!ok) a.rope_g4q = a.rope_g4k = nullptr;
             }
             return launch_epi<EPI_QKV_ROPE>(a, stream);
         case EPI_ADDROWS: return launch_epi<EPI_ADDROWS>(a, stream);

@@ -41,15 +41,15 @@ struct F5GemmArgs {
     int seq_len, npad, heads, dmodel;
     op16_t* vt[2];            // [B*heads][64][npad]
     float q_premul;           // EPI_QKV_ROPE: != 0 -> the q columns (col < dmodel) are multiplied by it before rounding (softmax scale * log2 e)
-    // EPI_QKV_ROPE on the 256x256 kernel: PAIR-major rotation tables [dim_head/2][rope_ldt] (position contiguous), one pair for the
-    // q columns (already carrying q_premul) and one for the k columns.  All four set = the q / k column tiles are accumulated
-    // TRANSPOSED (lane = token: rotation pairs in-lane, 8-byte staging writes; gemm.hip staged_epilogue_tr_rope); other kernels and
-    // the V tiles keep using the token-major tables / the straight tile.
-    const float* rope_cos_tq;
-    const float* rope_sin_tq;
-    const float* rope_cos_tk;
-    const float* rope_sin_tk;
-    int rope_ldt;
+    // EPI_QKV_ROPE on the staged kernels: GROUP-major rotation tables [dim_head / 4][seq_len][4] -- for rotation pairs (2g, 2g + 1) of
+    // position n the four factors (cos_2g, cos_2g+1, sin_2g, sin_2g+1) are ONE 16-byte element, positions contiguous: a lane that holds
+    // token n and 4 consecutive features reads its factors with one global_load_dwordx4, 32 consecutive tokens read 512 contiguous
+    // bytes (round 6; the pair-major [dim_head/2][positions] tables before it took four 4-byte loads).  One table for the q columns
+    // (already carrying q_premul) and one for the k columns.  Both set = the q / k column tiles are accumulated TRANSPOSED (lane =
+    // token: rotation pairs in-lane, 8-byte staging writes; gemm_dev.hpp staged_epilogue_tr_rope); other kernels and the V tiles keep
+    // using the token-major tables / the straight tile.
+    const float* rope_g4q;
+    const float* rope_g4k;
     int debug_flags;          // bit 0: skip the epilogue (timing experiments only)
     int nband;                // 256x256 kernel: > 0 = tiles numbered band-major, bands of nband column tiles (set by the launcher)
     // ---- EPI_RESID_GATE only, small-tile kernels only (f5_gemm_resid_ln_fusable): LN-modulate of the NEXT sub-layer fused

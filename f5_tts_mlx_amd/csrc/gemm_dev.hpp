@@ -572,8 +572,14 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
     const int hi = lane >> 5, lcol = lane & 31;
     const bool two = p.out_bf[1] != nullptr;
     const bool isq = colbase < p.dmodel;
-    const float* ct = isq ? p.rope_cos_tq : p.rope_cos_tk;
-    const float* st = isq ? p.rope_sin_tq : p.rope_sin_tk;
+    // group-major factors (gemm.hpp rope_g4*): element (g, n) = 16 bytes.  The lane's part of the address -- token n, and hi picks the
+    // odd group of the pair of groups a (nb, rg) step covers -- is a 32-bit byte offset; the (nb, rg) part is wave-uniform and goes
+    // into a scalar base: global_load_dwordx4 v, v_off, s[base], no 64-bit VALU address arithmetic (round 5 counted 200 of the 860
+    // executed VALU instructions of this epilogue as such)
+    typedef __attribute__((address_space(1))) const char gcchar;
+    typedef __attribute__((address_space(1))) const f32x4 gcf32x4;
+    gcchar* const tb = (gcchar*)(isq ? p.rope_g4q : p.rope_g4k);
+    const uint32_t gstep = (uint32_t)p.seq_len * 16u;             // bytes from group g to group g + 1
     op16_t* rh = reg;
     op16_t* rl = reg + 32 * LD;
     f5_sat_t trk;
@@ -592,6 +598,7 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
         int row = rowblk + lcol;
         if (row > p.M - 1) row = p.M - 1;                    // rows past the end compute a valid rotation and are never stored
         const int n = row % p.seq_len;
+        uint32_t loff = (uint32_t)(hi * p.seq_len + n) * 16u;
         f5_f32x2 rr = {1.0f, 0.0f};
         if (FOLD) rr = rrv[mb];
         const f5_f32x2 nr1v = f5_bc2(-rr[1]);
@@ -603,15 +610,19 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int c = colbase + nb * 32 + rg * 8 + hi * 4;
-                const int j0 = (c & 63) >> 1;
                 if (F5_PROBE_NOMATH(p)) {
                     c0[rg] = c1[rg] = 1.0f;
                     s0[rg] = s1[rg] = 0.0f;
                 } else {
-                    c0[rg] = ct[(size_t)j0 * p.rope_ldt + n];
-                    c1[rg] = ct[(size_t)(j0 + 1) * p.rope_ldt + n];
-                    s0[rg] = st[(size_t)j0 * p.rope_ldt + n];
-                    s1[rg] = st[(size_t)(j0 + 1) * p.rope_ldt + n];
+                    // features c .. c + 3 of a 64-wide head = rotation pairs 2g, 2g + 1 with g = ((c & 63) >> 2): its hi part is in loff
+                    const int g0 = (((colbase & 63) + nb * 32 + rg * 8) & 63) >> 2;   // wave-uniform (colbase is a multiple of 32)
+                    gcchar* gb = tb + (size_t)g0 * gstep;
+                    asm volatile("" : "+v"(loff));                                   // (keeps the zero-extension next to the load: saddr form)
+                    const f32x4 cs = *(gcf32x4*)(gb + loff);
+                    c0[rg] = cs[0];
+                    c1[rg] = cs[1];
+                    s0[rg] = cs[2];
+                    s1[rg] = cs[3];
                 }
                 if (FOLD) {
                     const f32x4 c1q = *reinterpret_cast<const f32x4*>(&fl[c - colbase]), c2q = *reinterpret_cast<const f32x4*>(&fl[W + c - colbase]);

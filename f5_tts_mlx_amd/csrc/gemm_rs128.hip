@@ -294,7 +294,7 @@ static int launch_rs128(const F5GemmArgs& a, hipStream_t stream) {
     if (a.bias != nullptr && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) ab.debug_flags |= 16384;
     constexpr bool CAN_FOLD = EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH;
     const bool fold = CAN_FOLD && ab.fold_rowf != nullptr;     // (f5_launch_gemm has checked the fold's preconditions: transposed q / k tiles)
-    if (EPI == EPI_QKV_ROPE && ab.rope_cos_tk != nullptr) {
+    if (EPI == EPI_QKV_ROPE && ab.rope_g4k != nullptr) {
         if (fold) hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, EPI == EPI_QKV_ROPE, CAN_FOLD>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
         else hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, EPI == EPI_QKV_ROPE, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
     } else {

@@ -34,7 +34,7 @@ using f5bf::f5_launch_ln_modulate_f8;
 using f5bf::f5_launch_quantize_mx;
 using f5bf::f5_launch_quantize_mx_bf16;
 using f5bf::f5_launch_rope_table;
-using f5bf::f5_launch_rope_table_t;
+using f5bf::f5_launch_rope_table_g4;
 using f5bf::f5_launch_rowkeep;
 using f5bf::f5_launch_stage_words;
 using f5bf::f5_launch_copy_words;

@@ -491,27 +491,26 @@ __global__ void rope_table_kernel(float* __restrict__ cos_t, float* __restrict__
         sin_t[(size_t)n * half + j] = sinf(a);
     }
 }
-// PAIR-major twins of the tables above for the transposed q / k tiles of the 256x256 QKV kernel (gemm.hip staged_epilogue_tr_rope):
-// [dim_head/2][ldt], position contiguous, so that 32 lanes holding 32 consecutive tokens read one 128-byte line.  Same fp32
-// expression for the angle; the q pair carries the factor the engine folds into q (softmax scale * log2 e, or 1).
-__global__ void rope_table_t_kernel(float* __restrict__ cos_tq, float* __restrict__ sin_tq, float* __restrict__ cos_tk,
-                                    float* __restrict__ sin_tk, int seq_len, int ldt, int dim_head, float qscale) {
+// GROUP-major twins of the tables above for the transposed q / k tiles of the staged QKV kernels (gemm_dev.hpp staged_epilogue_tr_rope):
+// [dim_head / 4][seq_len][4] with element (g, n) = (cos_2g, cos_2g+1, sin_2g, sin_2g+1) of position n -- one 16-byte load per lane and
+// 4 features, 512 contiguous bytes per 32 consecutive tokens.  Same fp32 expression for the angle; the q table carries the factor the
+// engine folds into q (softmax scale * log2 e, or 1).
+__global__ void rope_table_g4_kernel(float* __restrict__ tq, float* __restrict__ tk, int seq_len, int dim_head, float qscale) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
+    const int j = blockIdx.y;                                                    // rotation pair
     if (n >= seq_len) return;
     const float inv = 1.0f / powf(10000.0f, (float)(2 * j) / (float)dim_head);  // rope.py:23
     const float a = (float)n * inv;                                              // fp32 product, rope.py:45
     const float c = cosf(a), s = sinf(a);
-    const size_t o = (size_t)j * ldt + n;
-    cos_tk[o] = c;
-    sin_tk[o] = s;
-    cos_tq[o] = c * qscale;
-    sin_tq[o] = s * qscale;
+    const size_t o = ((size_t)(j >> 1) * seq_len + n) * 4 + (j & 1);
+    tk[o] = c;
+    tk[o + 2] = s;
+    tq[o] = c * qscale;
+    tq[o + 2] = s * qscale;
 }
-int f5_launch_rope_table_t(float* cos_tq, float* sin_tq, float* cos_tk, float* sin_tk, int seq_len, int ldt, int dim_head, float qscale,
-                           hipStream_t s) {
-    hipLaunchKernelGGL(rope_table_t_kernel, dim3(f5_cdiv(seq_len, 64), dim_head / 2), dim3(64), 0, s, cos_tq, sin_tq, cos_tk, sin_tk,
-                       seq_len, ldt, dim_head, qscale);
+int f5_launch_rope_table_g4(float* tq, float* tk, int seq_len, int dim_head, float qscale, hipStream_t s) {
+    F5_REQUIRE(dim_head % 4 == 0, "rope_table_g4: dim_head must be a multiple of 4");
+    hipLaunchKernelGGL(rope_table_g4_kernel, dim3(f5_cdiv(seq_len, 64), dim_head / 2), dim3(64), 0, s, tq, tk, seq_len, dim_head, qscale);
     F5_LAUNCH_CHECK();
     return 0;
 }

@@ -50,8 +50,7 @@ int f5_launch_skinny_gemm(const float* a, const float* w, const float* b, float*
 
 // rotary cos/sin table [seq_len][dim_head/2] (rope.py:38-60) and text positional table (rope.py:63-73)
 int f5_launch_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, hipStream_t s);
-int f5_launch_rope_table_t(float* cos_tq, float* sin_tq, float* cos_tk, float* sin_tk, int seq_len, int ldt, int dim_head, float qscale,
-                           hipStream_t s);
+int f5_launch_rope_table_g4(float* tq, float* tk, int seq_len, int dim_head, float qscale, hipStream_t s);
 int f5_launch_text_pos_table(float* table, int max_pos, int dim, hipStream_t s);
 
 // y (fp32 [rows][mel]) -> bf16 [rows][128] zero padded (A operand of the per-step x projection)

@@ -166,10 +166,11 @@ int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_hi, const v
                    const float* rope_cos, const float* rope_sin, void* qk_hi, void* qk_lo, void* vt_hi, void* vt_lo, int B,
                    int seq_len, int npad, int heads, int dmodel, int nseg, void* stream);
 int f5_op_rope_table(float* cos_t, float* sin_t, int seq_len, int dim_head, void* stream);
-/* PAIR-major twins of the rotation tables, [dim_head/2][seq_len], the q pair multiplied by qscale (1 = plain q): with them the
- * 256x256 QKV kernel accumulates the q / k column tiles transposed (rotation pairs in-lane); sample() builds its own */
-int f5_op_rope_table_t(float* cos_tq, float* sin_tq, float* cos_tk, float* sin_tk, int seq_len, int dim_head, float qscale,
-                       void* stream);
+/* GROUP-major twins of the rotation tables: tq / tk are [dim_head/4][seq_len][4] floats (16 seq_len dim_head/4 bytes each, 16-byte
+ * aligned), element (g, n) = (cos, cos, sin, sin) of rotation pairs 2g, 2g + 1 at position n, the q table multiplied by qscale (1 = plain
+ * q): with them the staged QKV kernels accumulate the q / k column tiles transposed (rotation pairs in-lane, one 16-byte load per lane
+ * and 4 features); sample() builds its own */
+int f5_op_rope_table_g4(float* tq, float* tk, int seq_len, int dim_head, float qscale, void* stream);
 /* dit.py:29-50 one grouped conv + Mish; mode 0 -> bf16 out, mode 1 -> out_f32 += */
 int f5_op_convpos(const void* in_hi, const void* in_lo, const void* w_hi, const void* w_lo, const float* bias, void* out_hi,
                   void* out_lo, float* out_f32, int B, int seq_len, int C, int groups, int taps, int nseg, int mode,
@@ -312,7 +313,7 @@ int f5_debug_set_op_fold_overflow_flag(int* flag);   /* device word the producer
 int f5_op_fold_consts(const void* w_hi, int ldw, const float* bias, const float* scale, const float* shift, size_t vec_stride, int nvec,
                       float* c1, float* c2, size_t out_stride, int N, int K, void* stream);
 /* op-level twins for f5_op_qkv_rope / f5_op_attention */
-int f5_debug_set_op_rope_tables_t(const float* cos_tq, const float* sin_tq, const float* cos_tk, const float* sin_tk); /* NULLs = off */
+int f5_debug_set_op_rope_tables_g4(const float* tq, const float* tk); /* NULLs = off */
 int f5_debug_set_op_q_premul(float factor); /* f5_op_qkv_rope scales q by factor, f5_op_attention expects q pre-scaled; 0 = off (default) */
 
 /* ---- MX-fp8 path (BASELINE configs[4]; gfx950 v_mfma_scale_f32_32x32x64_f8f6f4): OCP e4m3 elements, one E8M0 scale per 32

@@ -211,9 +211,9 @@ def test_fp16_range_detector_on_every_packer(lib, tile):
                     assert float(out16.float().abs().max()) == 65504.0
         cos_t, sin_t = torch.empty(n, 32, device=DEV), torch.empty(n, 32, device=DEV)
         E.check(lib.f5_op_rope_table(P(cos_t), P(sin_t), n, 64, stream()))
-        tt = [torch.empty(32, n, device=DEV) for _ in range(4)]
-        E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), n, 64, C.c_float(1.0), stream()))
-        E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
+        tt = [torch.empty(64 * n, device=DEV) for _ in range(2)]
+        E.check(lib.f5_op_rope_table_g4(P(tt[0]), P(tt[1]), n, 64, C.c_float(1.0), stream()))
+        E.check(lib.f5_debug_set_op_rope_tables_g4(P(tt[0]), P(tt[1])))
         try:
             for which, row in (("clean", None), ("q", 100), ("k", D + 77), ("v", 2 * D + 515)):
                 w = randn(r, 3 * D, D, scale=D ** -0.5)
@@ -227,7 +227,7 @@ def test_fp16_range_detector_on_every_packer(lib, tile):
                     lambda: (E.check(lib.f5_op_qkv_rope(P(a_hi), P(None), P(w_hi), P(None), P(bias), P(cos_t), P(sin_t), P(qk), P(None), P(vt), P(None),
                                                         B, n, npad, H, D, 1, stream()), "qkv_rope"), qk, vt)[1:], 0 if row is None else 4)
         finally:
-            E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+            E.check(lib.f5_debug_set_op_rope_tables_g4(P(None), P(None)))
     finally:
         E.check(lib.f5_debug_set_gemm_tile(0))
 

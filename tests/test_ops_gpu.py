@@ -125,12 +125,13 @@ def _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul, tr_tables=Fal
     bias_d = bias.to(DEV)
     tt = None
     if tr_tables:
-        # pair-major rotation tables (the q pair carrying the q factor): the 256x256 kernel then accumulates the q / k tiles
-        # transposed, as sample() does at large batch
-        tt = [torch.empty((32, N), device=DEV) for _ in range(4)]
-        E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), N, 64, C.c_float(QPRE if premul else 1.0), stream()))
-        assert torch.equal(tt[2].T.contiguous(), cos_t) and torch.equal(tt[3].T.contiguous(), sin_t)
-        E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
+        # group-major rotation tables [16][N][4] = (cos, cos, sin, sin) of two neighbouring pairs (the q table carrying the q factor):
+        # the staged kernels then accumulate the q / k tiles transposed, as sample() does; the k table holds the token-major values
+        tt = [torch.empty(64 * N, device=DEV) for _ in range(2)]
+        E.check(lib.f5_op_rope_table_g4(P(tt[0]), P(tt[1]), N, 64, C.c_float(QPRE if premul else 1.0), stream()))
+        g4 = tt[1].view(16, N, 4)
+        assert torch.equal(g4[:, :, 0:2].permute(1, 0, 2).reshape(N, 32), cos_t) and torch.equal(g4[:, :, 2:4].permute(1, 0, 2).reshape(N, 32), sin_t)
+        E.check(lib.f5_debug_set_op_rope_tables_g4(P(tt[0]), P(tt[1])))
     try:
         E.check(lib.f5_op_qkv_rope(P(x_hi), P(x_lo), P(w_hi), P(w_lo), P(bias_d), P(cos_t), P(sin_t), P(qk[0]), P(qk[1]),
                                    P(vt[0]), P(vt[1]), B, N, npad, H, D, nseg, stream()), "qkv_rope")
@@ -138,7 +139,7 @@ def _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul, tr_tables=Fal
         if tr_tables:       # the straight tiles must give the same 16-bit values (same expressions; report if contraction differs)
             qk2 = [torch.zeros_like(qk[0]) for _ in range(2)]
             vt2 = [torch.zeros_like(vt[0]) for _ in range(2)]
-            E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+            E.check(lib.f5_debug_set_op_rope_tables_g4(P(None), P(None)))
             E.check(lib.f5_op_qkv_rope(P(x_hi), P(x_lo), P(w_hi), P(w_lo), P(bias_d), P(cos_t), P(sin_t), P(qk2[0]), P(qk2[1]),
                                        P(vt2[0]), P(vt2[1]), B, N, npad, H, D, nseg, stream()), "qkv_rope")
             sync()
@@ -147,7 +148,7 @@ def _attention_case_body(lib, B, H, N, kv_len, nseg, seed, premul, tr_tables=Fal
                   f"identical = {torch.equal(qk[0], qk2[0])}")
             assert dq <= 2.0 ** -8 * float(qk2[0].float().abs().max()) and torch.equal(vt[0], vt2[0])
     finally:
-        E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+        E.check(lib.f5_debug_set_op_rope_tables_g4(P(None), P(None)))
     out = [torch.zeros((B * N, D), dtype=op_dtype(), device=DEV) for _ in range(2)]
     kv = torch.tensor(kv_len, dtype=torch.int32, device=DEV) if kv_len is not None else None
     E.check(lib.f5_op_attention(P(qk[0]), P(qk[1]), P(vt[0]), P(vt[1]), P(out[0]), P(out[1]), P(kv), B, H, N, npad, D,
@@ -613,12 +614,12 @@ def test_transposed_qkv_tiles_race_screen(lib, tile):
             a_hi, _ = split_bf16(randn(r, M, D).to(DEV))
             cos_t, sin_t = torch.empty(n, 32, device=DEV), torch.empty(n, 32, device=DEV)
             E.check(lib.f5_op_rope_table(P(cos_t), P(sin_t), n, 64, stream()))          # token-major (straight tiles) ...
-            tt = [torch.empty(32, n, device=DEV) for _ in range(4)]
-            E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), n, 64, C.c_float(1.0), stream()))   # ... and pair-major twins
+            tt = [torch.empty(64 * n, device=DEV) for _ in range(2)]
+            E.check(lib.f5_op_rope_table_g4(P(tt[0]), P(tt[1]), n, 64, C.c_float(1.0), stream()))   # ... and pair-major twins
 
             def run(flags):
                 E.check(lib.f5_debug_set_gemm_flags(flags))
-                E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
+                E.check(lib.f5_debug_set_op_rope_tables_g4(P(tt[0]), P(tt[1])))
                 qk = torch.zeros(M, 2 * D, dtype=op_dtype(), device=DEV)
                 vt = torch.zeros(B * H, 64, npad, dtype=op_dtype(), device=DEV)
                 E.check(lib.f5_op_qkv_rope(P(a_hi), P(None), P(w_hi), P(None), P(bias), P(cos_t), P(sin_t), P(qk), P(None), P(vt), P(None),
@@ -633,7 +634,7 @@ def test_transposed_qkv_tiles_race_screen(lib, tile):
                     assert torch.equal(qk, ref_qk) and torch.equal(vt, ref_vt), (tile, B, n, i, int((qk != ref_qk).sum()))
             finally:
                 E.check(lib.f5_debug_set_gemm_flags(0))
-                E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+                E.check(lib.f5_debug_set_op_rope_tables_g4(P(None), P(None)))
     finally:
         E.check(lib.f5_debug_set_gemm_tile(0))
 
@@ -1037,13 +1038,13 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
             npad = (Nq + 63) // 64 * 64
             cos_t, sin_t = torch.empty((Nq, 32), device=DEV), torch.empty((Nq, 32), device=DEV)
             E.check(lib.f5_op_rope_table(P(cos_t), P(sin_t), Nq, 64, stream()))
-            tt = [torch.empty((32, Nq), device=DEV) for _ in range(4)]
-            E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), Nq, 64, C.c_float(QPRE), stream()))
+            tt = [torch.empty(64 * Nq, device=DEV) for _ in range(2)]
+            E.check(lib.f5_op_rope_table_g4(P(tt[0]), P(tt[1]), Nq, 64, C.c_float(QPRE), stream()))
             qk = torch.zeros((M, 2 * D), dtype=op_dtype(), device=DEV)
             vt = torch.zeros((Bq * H, 64, npad), dtype=op_dtype(), device=DEV)
             qk_unf, vt_unf = torch.zeros_like(qk), torch.zeros_like(vt)
             c1, c2, w64 = consts["qkv"]
-            E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
+            E.check(lib.f5_debug_set_op_rope_tables_g4(P(tt[0]), P(tt[1])))
             E.check(lib.f5_debug_set_op_q_premul(C.c_float(QPRE)))
             try:
                 E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(None), P(None)))
@@ -1054,7 +1055,7 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
                                            Bq, Nq, npad, H, D, 1, stream()), "qkv_rope folded")
                 sync()
             finally:
-                E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+                E.check(lib.f5_debug_set_op_rope_tables_g4(P(None), P(None)))
                 E.check(lib.f5_debug_set_op_q_premul(C.c_float(0.0)))
         finally:
             E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(None), P(None)))

@@ -136,9 +136,9 @@ def main():
             out16 = torch.empty(M_ROWS, N, dtype=opd, device=dev)
             npad = (N_FRAMES + 63) // 64 * 64
             cos_t, sin_t = torch.ones(N_FRAMES, 32, device=dev), torch.zeros(N_FRAMES, 32, device=dev)
-            tt = [torch.empty((32, N_FRAMES), device=dev) for _ in range(4)]
+            tt = [torch.empty(64 * N_FRAMES, device=dev) for _ in range(2)]
             E.check(lib.f5_op_rope_table(P(cos_t), P(sin_t), N_FRAMES, 64, st()))
-            E.check(lib.f5_op_rope_table_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3]), N_FRAMES, 64, C.c_float(1.0), st()))
+            E.check(lib.f5_op_rope_table_g4(P(tt[0]), P(tt[1]), N_FRAMES, 64, C.c_float(1.0), st()))
             qk = torch.empty(M_ROWS, 2 * D, dtype=opd, device=dev)
             vt = torch.zeros(64 * H, 64, npad, dtype=opd, device=dev)
             if kind == "resid":
@@ -147,7 +147,7 @@ def main():
             elif kind == "gelu":
                 ours = lambda: E.check(lib.f5_op_gemm(P(a), P(None), P(w), P(None), P(bias), P(None), P(out16), P(None), M_ROWS, N, K, K, K, N, 1, 2, st()))   # noqa: E731
             else:
-                E.check(lib.f5_debug_set_op_rope_tables_t(P(tt[0]), P(tt[1]), P(tt[2]), P(tt[3])))
+                E.check(lib.f5_debug_set_op_rope_tables_g4(P(tt[0]), P(tt[1])))
                 ours = lambda: E.check(lib.f5_op_qkv_rope(P(a), P(None), P(w), P(None), P(bias), P(cos_t), P(sin_t), P(qk), P(None), P(vt),   # noqa: E731
                                                           P(None), 64, N_FRAMES, npad, H, D, 1, st()))
             nwg = min(MAXWG, ((M_ROWS + 255) // 256) * (N // 256))
@@ -187,7 +187,7 @@ def main():
             E.check(lib.f5_debug_set_op_fold_producer(P(None), P(None), P(None), P(None)))
             E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(None), P(None)))
             if kind == "qkv":
-                E.check(lib.f5_debug_set_op_rope_tables_t(P(None), P(None), P(None), P(None)))
+                E.check(lib.f5_debug_set_op_rope_tables_g4(P(None), P(None)))
 
 
 if __name__ == "__main__":
