@@ -17,7 +17,7 @@ for e in d["entries"]:
         e = dict(e, key=e["key"] + suffix)
     old.append(e)
 d["entries"] = new + old
-d["note"] += ("  Round 5: the un-suffixed entries are the final round-5 build (tools/gpu_r5_final.sh: shifted LN-fold producer, packed epilogue "
-              f"arithmetic); *{suffix} = the same launches on the round-4 build.")
+d["note"] += (f"  Merge of {src}: the un-suffixed entries are that round's final build (its tools/gpu_rN_final.sh run); "
+              f"*{suffix} = the same launches on the build before it.")
 json.dump(d, open(path, "w"), indent=1)
 print(len(new), "new entries,", len(old), "kept")
