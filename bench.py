@@ -516,6 +516,8 @@ def main():
 
     def make_model(precision):
         m = DiT.from_config(F5TTS_335M, precision=precision, device=device)
+        if os.environ.get("F5_BENCH_LN_FOLD") is not None:             # A/B runs under a profiler (tools/gpu_r6_prof_b1.sh); default: the engine's own
+            m.engine.set_option("ln_fold", int(os.environ["F5_BENCH_LN_FOLD"]))
         return m
 
     weights = None

@@ -66,7 +66,8 @@ struct Workspace {
     // LN fold (0 bytes each where the fold cannot run: plan_workspace)
     size_t lnstats;                // per 64-column slice and row (sum d, centred sum of squares) of d = x - lnmean, [D / 64][M2][2] floats
     size_t lnrowf;                 // row factors (rstd, rstd * (mean - lnmean)), [M2][2] floats
-    size_t lnmean;                 // the row's mean at its previous LayerNorm = the shift of the next folded operand, [M2] floats
+    size_t lnmean;                 // the row's mean at its previous LayerNorm = the shift of the next folded operand, 2 x [M2] floats: the
+                                   // consumers that merge the statistics themselves (option fold_stats) read one and write the other
     size_t foldc[2];               // c1, c2 tables, [nfe][L][3 D + FF] floats each
     bool fold_planned;
     size_t vt_bytes;
@@ -93,6 +94,9 @@ struct F5Options {
     int ln_fold = -1;     // LN-modulate folded into the GEMMs around it (gemm.hpp fold_*): -1 = where it is measured faster (>= LN_FOLD_AUTO_ROWS
                           // rows and the four block GEMMs on the staged kernels, one-pass operand modes), 0 = never, 1 = wherever it can run
                           // (batch >= 4 at the 335M shape; fails loudly elsewhere)
+    int fold_stats = -1;  // LN fold: 1 = the consumer GEMMs merge the producer's slice statistics into their row factors themselves (gemm.hpp fold_stats;
+                          // width 1024 only), 0 = a f5_fold_rows launch between producer and consumer (round 4-5; rules the batch-1-sized route
+                          // out), -1 = the statistics form on the batch-1-sized route only
     int graph_split = 0;  // 0: a call is ONE hipGraphExec (~5 000 kernel nodes at 32 points); 1: one exec per ODE step (prep rides in the first), launched
                           // back to back -- the same kernels with the same arguments, 31 replays of ~165 nodes (round-6 probe: does a long exec cost more per node?)
     int sat_check = 1;    // precision f16: every 16-bit operand producer reports values beyond +-65 504 in the status word (bit 2); 0 = A/B
@@ -340,6 +344,7 @@ extern "C" int f5_engine_set_option(f5_engine* e, const char* name, int value) {
     else if (n == "ln_fold") e->opt.ln_fold = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "sat_check") e->opt.sat_check = value ? 1 : 0;
     else if (n == "graph_split") e->opt.graph_split = value ? 1 : 0;
+    else if (n == "fold_stats") e->opt.fold_stats = value < 0 ? -1 : (value ? 1 : 0);
     else {
         f5_set_error("unknown engine option %s (q_premul, qkv_transposed, ln_fusion, gemm_flags, attn_pipe, null_keeps_cond, ln_fold, sat_check)", name);
         return 2;
@@ -358,6 +363,7 @@ extern "C" int f5_engine_get_option(f5_engine* e, const char* name, int* value) 
     else if (n == "ln_fold") *value = e->opt.ln_fold;
     else if (n == "sat_check") *value = e->opt.sat_check;
     else if (n == "graph_split") *value = e->opt.graph_split;
+    else if (n == "fold_stats") *value = e->opt.fold_stats;
     else {
         f5_set_error("unknown engine option %s", name);
         return 2;
@@ -467,6 +473,11 @@ extern "C" int f5_finalize_weights(f5_engine* e, void* stream) {
 // 16 +0.8 %, 32 +2.5 %: the LN launches it removes cost ~2 us per thousand rows, what it adds (x16 write in the residual epilogues, the
 // row-factor kernel) has a floor
 constexpr long LN_FOLD_AUTO_ROWS = 22000;
+// The batch-1-sized route (round 6): all four block GEMMs are ONE round of workgroups, the consumers merge the slice statistics themselves
+// (no row-factor launch), so the fold removes 44 of the 46 LN-modulate launches of a forward for a few hundred VALU instructions in the
+// residual epilogues.  LN_FOLD_SMALL_AUTO: chosen by the automatic mode (-1) where the route applies.
+constexpr long LN_FOLD_SMALL_ROWS = 2048;
+constexpr bool LN_FOLD_SMALL_AUTO = false;     // measured -0.5 ... -1.5 % at batch 1 (profiles/r06): below the 4 % bar, so opt-in (ln_fold = 1)
 
 static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int steps, int method) {
     const f5_config& c = e->cfg;
@@ -529,11 +540,13 @@ static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int st
     }
     // LN fold buffers only where the fold can run (a superset of ln_fold_state(): that one also knows the branch count of the call):
     // one-pass 16-bit operand modes, the option not 0, and -- in the automatic mode -- enough rows for it to be chosen with both branches
-    w.fold_planned = np == 1 && e->prec != F5_PREC_MXFP8 && e->opt.ln_fold != 0 && (e->opt.ln_fold == 1 || (long)M2 >= LN_FOLD_AUTO_ROWS);
+    // (... or few enough for the single-round kernels of the batch-1-sized route, gemm.hpp f5_gemm_fold_small: <= 2 048 rows at width 1024)
+    w.fold_planned = np == 1 && e->prec != F5_PREC_MXFP8 && e->opt.ln_fold != 0 &&
+                     (e->opt.ln_fold == 1 || (long)M2 >= LN_FOLD_AUTO_ROWS || ((long)M2 <= LN_FOLD_SMALL_ROWS && LN_FOLD_SMALL_AUTO));
     const size_t fp = w.fold_planned ? 1 : 0;
     w.lnstats = b.take(fp * M2 * (size_t)((D + 63) / 64) * 2 * 4);
     w.lnrowf = b.take(fp * M2 * 2 * 4);
-    w.lnmean = b.take(fp * M2 * 4);
+    w.lnmean = b.take(fp * 2 * M2 * 4);
     for (int p = 0; p < 2; ++p) w.foldc[p] = b.take(fp * nfe1 * L * (size_t)(3 * D + FF) * 4);
     w.h8 = w.h8s = w.ao8 = w.ao8s = w.ffh8 = w.ffh8s = 0;
     if (e->prec == F5_PREC_MXFP8) {
@@ -617,26 +630,30 @@ static int ln_fold_state(const Ctx& c) {
     const int D = cf.dim, FF = cf.ff_dim, M = c.nb * c.B * c.N;
     bool ok = e->np == 1 && e->prec != F5_PREC_MXFP8 && e->opt.qkv_tr && !e->opt.fuse_ln && D % 256 == 0 && D <= 2048 && FF % 256 == 0 &&
               (e->opt.gemm_flags & 16384) == 0 && cf.depth >= 1;
+    bool small = ok && D == 1024 && e->opt.fold_stats != 0 && (e->opt.gemm_flags & (8 | 256)) == 0;   // the single-round kernels: statistics form only
     if (ok) {
         F5GemmArgs g;
         memset(&g, 0, sizeof(g));
         g.M = M;
         g.seq_len = c.N;
+        g.nseg = 1;
         const int shapes[4][3] = {{3 * D, D, EPI_QKV_ROPE}, {D, D, EPI_RESID_GATE}, {FF, D, EPI_GELU_TANH}, {D, FF, EPI_RESID_GATE}};
         for (const auto& sh : shapes) {
             g.N = sh[0];
             g.K = sh[1];
             ok = ok && c.ops.gemm_runs_staged(g, sh[2]);
+            small = small && c.ops.gemm_fold_small(g, sh[2], true);
         }
     }
-    if (e->opt.ln_fold < 0 && M < LN_FOLD_AUTO_ROWS) return 0;
-    if (!c.w.fold_planned) ok = false;              // (cannot happen: the plan's predicate is a superset of this one)
-    if (!ok && e->opt.ln_fold == 1) {
+    if (e->opt.ln_fold < 0 && !(M >= LN_FOLD_AUTO_ROWS && ok) && !(small && LN_FOLD_SMALL_AUTO)) return 0;
+    if (!c.w.fold_planned) ok = small = false;      // (cannot happen: the plan's predicate is a superset of this one)
+    if (!ok && !small && e->opt.ln_fold == 1) {
         f5_set_error("ln_fold = 1: this shape / precision cannot run the folded LN (needs f16 or bf16, qkv_transposed, no ln_fusion, dim %% 256 "
-                     "== 0, and all four block GEMMs on the 256x256 / role-split 128x256 kernels: batch >= 4 at the 335M shape)");
+                     "== 0, and all four block GEMMs on the 256x256 / role-split 128x256 kernels -- batch >= 4 at the 335M shape -- or on the "
+                     "single-round kernels of the batch-1-sized route: width 1024, fold_stats != 0)");
         return -1;
     }
-    return ok ? 1 : 0;
+    return ok ? 1 : (small ? 2 : 0);
 }
 
 // loop-invariant preparation: time/adaLN tables, text path, hoisted input projection, masks, rope
@@ -894,11 +911,27 @@ static int run_dit(const Ctx& c, int j) {
     // LN in their epilogues with the constants of this evaluation (run_prep)
     const int fold_state = ln_fold_state(c);
     if (fold_state < 0) return 2;
-    const bool fold = fold_state == 1;
+    const bool fold = fold_state >= 1;
     const float* fc1 = c.p<float>(w.foldc[0]) + (size_t)j * L * (3 * D + FF);
     const float* fc2 = c.p<float>(w.foldc[1]) + (size_t)j * L * (3 * D + FF);
+    // the rows' shift m lives in lnmean[cur_mean]; with fold_stats a consumer reads it, writes the rows' new means into the other half and
+    // the halves swap; with a f5_fold_rows launch the kernel updates lnmean[0] in place
+    // statistics form: always on the batch-1-sized route (state 2: its kernels have no other), by option on the staged kernels (measured
+    // slower there: every tile of a multi-round launch repeats the merge -- +1.9 % at batch 32, +1.6 % at 8, profiles/r06)
+    const bool stats_form = fold_state == 2 || (fold && e->opt.fold_stats == 1 && D == 1024);
+    int cur_mean = 0;
+    auto lnmean = [&](int which) { return c.p<float>(w.lnmean) + (size_t)which * M; };
     auto fold_consumer = [&](F5GemmArgs& g, int block, int col0) {
-        g.fold_rowf = c.p<float>(w.lnrowf);
+        if (stats_form) {
+            g.fold_stats = c.p<float>(w.lnstats);
+            g.fold_stats_ld = M;
+            g.fold_shift = lnmean(cur_mean);
+            g.fold_mean_out = lnmean(cur_mean ^ 1);
+            g.fold_eps = 1e-6f;
+            cur_mean ^= 1;
+        } else {
+            g.fold_rowf = c.p<float>(w.lnrowf);
+        }
         g.fold_c1 = fc1 + (size_t)block * (3 * D + FF) + col0;
         g.fold_c2 = fc2 + (size_t)block * (3 * D + FF) + col0;
     };
@@ -906,12 +939,15 @@ static int run_dit(const Ctx& c, int j) {
         g.x16_out = c.pb(w.h, 0);
         g.ldx16 = D;
         g.x16_scale = next_scale;
-        g.x16_shift = c.p<float>(w.lnmean);        // the row's mean at the previous LayerNorm (LN kernel of block 0 / fold_rows)
+        g.x16_shift = lnmean(cur_mean);            // the row's mean at the previous LayerNorm (LN kernel of block 0 / the last consumer / fold_rows)
         g.stats_out = c.p<float>(w.lnstats);
         g.stats_ld = M;
         g.x16_overflow = c.p<int>(w.status);
     };
-    auto fold_rows = [&]() { return K.fold_rows(c.p<float>(w.lnstats), M, D / 64, M, 1e-6f, c.p<float>(w.lnrowf), c.p<float>(w.lnmean), s); };
+    auto fold_rows = [&]() {
+        if (stats_form) return 0;
+        return K.fold_rows(c.p<float>(w.lnstats), M, D / 64, M, 1e-6f, c.p<float>(w.lnrowf), c.p<float>(w.lnmean), s);
+    };
     bool h_folded = false;                       // `h` holds x (1 + scale) + row sums (fold) instead of the finished LN-modulate
     for (int i = 0; i < L && e->prec != F5_PREC_MXFP8; ++i) {
         const BlockW& bw = e->blocks[i];
@@ -1118,7 +1154,7 @@ static int stage_inputs(Ctx& c, const f5_sample_args* a, const float* x_override
                "internal: scalar staging layout");
     const int fold_state = ln_fold_state(c);
     if (fold_state < 0) return 2;
-    words[0] = fold_state == 1 ? 2u : 0u;            // status word: bit 1 = the LN fold runs in this call, bit 0 is the kernels'
+    words[0] = fold_state >= 1 ? 2u : 0u;            // status word: bit 1 = the LN fold runs in this call, bit 0 is the kernels'
     uint32_t* wd = words.data() + 1;
     memcpy(wd, a->lens, (size_t)c.B * 4);
     for (int b = 0; b < c.B; ++b) wd[c.B + b] = wd[2 * c.B + b] = (uint32_t)a->durations[b];
@@ -1184,8 +1220,8 @@ extern "C" int f5_sample(f5_engine* e, const f5_sample_args* a, void* stream) {
     // hipGraph cache.  The key is everything a captured node depends on BY VALUE: shapes, solver, branch count, masking and the
     // workspace address.  Per-call scalars (cfg strength, time grid, dt) are read from workspace memory staged above.
     char key[256];
-    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d nk%d lf%d sc%d gs%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
-             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, e->opt.null_keeps_cond, e->opt.ln_fold, e->opt.sat_check, e->opt.graph_split, g_knob_epoch,
+    snprintf(key, sizeof(key), "B%d N%d nt%d st%d m%d nb%d mask%d ln%d qp%d qt%d gf%d ap%d nk%d lf%d sc%d gs%d fs%d ke%d ws%p", c.B, c.N, c.nt, a->steps, a->method, c.nb,
+             (int)c.use_mask, e->opt.fuse_ln, e->opt.q_premul, e->opt.qkv_tr, e->opt.gemm_flags, e->opt.attn_pipe, e->opt.null_keeps_cond, e->opt.ln_fold, e->opt.sat_check, e->opt.graph_split, e->opt.fold_stats, g_knob_epoch,
              a->workspace);
     bool graph = a->use_graph == 1;
     if (a->use_graph == F5_GRAPH_AUTO) {
@@ -1534,10 +1570,25 @@ extern "C" int f5_debug_set_op_fold_consumer(const float* rowf, const float* c1,
     g_op_fold.c2 = c2;
     return 0;
 }
+// the statistics form (gemm.hpp fold_stats): the consumers of the f5_op_* launches that follow merge the producer's slice statistics
+// themselves; stats = the producer's stats_out ([16][ld][2]), shift = what it subtracted (or NULL), mean_out = where column tile 0
+// writes the rows' means (or NULL).  Takes the place of `rowf` of f5_debug_set_op_fold_consumer (set that one with rowf = NULL).
+static struct { const float* stats; int ld; const float* shift; float* mean_out; } g_op_fold_stats = {nullptr, 0, nullptr, nullptr};
+extern "C" int f5_debug_set_op_fold_stats(const float* stats, int ld, const float* shift, float* mean_out) {
+    g_op_fold_stats = {stats, ld, shift, mean_out};
+    return 0;
+}
 static void op_fold_consumer(F5GemmArgs& g) {
     g.fold_rowf = g_op_fold.rowf;
     g.fold_c1 = g_op_fold.c1;
     g.fold_c2 = g_op_fold.c2;
+    if (g_op_fold.rowf == nullptr) {
+        g.fold_stats = g_op_fold_stats.stats;
+        g.fold_stats_ld = g_op_fold_stats.ld;
+        g.fold_shift = g_op_fold_stats.shift;
+        g.fold_mean_out = g_op_fold_stats.mean_out;
+        g.fold_eps = 1e-6f;
+    }
 }
 extern "C" int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, float* row_shift, void* stream) {
     return g_ops.fold_rows(stats, M, nslice, M, 1e-6f, rowf, row_shift, (hipStream_t)stream);
@@ -1570,7 +1621,7 @@ extern "C" int f5_op_gemm(const void* a_hi, const void* a_lo, const void* w_hi, 
     g.out_bf[0] = (op16_t*)out_bf_hi;
     g.out_bf[1] = (op16_t*)out_bf_lo;
     g.ldob = ldo;
-    if (epi == EPI_GELU_TANH && g_op_fold.rowf != nullptr) op_fold_consumer(g);
+    if (epi == EPI_GELU_TANH && (g_op_fold.rowf != nullptr || g_op_fold_stats.stats != nullptr)) op_fold_consumer(g);
     return g_ops.gemm(g, epi, (hipStream_t)stream);
 }
 
@@ -1682,7 +1733,7 @@ extern "C" int f5_op_qkv_rope(const void* a_hi, const void* a_lo, const void* w_
     g.rope_g4k = g_op_rope_t[1];
     g.vt[0] = (op16_t*)vt_hi;
     g.vt[1] = (op16_t*)vt_lo;
-    if (g_op_fold.rowf != nullptr) op_fold_consumer(g);
+    if (g_op_fold.rowf != nullptr || g_op_fold_stats.stats != nullptr) op_fold_consumer(g);
     return g_ops.gemm(g, EPI_QKV_ROPE, (hipStream_t)stream);
 }
 

@@ -38,65 +38,6 @@ struct ResidPre {
     float bias[NB], gate[NB];
     uint32_t keep[MB][4];       // keep bytes of rows (rg*8 + hi*4 + 0..3) of row block mb
 };
-template <int MB, int NB>
-__device__ __forceinline__ void resid_preload(const F5GemmArgs& p, ResidPre<MB, NB>& q, int row0, int colbase, int lane) {
-    const int hi = lane >> 5, lcol = lane & 31;
-    const bool keep_words = p.rowkeep != nullptr && (reinterpret_cast<uintptr_t>(p.rowkeep) & 3) == 0;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int c = colbase + nb * 32 + lcol;
-        const bool ok = c < p.N;
-        q.bias[nb] = (p.bias != nullptr && ok) ? p.bias[c] : 0.0f;
-        q.gate[nb] = ok ? p.gate[c] : 0.0f;
-    }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int rowb = row0 + mb * 32 + rg * 8 + hi * 4;
-            uint32_t kw = 0x01010101u;
-            if (p.rowkeep != nullptr) {
-                if (keep_words && rowb + 3 < p.M) {
-                    kw = *reinterpret_cast<const uint32_t*>(p.rowkeep + rowb);
-                } else {
-                    kw = 0;
-#pragma unroll
-                    for (int ri = 0; ri < 4; ++ri)
-                        if (rowb + ri < p.M) kw |= (uint32_t)p.rowkeep[rowb + ri] << (8 * ri);
-                }
-            }
-            q.keep[mb][rg] = kw;
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int row = rowb + ri, c = colbase + nb * 32 + lcol;
-                    q.x[mb][rg * 4 + ri][nb] = (row < p.M && c < p.N) ? p.out_f32[(size_t)row * p.ldo + c] : 0.0f;
-                }
-        }
-}
-template <int MB, int NB>
-__device__ __forceinline__ void resid_epilogue_preloaded(const F5GemmArgs& p, f32x16 (&acc)[MB][NB], const ResidPre<MB, NB>& q, int row0,
-                                                         int colbase, int lane) {
-    const int hi = lane >> 5, lcol = lane & 31;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const int row = row0 + mb * 32 + rg * 8 + hi * 4 + ri;
-                const bool kp = ((q.keep[mb][rg] >> (8 * ri)) & 0xffu) != 0;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int c = colbase + nb * 32 + lcol;
-                    float v = acc[mb][nb][rg * 4 + ri] + q.bias[nb];
-                    if (!kp) v = 0.0f;
-                    if (row < p.M && c < p.N) p.out_f32[(size_t)row * p.ldo + c] = q.x[mb][rg * 4 + ri][nb] + q.gate[nb] * v;
-                }
-            }
-}
-
 // ---- LN-modulate fused behind the residual update (EPI_RESID_GATE of the small-tile kernels, batch-1-sized problems) ------
 // At M = 2*937 every launch is one round of workgroups and costs ~2 us of launch / drain on top of its work, and the
 // stand-alone LN-modulate kernels are 2 of the 7 launches of a DiT block (5.2 us each).  Instead, every workgroup of the
@@ -339,7 +280,10 @@ static int ring_order(const F5GemmArgs& a, int tiles_m, int tiles_n) {
 
 // ABL (timing experiments only, results are garbage; tools/ring_ablate.py): 1 = no operand loads after the prologue, 2 = no MFMAs,
 // 4 = no LDS fragment reads, 8 = no workgroup barrier -- what a K step of a lone workgroup is made of
-template <int EPI, int MB, int NB, int NST, int WM = 2, int WN = 2, int KS = 1, int ABL = 0>
+// FOLD (round 6, batch-1-sized launches of the LN fold, gemm.hpp): 1 = EPI_RESID_GATE writes the folded operand and its slice statistics
+// (staged_epilogue_resid with its loads requested before the K loop), 2 = EPI_GELU_TANH is a fold consumer that merges the producer's statistics itself (fold_stats), on
+// transposed wave tiles like the large kernels
+template <int EPI, int MB, int NB, int NST, int WM = 2, int WN = 2, int KS = 1, int ABL = 0, int FOLD = 0>
 __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmArgs p, int tiles_n, int ntiles) {
     // WM x WN waves per K group, wave tile 32*MB x 32*NB; KS groups split the K tiles round-robin (group g owns tiles
     // g, g+KS, ...; its own ring) and are summed in group order through LDS at the end: small-M problems are one round
@@ -453,7 +397,24 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     constexpr bool PRE_RESID = EPI == EPI_RESID_GATE && MB * NB <= 3;   // 64 more live VGPRs would spill the 2x2 wave tile
     ResidPre<PRE_RESID ? MB : 1, PRE_RESID ? NB : 1> rpre;
     const bool use_pre = PRE_RESID && p.ln_counter == nullptr && (p.debug_flags & (8 | 256)) == 0;
-    if (PRE_RESID && use_pre && grp == 0) resid_preload<PRE_RESID ? MB : 1, PRE_RESID ? NB : 1>(p, rpre, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane);
+    if (PRE_RESID && use_pre && grp == 0 && FOLD != 1)
+        resid_preload<PRE_RESID ? MB : 1, PRE_RESID ? NB : 1>(p, rpre, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane);
+    static_assert(FOLD == 0 || (FOLD == 1 && PRE_RESID && NB == 2) || (FOLD == 2 && EPI == EPI_GELU_TANH && NB == 2 && KS == 1 && WM * WN == 8),
+                  "fold producer = the preloaded residual epilogue on 64-column wave tiles; fold consumer = the 8-wave GELU launch");
+    // fold producer: the LDS-staged residual epilogue of the large kernels (16-byte accesses in full row segments, slice statistics by
+    // 16-lane DPP reductions), with its rows of x / keep bytes / shifts / column vectors requested here, before the K loop (a straight-tile
+    // variant -- lane = column, a 32-lane butterfly per row -- measured +3.7 us per launch against +1.6 for this one, profiles/r06)
+    ResidStagedPre<FOLD == 1 ? NB : 1> spre_p;
+    if constexpr (FOLD == 1) {
+        if (grp == 0) resid_staged_preload<NB>(p, spre_p, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane);
+    }
+    // fold consumer: the slice statistics of this lane's rows and its c1 | c2 columns -- older than every operand load, so the first
+    // counted wait of the K loop covers them too
+    FoldPre fpre_c;
+    fold_prefetch_clear(fpre_c);
+    FoldStatsPre<8> spre_c;
+    fold_stats_clear(spre_c);
+    if constexpr (FOLD == 2) fold_stats_request_tr<1>(p, spre_c, fpre_c, m0 + wm * 32, n0 + wn * 64, lane);
 
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
@@ -517,6 +478,27 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
     // tiles (an LDS-free variant of this path returned wrong values on lanes 48-63 there in round 2; round 3 traced that to
     // SLP-packed f32 instructions next to other workgroups' MFMAs -- profiles/r03/pk_f32_next_to_mfma_hazard.txt -- which is why
     // this file is built with -fno-slp-vectorize; the 4-wave kernels gain nothing from transposed tiles at the sizes they serve).
+    if constexpr (FOLD == 2) {
+        // the statistics and c1 | c2 have landed with the first K tile (they are older): merge them into this lane's row factor now,
+        // while the other tiles are in flight
+        if (NST == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fold_stats_pin(spre_c);
+        fold_stats_finish_tr<1>(p, spre_c, fpre_c, m0 + wm * 32, lane, p.fold_mean_out != nullptr && n0 == 0 && wn == 0);
+        fold_prefetch_pin(fpre_c);
+        for (int jj = 0; jj < nit; jj += NST) {
+            RING_STEP(0, jj, true);
+            if (NST > 1 && jj + 1 < nit) RING_STEP(1 % NST, jj + 1, true);
+            if (NST > 2 && jj + 2 < nit) RING_STEP(2 % NST, jj + 2, true);
+            if (NST > 3 && jj + 3 < nit) RING_STEP(3 % NST, jj + 3, true);
+        }
+        __syncthreads();                                  // the ring is dead: its LDS becomes the staging area
+        static_assert(FOLD != 2 || WM * WN * (small_tile_stage_elems<NB>() * 2 + 512) <= RING * 2, "staging + c1 | c2 scratch fit in the ring");
+        float* fl = reinterpret_cast<float*>(smem_all + WM * WN * small_tile_stage_elems<NB>()) + wave * 128;
+        staged_epilogue_tr<EPI, MB, NB, true>(p, acc, smem_all + wave * small_tile_stage_elems<NB>(), m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane,
+                                              fl, &fpre_c);
+        return;
+    }
     constexpr bool QKV_TR_OK = EPI == EPI_QKV_ROPE && (32 * NB) % 64 == 0 && (NB & (NB - 1)) == 0 && KS == 1 && WM * WN == 8;
     if (QKV_TR_OK && p.rope_g4k != nullptr && n0 + wn * (32 * NB) < 2 * p.dmodel) {
         for (int jj = 0; jj < nit; jj += NST) {
@@ -583,6 +565,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void f5_gemm_ring_kernel(F5GemmA
         return;
     }
 #endif
+    if constexpr (FOLD == 1) {
+        // staging area behind the K-split reduction area (other waves of the group may still be reading theirs)
+        constexpr int RED_BYTES = (KS - 1) * WM * WN * MB * NB * 16 * 64 * 4;
+        static_assert(RED_BYTES + WM * WN * 32 * (32 * NB + 4) * 4 <= KS * RING * 2, "staging behind the reduction area");
+        float* stg = reinterpret_cast<float*>(reinterpret_cast<char*>(smem_all) + RED_BYTES) + wave * (32 * (32 * NB + 4));
+        staged_epilogue_resid<MB, NB, true>(p, acc, stg, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane, &spre_p);
+        return;
+    }
     if constexpr (PRE_RESID) {
         if (use_pre) {
             resid_epilogue_preloaded<MB, NB>(p, acc, rpre, m0 + wm * (32 * MB), n0 + wn * (32 * NB), lane);
@@ -618,6 +608,13 @@ static int launch_ring_ks2(const F5GemmArgs& a, hipStream_t stream) {
     const int ntiles = tiles_m * tiles_n;
     const int order = ring_order(a, tiles_m, tiles_n);
     constexpr int NST = MB == 1 ? 3 : 2;
+    if constexpr (EPI == EPI_RESID_GATE && MB == 1) {
+        if (a.x16_out != nullptr) {                       // LN-fold producer (f5_gemm_fold_small has checked the preconditions)
+            hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, 2, NST, 2, 2, 2, 0, 1>), dim3(ntiles), dim3(512), 0, stream, a, order, ntiles);
+            F5_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, MB, 2, NST, 2, 2, 2>), dim3(ntiles), dim3(512), 0, stream, a, order, ntiles);
     F5_LAUNCH_CHECK();
     return 0;
@@ -630,6 +627,13 @@ static int launch_ring8(const F5GemmArgs& a, hipStream_t stream) {
     const int ntiles = tiles_m * tiles_n;
     const int order = ring_order(a, tiles_m, tiles_n);
     constexpr int NST = (BMt + BNt) * 64 * 2 * 4 <= 128 * 1024 ? 4 : 3;
+    if constexpr (EPI == EPI_GELU_TANH && NB == 2) {
+        if (a.fold_stats != nullptr) {                    // LN-fold consumer, statistics form (f5_gemm_fold_small has checked the preconditions)
+            hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, 1, NB, NST, 4, 2, 1, 0, 2>), dim3(ntiles), dim3(512), 0, stream, a, order, ntiles);
+            F5_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((f5_gemm_ring_kernel<EPI, 1, NB, NST, 4, 2>), dim3(ntiles), dim3(512), 0, stream, a, order, ntiles);
     F5_LAUNCH_CHECK();
     return 0;
@@ -723,9 +727,30 @@ bool f5_gemm_runs_staged(const F5GemmArgs& a, int epi) {
     return qkv_rows_ok && (sel == 14 || (sel == 0 && t128 >= 384));
 }
 
+// The batch-1-sized route of the LN fold (round 6): true when f5_launch_gemm sends this launch to the single-round kernel that implements
+// the fold for its role -- EPI_RESID_GATE: the 64 x 128 split-K ring kernel with the preloaded residual epilogue (producer: x16_out /
+// stats_out), EPI_GELU_TANH: the 8-wave 128 x 128 ring kernel (consumer, statistics form only: fold_stats), EPI_QKV_ROPE: one round of
+// role-split 128 x 256 tiles (consumer; `qkv_tr` = the group-major rotation tables will be set).  Same rules as launch_epi below.
+bool f5_gemm_fold_small(const F5GemmArgs& a, int epi, bool qkv_tr) {
+    if (f5_gemm_tile_override != 0 || !f5_gemm_ring_default || a.ln_counter != nullptr || a.nseg != 1 || a.N % 256 != 0 || a.M < 1) return false;
+    const long t256 = (long)f5_cdiv(a.M, 256) * (a.N / 256);
+    const long t128 = (long)f5_cdiv(a.M, 128) * f5_cdiv(a.N, 128);
+    const long t64x128 = (long)f5_cdiv(a.M, 64) * f5_cdiv(a.N, 128);
+    if ((a.M >= 256 && t256 >= 512) || t128 >= 384) return false;                 // the staged multi-round kernels take these
+    if (epi == EPI_QKV_ROPE) {
+        if (!qkv_tr || a.seq_len <= 0 || a.M % a.seq_len != 0 || f5_gemm_qkv_small_tile != 0) return false;
+        const long t = (long)(a.M / a.seq_len) * f5_cdiv(a.seq_len, 128) * (a.N / 256);
+        return t >= 176 && t <= 256;
+    }
+    if (epi == EPI_GELU_TANH) return t128 >= 176 && t128 <= 256;
+    if (epi == EPI_RESID_GATE) return !(t128 >= 176 && t128 <= 256) && t64x128 >= 176 && t64x128 <= 256 && (a.debug_flags & (8 | 256)) == 0;
+    return false;
+}
+
 // ---- constants of the LN fold (gemm.hpp): one wave holds FC_ROWS weight rows in registers as fp32 and streams every modulation
 // vector past them (the vectors are L2-resident: nvec x 2 x K floats)
 constexpr int FC_ROWS = 4, FC_MAXC = 8;
+int f5_fold_consts_mfma = 1;     // 0 = the VALU kernel (A/B)
 __global__ __launch_bounds__(256) void f5_fold_consts_kernel(const op16_t* __restrict__ w, int ldw, const float* __restrict__ bias,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, size_t vec_stride,
                                                              int nvec, float* __restrict__ c1, float* __restrict__ c2, size_t out_stride, int N,
@@ -793,6 +818,83 @@ __global__ __launch_bounds__(256) void f5_fold_consts_kernel(const op16_t* __res
     }
 }
 
+// The same constants on the matrix cores (round 6).  The VALU kernel above spends 48 cross-lane operations per modulation vector and four
+// weight rows: 455 us per projection for the 31 evaluations x 22 blocks of a 32-point solve -- nothing at batch 32, 1.3 % of a batch-1
+// sample().  Here a wave owns 32 output columns and all (<= 128) modulation vectors: C[v][n] = sum_k S[v][k] W[n][k] as
+// v_mfma_f32_32x32x16 with W straight from memory (its rows ARE the operand: 8 consecutive k per lane, 16-byte loads) and S split on
+// the fly into an operand-typed (hi, lo) pair, S ~ hi + lo (fp16: 22 significand bits, fp32-class; bf16: 16), two MFMAs per product.
+// Every weight row is read once per launch (10.5 MB per block), the vectors 32x less often than before.
+template <int NVB>
+__global__ __launch_bounds__(256) void f5_fold_consts_mfma_kernel(const op16_t* __restrict__ w, int ldw, const float* __restrict__ bias,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  size_t vec_stride, int nvec, float* __restrict__ c1, float* __restrict__ c2,
+                                                                  size_t out_stride, int N, int K, F5FoldBatch bt) {
+    w += (size_t)blockIdx.y * bt.w_stride;
+    if (bias) bias += (size_t)blockIdx.y * bt.bias_stride;
+    scale += (size_t)blockIdx.y * bt.mod_stride;
+    shift += (size_t)blockIdx.y * bt.mod_stride;
+    c1 += (size_t)blockIdx.y * bt.out_blk_stride;
+    c2 += (size_t)blockIdx.y * bt.out_blk_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * 32;
+    if (n0 >= N) return;
+    const int lr = lane & 31, kh = (lane >> 5) * 8;
+    const int nrow = n0 + lr < N ? n0 + lr : N - 1;
+    const op16_t* wp = w + (size_t)nrow * ldw + kh;
+    const float* sp[NVB];
+    const float* bp[NVB];
+#pragma unroll
+    for (int vb = 0; vb < NVB; ++vb) {
+        const int v = vb * 32 + lr < nvec ? vb * 32 + lr : nvec - 1;
+        sp[vb] = scale + (size_t)v * vec_stride + kh;
+        bp[vb] = shift + (size_t)v * vec_stride + kh;
+    }
+    f32x16 a1[NVB], a2[NVB];
+#pragma unroll
+    for (int vb = 0; vb < NVB; ++vb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a1[vb][e] = a2[vb][e] = 0.0f;
+    auto split = [](const f32x4& lo4, const f32x4& hi4, float add, op16x8& h, op16x8& l) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (e < 4 ? lo4[e] : hi4[e - 4]) + add;
+            const op16_t hh = f5_f2op(f);
+            h[e] = hh;
+            l[e] = static_cast<op16_t>(f - static_cast<float>(hh));
+        }
+    };
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const op16x8 wf = *reinterpret_cast<const op16x8*>(wp + k0);
+#pragma unroll
+        for (int vb = 0; vb < NVB; ++vb) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp[vb] + k0), s1 = *reinterpret_cast<const f32x4*>(sp[vb] + k0 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp[vb] + k0), b1 = *reinterpret_cast<const f32x4*>(bp[vb] + k0 + 4);
+            op16x8 sh, sl, bh, bl;
+            split(s0, s1, 1.0f, sh, sl);
+            split(b0, b1, 0.0f, bh, bl);
+            a1[vb] = F5_MFMA32(sh, wf, a1[vb], 0, 0, 0);
+            a1[vb] = F5_MFMA32(sl, wf, a1[vb], 0, 0, 0);
+            a2[vb] = F5_MFMA32(bh, wf, a2[vb], 0, 0, 0);
+            a2[vb] = F5_MFMA32(bl, wf, a2[vb], 0, 0, 0);
+        }
+    }
+    // C layout: lane = column n0 + lr, register r = vector vb * 32 + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
+    const int n = n0 + lr;
+    if (n < N) {
+        const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int vb = 0; vb < NVB; ++vb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = vb * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (v < nvec) {
+                    c1[(size_t)v * out_stride + n] = a1[vb][r];
+                    c2[(size_t)v * out_stride + n] = a2[vb][r] + bn;
+                }
+            }
+    }
+}
+
 // Slice statistics -> row factors.  A slice carries (sum d, sum (d - its own mean)^2) of 64 values d = x - m; the row's statistics are
 // the group form of Chan's merge -- mean = sum of the slice sums / n, M2 = sum of the slice M2 + 64 sum (slice mean - mean)^2: every
 // term is a sum of squares, nothing of the size of mean^2 is ever subtracted (the round-4 kernel computed E[x^2] - E[x]^2 from one-pass
@@ -810,15 +912,23 @@ __global__ __launch_bounds__(256) void f5_fold_rows_kernel(const float* __restri
         f5_f32x2 t[NS > 0 ? NS : 1];
 #pragma unroll
         for (int i = 0; i < NS; ++i) t[i] = sp[(size_t)i * ld];
-        float s = 0.0f;
+        // (slices 0 .. NS/2 - 1 in order) + (slices NS/2 .. in order): the order the consumers use when they merge the statistics
+        // themselves (gemm_dev.hpp fold_stats_finish_*: two lane halves / two in-lane chains) -- one bit pattern per row either way
+        float s_lo = t[0][0], s_hi = t[NS / 2][0];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) s += t[i][0];          // slice order: deterministic
-        mean = s * inv_n;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const float dm = t[i][0] * (1.0f / 64.0f) - mean;
-            m2 += t[i][1] + 64.0f * dm * dm;
+        for (int i = 1; i < NS / 2; ++i) {
+            s_lo += t[i][0];
+            s_hi += t[NS / 2 + i][0];
         }
+        mean = (s_lo + s_hi) * inv_n;
+        float m_lo = 0.0f, m_hi = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NS / 2; ++i) {
+            const float d0 = t[i][0] * (1.0f / 64.0f) - mean, d1 = t[NS / 2 + i][0] * (1.0f / 64.0f) - mean;
+            m_lo += t[i][1] + 64.0f * d0 * d0;
+            m_hi += t[NS / 2 + i][1] + 64.0f * d1 * d1;
+        }
+        m2 = m_lo + m_hi;
     } else {
         float s = 0.0f;
         for (int i = 0; i < nslice; ++i) s += sp[(size_t)i * ld][0];
@@ -851,6 +961,19 @@ int f5_launch_fold_consts(const op16_t* w, int ldw, const float* bias, const flo
                256 * FC_MAXC);
     F5_REQUIRE(((reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0,
                "fold_consts: unaligned operand");
+    if (K % 16 == 0 && ldw % 8 == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 && nvec <= 128 && f5_fold_consts_mfma) {
+        const dim3 grid(f5_cdiv(N, 4 * 32), bt.count);
+#define FC_LAUNCH(NVB_) hipLaunchKernelGGL(f5_fold_consts_mfma_kernel<NVB_>, grid, dim3(256), 0, stream, w, ldw, bias, scale, shift, vec_stride, nvec, c1, c2, out_stride, N, K, bt)
+        switch ((nvec + 31) / 32) {
+            case 1: FC_LAUNCH(1); break;
+            case 2: FC_LAUNCH(2); break;
+            case 3: FC_LAUNCH(3); break;
+            default: FC_LAUNCH(4); break;
+        }
+#undef FC_LAUNCH
+        F5_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(f5_fold_consts_kernel, dim3(f5_cdiv(N, 4 * FC_ROWS), bt.count), dim3(256), 0, stream, w, ldw, bias, scale, shift,
                        vec_stride, nvec, c1, c2, out_stride, N, K, bt);
     F5_LAUNCH_CHECK();
@@ -912,8 +1035,14 @@ static int launch_epi(const F5GemmArgs& a, hipStream_t stream) {
         if ((sel == 14 || qkv14 || mid) && a.N % 256 == 0 && a.ln_counter == nullptr) return f5_launch_gemm_rs128(a, EPI, stream);
         if (sel == 14) sel = 0;
     }
-    F5_REQUIRE(a.x16_out == nullptr && a.fold_rowf == nullptr,
-               "gemm: the LN fold (x16_out / fold_rowf) needs a launch on the 256x256 or the role-split 128x256 kernel (f5_gemm_runs_staged)");
+    {
+        // the small single-round kernels implement the fold for exactly the launches f5_gemm_fold_small names (statistics form)
+        const bool small = f5_gemm_fold_small(a, EPI, true);
+        F5_REQUIRE((a.x16_out == nullptr || (small && EPI == EPI_RESID_GATE)) && a.fold_rowf == nullptr &&
+                       (a.fold_stats == nullptr || (small && EPI == EPI_GELU_TANH)),
+                   "gemm: the LN fold (x16_out / fold_rowf / fold_stats) needs a launch on the 256x256 or the role-split 128x256 kernel "
+                   "(f5_gemm_runs_staged), or one of the batch-1-sized launches of f5_gemm_fold_small in the statistics form");
+    }
     if constexpr (EPI == EPI_QKV_ROPE) {
         // batch-1-sized QKV projection with pair-major tables: one round of 8-wave 128 x 256 tiles with transposed q / k wave tiles
         // (f5_gemm_qkv_small_tile = 13 / 12) instead of 64 x 128 register-staged tiles (0)
@@ -978,11 +1107,14 @@ int f5_launch_gemm(const F5GemmArgs& a_in, int epi, hipStream_t stream) {
                        (reinterpret_cast<uintptr_t>(a.stats_out) & 7) == 0,
                    "gemm: LN-fold producer needs EPI_RESID_GATE, x16_out + stats_out + x16_scale (16-byte aligned), N %% 64 == 0");
     }
-    if (a.fold_rowf != nullptr) {
+    if (a.fold_rowf != nullptr || a.fold_stats != nullptr) {
         F5_REQUIRE((epi == EPI_QKV_ROPE || epi == EPI_GELU_TANH) && a.nseg == 1 && a.out_bf[1] == nullptr && a.fold_c1 && a.fold_c2 &&
                        ((reinterpret_cast<uintptr_t>(a.fold_c1) | reinterpret_cast<uintptr_t>(a.fold_c2)) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.fold_rowf) & 7) == 0 && (a.debug_flags & 16384) == 0,
                    "gemm: LN-fold consumer needs EPI_QKV_ROPE / EPI_GELU_TANH, one-pass operands, aligned fold_c1 / fold_c2 / fold_rowf");
+        F5_REQUIRE(a.fold_stats == nullptr || (a.K == 1024 && a.fold_stats_ld >= a.M && (reinterpret_cast<uintptr_t>(a.fold_stats) & 7) == 0 &&
+                                               a.fold_mean_out != a.fold_shift),
+                   "gemm: the statistics form of the LN fold needs K = 1024 (16 slices), fold_stats_ld >= M and fold_mean_out != fold_shift");
         F5_REQUIRE(epi != EPI_QKV_ROPE || (a.rope_g4k && a.dmodel % 256 == 0), "gemm(qkv): the LN fold needs the transposed q / k tiles");
         a.bias = nullptr;                             // inside fold_c2
     }

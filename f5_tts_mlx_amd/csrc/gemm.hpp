@@ -85,6 +85,15 @@ struct F5GemmArgs {
                               // 16-bit tile) went through the fp16 clamp (op16.hpp f5_sat_commit; f5_launch_gemm fills in rowops.hpp
                               // f5_sat_flag_host when this is null)
     const float* fold_rowf;   // [M][2] (rstd, rstd * (mean - m)) or null = plain GEMM
+    // ... or, INSTEAD of fold_rowf (round 6): the producer's slice statistics themselves -- the consumer merges them into its rows' factors
+    // before its K loop (the arithmetic of f5_fold_rows_kernel in the same order: the same bits), so no row-factor launch sits between
+    // producer and consumer: what makes the fold pay at batch 1, where a launch costs what it removes.  K must be 1024 (16 slices).
+    const float* fold_stats;  // [K / 64][fold_stats_ld][2] (sum d, centred sum of squares), as stats_out of the producer; or null
+    int fold_stats_ld;
+    const float* fold_shift;  // [M]: the shift m the producer subtracted (its x16_shift), or null = 0
+    float* fold_mean_out;     // [M]: written with m + mean(d) = the row's mean (the NEXT producer's x16_shift; must not alias fold_shift:
+                              // other workgroups still read it), by the workgroups of column tile 0 only; or null
+    float fold_eps;
     const float* fold_c1;     // [N], 16-byte aligned
     const float* fold_c2;     // [N], 16-byte aligned
     // ---- MX-fp8 path (f5_launch_gemm_f8): e4m3 operands with one E8M0 scale per 32 consecutive K elements
@@ -102,6 +111,9 @@ int f5_launch_gemm(const F5GemmArgs& a, int epi, hipStream_t stream);
 // true when f5_launch_gemm runs this launch on a kernel with the LDS-staged epilogues (256x256 / role-split 128x256): the only ones
 // that implement the x16_out / stats_out / fold_* fields (f5_launch_gemm fails loudly for the others)
 bool f5_gemm_runs_staged(const F5GemmArgs& a, int epi);
+// true when f5_launch_gemm runs this launch on the batch-1-sized (single-round) kernel that implements the LN fold for its role:
+// producer (EPI_RESID_GATE), or consumer in the statistics form (EPI_GELU_TANH, EPI_QKV_ROPE with group-major rotation tables = qkv_tr)
+bool f5_gemm_fold_small(const F5GemmArgs& a, int epi, bool qkv_tr);
 // row factors of the fold: rowf[r] = (rstd, rstd * (mean - m)) of row r from its nslice slice statistics (stats[slice][ld][2] =
 // (sum d, centred sum of squares) of d = x - m; width = 64 nslice).  row_shift (optional, [M]): on entry m (what the producer
 // subtracted; null = 0), on exit the row's mean -- the shift of the next folded operand.

@@ -64,7 +64,8 @@ __device__ unsigned long long f5_probe_ts[F5_PROBE_MAXWG * 8];
 // straight
 // FOLD: the LN-fold consumer (F5GemmArgs::fold_*) as its own instantiation: its requests are issued and pinned on every path of the
 // kernel (gemm_dev.hpp fold_prefetch_pin), the plain kernels carry none of it
-template <int EPI, bool QT, bool FOLD>
+// FOLD: 0 = plain, 1 = row factors from memory (fold_rowf), 2 = merged here from the producer's slice statistics (fold_stats)
+template <int EPI, bool QT, int FOLD>
 __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles_n, int nfull, int tiles_mf) {
     __shared__ __attribute__((aligned(16))) op16_t smem[2 * 4 * V2_HALF_ELEMS];   // [A0,A1,B0,B1][ring buffer][128*64]
 
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
 
     // LN fold: what the epilogue needs from memory is requested here, ahead of the operand loads (gemm_dev.hpp fold_prefetch_pin)
     static_assert(!FOLD || EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH, "fold consumers");
-    constexpr bool fold = FOLD;
+    constexpr bool fold = FOLD != 0;
     const int row0 = m0 + wm * 128, col0 = n0 + wn * 64;
     // 16-bit row-major outputs: the tile is accumulated TRANSPOSED (operands swapped in every MFMA) for staged_epilogue_tr.  Both
     // loop copies end in their own epilogue: no join with 128 live accumulator registers.
@@ -189,9 +190,15 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     const bool tr_path = (TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel);       // workgroup-uniform
     FoldPre fpre;
     fold_prefetch_clear(fpre);
-    if (fold) {
+    FoldStatsPre<FOLD == 2 ? 32 : 8> spre;
+    fold_stats_clear(spre);
+    if (FOLD == 1) {
         if (tr_path) fold_prefetch_tr<4>(p, fpre, row0, col0, lane);
         else fold_prefetch_v<4>(p, fpre, row0, col0, lane);
+    }
+    if constexpr (FOLD == 2) {
+        if (tr_path) fold_stats_request_tr<4>(p, spre, fpre, row0, col0, lane);
+        else fold_stats_request_v<4>(p, spre, fpre, row0, col0, lane);
     }
 
     // ---- prologue: K tile 0 (4 halves) + the B halves of K tile 1; running state = (segment, K offset) of tile tt+1 (A halves)
@@ -212,6 +219,11 @@ __global__ __launch_bounds__(512) void f5_gemm256_kernel(F5GemmArgs p, int tiles
     }
     if (fold) {                        // K tile 0 and the (older) fold requests waited for in full and pinned BEFORE tile 1's B halves
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // are issued: those have most of a K tile to land either way
+        if constexpr (FOLD == 2) {                           // the slice statistics have landed: merge them into this lane's row factors
+            fold_stats_pin(spre);
+            if (tr_path) fold_stats_finish_tr<4>(p, spre, fpre, row0, lane, p.fold_mean_out != nullptr && n0 == 0 && wn == 0);
+            else fold_stats_finish_v<4>(p, spre, fpre);
+        }
         fold_prefetch_pin(fpre);
     }
     if (1 < T) {
@@ -374,13 +386,17 @@ static int launch256(const F5GemmArgs& a, hipStream_t stream) {
     // staged_epilogue_tr reads the bias as 16-byte quads: an unaligned bias vector takes the straight-order path
     if (a.bias != nullptr && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) ab.debug_flags |= 16384;
     constexpr bool CAN_FOLD = EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH;
-    const bool fold = CAN_FOLD && ab.fold_rowf != nullptr;     // (f5_launch_gemm has checked the fold's preconditions: transposed q / k tiles)
+    // (f5_launch_gemm has checked the fold's preconditions: transposed q / k tiles, K = 1024 for the statistics form)
+    const int fold = !CAN_FOLD ? 0 : (ab.fold_stats != nullptr ? 2 : (ab.fold_rowf != nullptr ? 1 : 0));
+    constexpr bool QT = EPI == EPI_QKV_ROPE;
     if (EPI == EPI_QKV_ROPE && ab.rope_g4k != nullptr) {
-        if (fold) hipLaunchKernelGGL((f5_gemm256_kernel<EPI, EPI == EPI_QKV_ROPE, CAN_FOLD>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
-        else hipLaunchKernelGGL((f5_gemm256_kernel<EPI, EPI == EPI_QKV_ROPE, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        if (fold == 2) hipLaunchKernelGGL((f5_gemm256_kernel<EPI, QT, CAN_FOLD ? 2 : 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        else if (fold == 1) hipLaunchKernelGGL((f5_gemm256_kernel<EPI, QT, CAN_FOLD ? 1 : 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        else hipLaunchKernelGGL((f5_gemm256_kernel<EPI, QT, 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
     } else {
-        if (fold) hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false, CAN_FOLD>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
-        else hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        if (fold == 2) hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false, CAN_FOLD ? 2 : 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        else if (fold == 1) hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false, CAN_FOLD ? 1 : 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
+        else hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false, 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, nfull, tiles_mf);
     }
     F5_LAUNCH_CHECK();
     return 0;

@@ -250,6 +250,114 @@ __device__ __forceinline__ void fold_prefetch_v(const F5GemmArgs& p, FoldPre& f,
     f.c[3] = p.fold_c2[col0 + 32 + lcol];
 }
 
+// ---- row factors from the producer's slice statistics, inside the consumer (F5GemmArgs::fold_stats, round 6).  Requested with the other
+// fold operands BEFORE the prologue's operand loads (fold_stats_request_*), merged right behind the wait for the first K tile
+// (fold_stats_finish_*: ~100 VALU instructions while the second K tile is in flight); only FoldPre::rr stays live through the K loop.
+// Transposed tiles (lane = token): the two lane halves hold the same 32 tokens -- half 0 takes slices 0-7, half 1 slices 8-15, two
+// v_permlane32_swap exchanges complete the row.  Straight V tiles (lane = row): 16 slices per lane and row.  Sums are taken as
+// (slices 0-7 in order) + (slices 8-15 in order) everywhere, f5_fold_rows_kernel<16> included: one bit pattern per row whoever computes it.
+// NT = 8 * (rows per lane of a transposed tile) = 16 * (rows per lane of a straight V tile): 16 for 64 x 64 wave tiles, 32 for 128 x 64
+template <int NT>
+struct FoldStatsPre {
+    f5_f32x2 t[NT];           // transposed tiles: [mb * 8 + i] = slice (8 half + i) of row block mb; straight tiles: [r * 16 + k]
+    float sh[NT / 8];
+};
+template <int NT>
+__device__ __forceinline__ void fold_stats_clear(FoldStatsPre<NT>& q) {       // every field defined on every path (see fold_prefetch_pin)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) q.t[i] = f5_f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < NT / 8; ++i) q.sh[i] = 0.0f;
+}
+template <int NT>
+__device__ __forceinline__ void fold_stats_pin(FoldStatsPre<NT>& q) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) asm volatile("" : "+v"(q.t[i]));
+#pragma unroll
+    for (int i = 0; i < NT / 8; ++i) asm volatile("" : "+v"(q.sh[i]));
+}
+__device__ __forceinline__ f5_f32x2 fold_row_factor(float m2_lo, float m2_hi, float mean, float eps) {
+    const float rstd = rsqrtf((m2_lo + m2_hi) * (1.0f / 1024.0f) + eps);
+    return f5_f32x2{rstd, rstd * mean};
+}
+template <int MBW>
+__device__ __forceinline__ void fold_stats_request_tr(const F5GemmArgs& p, FoldStatsPre<8 * MBW>& q, FoldPre& f, int row0, int col0, int lane) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) {
+        int grow = row0 + mb * 32 + (lane & 31);
+        if (grow > p.M - 1) grow = p.M - 1;
+        const f5_f32x2* sp = reinterpret_cast<const f5_f32x2*>(p.fold_stats) + (size_t)(half * 8) * p.fold_stats_ld + grow;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q.t[mb * 8 + i] = sp[(size_t)i * p.fold_stats_ld];
+        q.sh[mb] = p.fold_shift != nullptr ? p.fold_shift[grow] : 0.0f;
+    }
+    f.c[0] = p.fold_c1[col0 + lane];
+    f.c[1] = p.fold_c2[col0 + lane];
+}
+template <int MBW>
+__device__ __forceinline__ void fold_stats_finish_tr(const F5GemmArgs& p, const FoldStatsPre<8 * MBW>& q, FoldPre& f, int row0, int lane, bool write_mean) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) {
+        float s = q.t[mb * 8][0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += q.t[mb * 8 + i][0];
+        const float so = f5_xor32(s, (unsigned)lane);
+        const float mean = ((half ? so : s) + (half ? s : so)) * (1.0f / 1024.0f);
+        float m2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float dm = q.t[mb * 8 + i][0] * (1.0f / 64.0f) - mean;
+            m2 += q.t[mb * 8 + i][1] + 64.0f * dm * dm;
+        }
+        const float mo = f5_xor32(m2, (unsigned)lane);
+        f.rr[mb] = fold_row_factor(half ? mo : m2, half ? m2 : mo, mean, p.fold_eps);
+        const int grow = row0 + mb * 32 + (lane & 31);
+        if (write_mean && half == 0 && grow < p.M) p.fold_mean_out[grow] = q.sh[mb] + mean;
+    }
+}
+template <int MBW>
+__device__ __forceinline__ void fold_stats_request_v(const F5GemmArgs& p, FoldStatsPre<8 * MBW>& q, FoldPre& f, int row0, int col0, int lane) {
+    constexpr int NR = (32 * MBW + 63) / 64;
+    static_assert(NR * 16 <= 8 * MBW, "one row per 64 rows of the wave tile");
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        int grow = row0 + i * 64 + lane;
+        if (grow > p.M - 1) grow = p.M - 1;
+        const f5_f32x2* sp = reinterpret_cast<const f5_f32x2*>(p.fold_stats) + grow;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) q.t[i * 16 + k] = sp[(size_t)k * p.fold_stats_ld];
+    }
+    const int lcol = lane & 31;
+    f.c[0] = p.fold_c1[col0 + lcol];
+    f.c[1] = p.fold_c1[col0 + 32 + lcol];
+    f.c[2] = p.fold_c2[col0 + lcol];
+    f.c[3] = p.fold_c2[col0 + 32 + lcol];
+}
+template <int MBW>
+__device__ __forceinline__ void fold_stats_finish_v(const F5GemmArgs& p, const FoldStatsPre<8 * MBW>& q, FoldPre& f) {
+    constexpr int NR = (32 * MBW + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        float s_lo = q.t[i * 16][0], s_hi = q.t[i * 16 + 8][0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            s_lo += q.t[i * 16 + k][0];
+            s_hi += q.t[i * 16 + 8 + k][0];
+        }
+        const float mean = (s_lo + s_hi) * (1.0f / 1024.0f);
+        float m_lo = 0.0f, m_hi = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d0 = q.t[i * 16 + k][0] * (1.0f / 64.0f) - mean, d1 = q.t[i * 16 + 8 + k][0] * (1.0f / 64.0f) - mean;
+            m_lo += q.t[i * 16 + k][1] + 64.0f * d0 * d0;
+            m_hi += q.t[i * 16 + 8 + k][1] + 64.0f * d1 * d1;
+        }
+        f.rr[i] = fold_row_factor(m_lo, m_hi, mean, p.fold_eps);
+    }
+}
+
 // ---- LDS-staged epilogues (used by the 256x256 and the 128x256 kernels).  A wave owns a (32*MBW) x (32*NBW) tile
 // and a private LDS region; the MFMA C layout (lane = column, registers = rows) is turned into 16-byte global accesses
 // in full row segments.  bf16 row-major outputs (FF1 / q / k / plain bf16): 32-row passes, [32][W+8] hi (+ lo).
@@ -684,9 +792,42 @@ __device__ __forceinline__ void staged_epilogue_tr_rope(const F5GemmArgs& p, f32
 
 // x += gate * ((acc + bias) * keep)  (dit.py:319,323): fp32 tile staged [32 rows][W+4] so that the read-modify-write of
 // the residual stream uses 16-byte accesses; the residual values are loaded before the LDS round trip.
-template <int MBW, int NBW>
+// PRE (single-round launches, MBW = 1): the rows of x, the keep bytes and the row shifts were requested BEFORE the K loop
+// (resid_staged_preload): in a one-round launch the epilogue's load round trip is on the critical chain (gemm.hip ResidPre)
+template <int NBW>
+struct ResidStagedPre {
+    f32x4 xr[32 / (64 / (32 * NBW / 4))];
+    uint32_t kraw[32 / (64 / (32 * NBW / 4))];
+    float xsh[32 / (64 / (32 * NBW / 4))];
+    float bcol[NBW];          // bias of the lane's columns (accumulator layout)
+    f32x4 g4, sc4;            // gate and 1 + scale of the lane's 16-byte chunk (row-segment layout)
+};
+template <int NBW>
+__device__ __forceinline__ void resid_staged_preload(const F5GemmArgs& p, ResidStagedPre<NBW>& q, int row0, int colbase, int lane) {
+    constexpr int CPR = 32 * NBW / 4, RPI = 64 / CPR, NI = 32 / RPI;
+    const int chunk = lane % CPR;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int grow = row0 + i * RPI + lane / CPR;
+        const bool ok = grow < p.M;
+        q.xr[i] = ok ? *reinterpret_cast<const f32x4*>(p.out_f32 + (size_t)grow * p.ldo + colbase + chunk * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        q.kraw[i] = (ok && p.rowkeep != nullptr) ? (uint32_t)p.rowkeep[grow] : 1u;
+        q.xsh[i] = (ok && p.x16_out != nullptr && p.x16_shift != nullptr) ? p.x16_shift[grow] : 0.0f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) q.bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + (lane & 31)] : 0.0f;
+    q.g4 = *reinterpret_cast<const f32x4*>(p.gate + colbase + chunk * 4);
+    q.sc4 = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    if (p.x16_out != nullptr) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.x16_scale + colbase + chunk * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q.sc4[e] += t[e];
+    }
+}
+template <int MBW, int NBW, bool PRE = false>
 __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x16 (&acc)[MBW][NBW], float* reg, int row0,
-                                                      int colbase, int lane) {
+                                                      int colbase, int lane, const ResidStagedPre<NBW>* pre = nullptr) {
+    static_assert(!PRE || MBW == 1, "the preloaded form covers one 32-row block");
     constexpr int W = 32 * NBW;
     constexpr int LD = W + 4;
     constexpr int CPR = W / 4;             // 16-byte chunks per row
@@ -695,12 +836,14 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
     const int hi = lane >> 5, lcol = lane & 31;
     float bcol[NBW];
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) bcol[nb] = p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f;
+    for (int nb = 0; nb < NBW; ++nb) bcol[nb] = PRE ? pre->bcol[nb] : (p.bias ? p.bias[colbase + nb * 32 + lcol] : 0.0f);
     const int chunk = lane % CPR;
-    f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gate + colbase + chunk * 4);
+    f32x4 g4 = PRE ? pre->g4 : *reinterpret_cast<const f32x4*>(p.gate + colbase + chunk * 4);
     asm volatile("" : "+v"(g4));
     f32x4 sc4 = {1.0f, 1.0f, 1.0f, 1.0f};               // LN fold: 1 + the scale of the LN that follows (F5GemmArgs::x16_scale)
-    if (p.x16_out != nullptr) {
+    if (PRE) {
+        sc4 = pre->sc4;
+    } else if (p.x16_out != nullptr) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(p.x16_scale + colbase + chunk * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sc4[e] += t[e];
@@ -715,6 +858,12 @@ __device__ __forceinline__ void staged_epilogue_resid(const F5GemmArgs& p, f32x1
                                            // memory round trip after the other
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
+            if (PRE) {
+                xr[i] = pre->xr[i];
+                kraw[i] = pre->kraw[i];
+                xsh[i] = pre->xsh[i];
+                continue;
+            }
             const int grow = rowblk + i * RPI + lane / CPR;
             const bool ok = grow < p.M;
             if (F5_PROBE_NT(p))

@@ -37,7 +37,8 @@ namespace F5_NS {
 // FOLD: the LN-fold consumer (F5GemmArgs::fold_*) as its own instantiation -- its requests are issued and pinned on EVERY path of the
 // kernel (a request under a run-time condition leaves the compiler's wait bookkeeping "pending" on the other path, and it then guards the
 // registers inside the K loop: gemm_dev.hpp fold_prefetch_pin), and the plain kernels carry none of it
-template <int EPI, bool QT, bool FOLD>
+// FOLD: 0 = plain, 1 = row factors from memory (fold_rowf), 2 = merged here from the producer's slice statistics (fold_stats)
+template <int EPI, bool QT, int FOLD>
 __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int tiles_n, int ntiles, int tiles_m) {
     constexpr int AH = 64 * BK;                 // elements of an A half (64 rows)
     constexpr int BH = 128 * BK;                // elements of a B half (128 rows)
@@ -168,31 +169,45 @@ __global__ __launch_bounds__(512) void f5_gemm_rs128_kernel(F5GemmArgs p, int ti
 
     // LN fold: what the epilogue needs from memory is requested here, ahead of the operand loads (gemm_dev.hpp fold_prefetch_pin)
     static_assert(!FOLD || EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH, "fold consumers");
-    constexpr bool fold = FOLD;
+    constexpr bool fold = FOLD != 0;
     const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
     constexpr bool TR_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF_BF16);
     const bool tr_path = (TR_EPI && (p.debug_flags & 16384) == 0) || (QT && n0 < 2 * p.dmodel);       // workgroup-uniform
     FoldPre fpre;
     fold_prefetch_clear(fpre);
-    if (fold) {                                         // (waves past the last row read clamped rows and never use them)
+    FoldStatsPre<FOLD == 2 ? 16 : 8> spre;
+    fold_stats_clear(spre);
+    if (FOLD == 1) {                                    // (waves past the last row read clamped rows and never use them)
         if (tr_path) fold_prefetch_tr<2>(p, fpre, row0, col0, lane);
         else fold_prefetch_v<2>(p, fpre, row0, col0, lane);
+    }
+    if constexpr (FOLD == 2) {
+        if (tr_path) fold_stats_request_tr<2>(p, spre, fpre, row0, col0, lane);
+        else fold_stats_request_v<2>(p, spre, fpre, row0, col0, lane);
     }
 
     // ---- prologue: steps 0 and 1 (slots 0, 1); step 0 must have landed.  With the fold, step 0 (and the requests above, which are
     // older) is waited for in full and pinned before step 1 is issued: step 1 has a whole K step to land either way
     RS_ISSUE_A(0);
     RS_ISSUE_B(0);
-    if (fold) {
+    if (FOLD == 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         fold_prefetch_pin(fpre);
     }
     if (1 < T) {
         RS_ISSUE_A(SLOT);
         RS_ISSUE_B(SLOT);
-        if (!fold) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (FOLD != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if constexpr (FOLD == 2) {
+        // the statistics form serves single-round launches, where the time of the kernel is one workgroup's chain: step 1 is already in
+        // flight (the wait above left its 6 loads pending; the statistics and step 0 are older and have landed), the merge below runs under it
+        fold_stats_pin(spre);
+        if (tr_path) fold_stats_finish_tr<2>(p, spre, fpre, row0, lane, p.fold_mean_out != nullptr && n0 == 0 && wn == 0);
+        else fold_stats_finish_v<2>(p, spre, fpre);
+        fold_prefetch_pin(fpre);
     }
     RS_BARRIER();
     if (wm == 1) RS_BARRIER();          // group 1 starts one interval late
@@ -293,13 +308,17 @@ static int launch_rs128(const F5GemmArgs& a, hipStream_t stream) {
     F5GemmArgs ab = a;
     if (a.bias != nullptr && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) ab.debug_flags |= 16384;
     constexpr bool CAN_FOLD = EPI == EPI_QKV_ROPE || EPI == EPI_GELU_TANH;
-    const bool fold = CAN_FOLD && ab.fold_rowf != nullptr;     // (f5_launch_gemm has checked the fold's preconditions: transposed q / k tiles)
+    // (f5_launch_gemm has checked the fold's preconditions: transposed q / k tiles, K = 1024 for the statistics form)
+    const int fold = !CAN_FOLD ? 0 : (ab.fold_stats != nullptr ? 2 : (ab.fold_rowf != nullptr ? 1 : 0));
+    constexpr bool QT = EPI == EPI_QKV_ROPE;
     if (EPI == EPI_QKV_ROPE && ab.rope_g4k != nullptr) {
-        if (fold) hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, EPI == EPI_QKV_ROPE, CAN_FOLD>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
-        else hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, EPI == EPI_QKV_ROPE, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        if (fold == 2) hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, QT, CAN_FOLD ? 2 : 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        else if (fold == 1) hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, QT, CAN_FOLD ? 1 : 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        else hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, QT, 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
     } else {
-        if (fold) hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, false, CAN_FOLD>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
-        else hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, false, false>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        if (fold == 2) hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, false, CAN_FOLD ? 2 : 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        else if (fold == 1) hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, false, CAN_FOLD ? 1 : 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
+        else hipLaunchKernelGGL((f5_gemm_rs128_kernel<EPI, false, 0>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles, tiles_m);
     }
     F5_LAUNCH_CHECK();
     return 0;

@@ -57,6 +57,9 @@ struct Ops {
     bool gemm_runs_staged(const F5GemmArgs& a, int epi) const {
         return h ? f5hf::f5_gemm_runs_staged(reinterpret_cast<const f5hf::F5GemmArgs&>(a), epi) : f5bf::f5_gemm_runs_staged(a, epi);
     }
+    bool gemm_fold_small(const F5GemmArgs& a, int epi, bool qkv_tr) const {
+        return h ? f5hf::f5_gemm_fold_small(reinterpret_cast<const f5hf::F5GemmArgs&>(a), epi, qkv_tr) : f5bf::f5_gemm_fold_small(a, epi, qkv_tr);
+    }
     int fold_rows(const float* stats, int ld, int nslice, int M, float eps, float* rowf, float* row_shift, hipStream_t s) const {
         return h ? f5hf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, row_shift, s)
                  : f5bf::f5_launch_fold_rows(stats, ld, nslice, M, eps, rowf, row_shift, s);

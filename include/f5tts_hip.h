@@ -306,6 +306,11 @@ int f5_debug_set_op_fold_producer(const float* next_scale, void* x16_out, float*
 int f5_op_fold_rows(const float* stats, int nslice, int M, float* rowf, float* row_shift, void* stream);
 int f5_debug_set_op_ln_mean_out(float* mean_out);
 int f5_debug_set_op_fold_consumer(const float* rowf, const float* c1, const float* c2);
+/* the statistics form of the consumer (round 6): with rowf = NULL above, f5_op_gemm (epi 2) / f5_op_qkv_rope merge the producer's slice
+ * statistics (its stats_out, [16][ld][2]; K = 1024) into their rows' factors themselves -- no f5_op_fold_rows launch in between; shift = the
+ * producer's row_shift on ENTRY (or NULL = 0); mean_out (or NULL) receives the rows' means from the workgroups of column tile 0 and must
+ * not alias shift.  NULL stats = off. */
+int f5_debug_set_op_fold_stats(const float* stats, int ld, const float* shift, float* mean_out);
 int f5_debug_set_op_sat_flag(int* flag);   /* device word the 16-bit packers of the f5_op_* launches that follow OR F5_STATUS_SATURATED into (fp16 operand type); NULL = off */
 int f5_debug_set_op_fold_overflow_flag(int* flag);   /* device word the producer ORs bit 0 into when (x - m)(1 + s) leaves the fp16 range; NULL = off */
 /* c1[v][n] = sum_k W[n][k] (1 + scale_v[k]), c2[v][n] = sum_k W[n][k] shift_v[k] + bias[n] for nvec modulation vectors (vec_stride

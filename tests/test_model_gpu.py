@@ -868,6 +868,41 @@ def test_fullsize_ln_fold_every_utterance_vs_oracle(full_f16, B):
     assert not torch.equal(out, base)
 
 
+def test_ln_fold_batch1_route_vs_oracle_golden(full_f16):
+    """Round 6 (VERDICT r5 "next" #6): the LN fold at BATCH 1 -- every block GEMM is one round of workgroups; the residual GEMMs (64 x 128
+    split-K ring kernel) write the folded operand + slice statistics, FF1 (8-wave ring kernel) and QKV (one round of role-split tiles)
+    merge the statistics themselves, no row-factor launch: 44 of the 46 LN-modulate launches of a forward disappear.  Opt-in (ln_fold = 1;
+    measured -0.5 ... -1.5 %, below the bar for a default).  The benchmark call itself: 335M, N = 937, 32-point Euler, against the fp32
+    oracle's golden like the unfolded path (gate 1e-3, trajectory points too), graph == eager bitwise, and the default (-1) still unfolded."""
+    import os
+    from f5test import ROOT
+    import bench
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_b1_euler32.npz"))
+    eng = full_f16.engine
+    f5 = F5TTS(transformer=full_f16)
+    cond, text, y0, _ = bench.synth_batch(1, 0, DEV)
+    kw = dict(duration=937, steps=32, method="euler", cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0)
+    base, _ = f5.sample(cond, text, use_graph=False, **kw)
+    try:
+        eng.set_option("ln_fold", 1)
+        out, traj = f5.sample(cond, text, use_graph=False, **kw)
+        out2, _ = f5.sample(cond, text, use_graph=True, **kw)
+        torch.cuda.synchronize()
+        # no-CFG call: one branch = 937 rows, the single-round kernels do not apply -> ln_fold = 1 must fail loudly, not fall back silently
+        with pytest.raises(RuntimeError, match="ln_fold = 1"):
+            f5.sample(cond, text, use_graph=False, **dict(kw, cfg_strength=0.0))
+    finally:
+        eng.set_option("ln_fold", -1)
+    auto, _ = f5.sample(cond, text, use_graph=False, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(auto, base), "the automatic mode must not pick the batch-1 route"
+    assert torch.equal(out2, out) and not torch.equal(out, base)
+    l1 = float((out.cpu()[0].double() - torch.from_numpy(g["out"]).double()).abs().mean())
+    l1b = float((base.cpu()[0].double() - torch.from_numpy(g["out"]).double()).abs().mean())
+    print(f"[ln_fold batch 1] f16 vs fp32 oracle over 62 forwards: folded {l1:.3e}, unfolded {l1b:.3e}; folded vs unfolded {float((out - base).abs().mean()):.3e}")
+    assert l1 <= MEL_L1_TOL and eng.range_events == 0 and eng.saturation_events == 0
+
+
 def test_ln_fold_single_forward_and_single_branch(full_f16):
     """ln_fold through the other two entry shapes: f5_dit_forward (one evaluation, its constants computed for nfe = 1) at batch 12, where
     the default (-1) folds, and sample() WITHOUT classifier-free guidance (one branch: 24 x 937 = 22 488 rows) -- each against the same
@@ -909,7 +944,8 @@ def test_ln_fold_single_forward_and_single_branch(full_f16):
 
 def test_ln_fold_ragged_batch_and_where_it_cannot_run(full_f16):
     """ln_fold on the RAGGED full-size batch (masked residual rows keep x: their x16 / row sums must still be written), and the option's
-    three values: 1 fails loudly at batch 1 (small-tile GEMMs), -1 (the default) keeps the LN kernels there, 0 = never."""
+    three values: 1 fails loudly where no fold-capable kernels run (batch 2 of 937 frames: neither the staged kernels nor the single-round
+    route of batch 1), -1 (the default) keeps the LN kernels there and at batch 1, 0 = never."""
     import os
     from f5test import ROOT
     import bench
@@ -929,9 +965,10 @@ def test_ln_fold_ragged_batch_and_where_it_cannot_run(full_f16):
         l1v = [float((out[i, :d] - ref[i, :d]).abs().mean()) for i, d in enumerate(dur.tolist())]
         print(f"[ln_fold ragged] mel L1 on the valid frames: worst {max(l1v):.3e}")
         assert torch.isfinite(out).all() and max(l1v) <= MEL_L1_TOL, l1v
-        c1, t1, y1, _ = bench.synth_batch(1, 0, DEV)
+        c2, t2, y2, _ = bench.synth_batch(2, 0, DEV)
         with pytest.raises(RuntimeError, match="ln_fold"):
-            f5.sample(c1, t1, duration=mg.N_FRAMES, y0=y1, use_graph=False, **mg.KW)
+            f5.sample(c2, t2, duration=mg.N_FRAMES, y0=y2, use_graph=False, **mg.KW)
+        c1, t1, y1, _ = bench.synth_batch(1, 0, DEV)
         eng.set_option("ln_fold", -1)
         assert eng.get_option("ln_fold") == -1
         a, _ = f5.sample(c1, t1, duration=mg.N_FRAMES, y0=y1, use_graph=False, **mg.KW)

@@ -140,7 +140,7 @@ def test_gemm_rs128_several_rounds_all_epilogues_f16(lib, tile):
     T.test_gemm_rs128_several_rounds_all_epilogues(lib, tile)
 
 
-@pytest.mark.parametrize("tile", [4, 14])
+@pytest.mark.parametrize("tile", [4, 14, "small"])
 @pytest.mark.parametrize("stress", range(len(T.FOLD_STRESS)))
 def test_ln_modulate_folded_into_the_gemms_around_it_f16(lib, tile, stress):
     T.test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress)

@@ -873,7 +873,7 @@ def test_gemm_rs128_several_rounds_all_epilogues(lib, tile):
 FOLD_STRESS = [(0.5, False, 0.2), (10.0, False, 0.3), (100.0, True, 1.0), (1.0, True, 0.0)]
 
 
-@pytest.mark.parametrize("tile", [4, 14])
+@pytest.mark.parametrize("tile", [4, 14, "small"])
 @pytest.mark.parametrize("stress", range(len(FOLD_STRESS)))
 def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
     """LN fold (csrc/gemm.hpp fold_*; dit.py:319-321 and :323 -> :270 -> :136): the residual GEMM leaves (x - m)(1 + s) as 16-bit operands
@@ -886,9 +886,15 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
     16-bit rounding) as well as against the exact LN-modulate + GEMM NEXT TO the unfolded path (ln_modulate kernel + plain GEMM) on the
     same inputs: row means of 0.5 / 10 / 100 sigma, four channels at 1e3 sigma -- the folded error must stay within 2x the unfolded one
     whatever the mean is (the round-4 formulation, m = 0, is 10x / 100x worse at 10 / 100 sigma: profiles/r05/ln_fold_numerics_study.jsonl)."""
+    # tile "small" (round 6): the batch-1-sized route -- automatic dispatch at M = 2 x 937 rows: the producer is the 64 x 128 split-K ring
+    # kernel, the consumers the 8-wave 128 x 128 ring kernel (FF1) and one round of role-split 128 x 256 tiles (QKV), both in the
+    # STATISTICS form (they merge the slice statistics themselves; there is no row-factor form on that route)
+    small = tile == "small"
     mu_sig, outliers, drift = FOLD_STRESS[stress]
-    r = rng(4100 + tile + 17 * stress)
-    Bq, Nq, H, D, FF = 8, 937, 16, 1024, 2048
+    r = rng(4100 + (1 if small else tile) + 17 * stress)
+    Bq, Nq, H, D, FF = (2 if small else 8), 937, 16, 1024, 2048
+    if small:
+        tile = 0
     M = Bq * Nq
     eps_op = 2.0 ** -8 if op_dtype() == torch.bfloat16 else 2.0 ** -11
     a = randn(r, M, D)
@@ -917,6 +923,7 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
         xnew = x_plain.cpu()
         m_prev = (xnew.double().mean(-1) - drift * xnew.double().std(-1, unbiased=False) * torch.where(randn(r, M) < 0, -1.0, 1.0).double()).float()
         shift_d = m_prev.to(DEV).clone()
+        shift0_d = shift_d.clone()                                            # (f5_op_fold_rows below replaces shift_d by the rows' means)
         E.check(lib.f5_debug_set_op_fold_producer(P(sv_d[1]), P(x16), P(stats), P(shift_d)))
         try:
             E.check(lib.f5_op_gemm_resid_gate(P(a_hi), P(None), P(wo_hi), P(None), P(bo_d), P(gate_d), P(keep_d), P(x), M, D, D, D, D, D, 1,
@@ -1016,11 +1023,16 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
         c1, c2, w64 = consts["ff1"]
         E.check(lib.f5_op_gemm(P(h16), P(None), P(w1_hi), P(None), P(bias1_d), P(None), P(out16_unf), P(None), M, FF, D, D, D, FF, 1, 2, stream()),
                 "gemm gelu unfolded")
-        E.check(lib.f5_debug_set_op_fold_consumer(P(rowf), P(c1[1]), P(c2[1])))
+        mean_small = torch.full((M,), float("nan"), device=DEV)
+        E.check(lib.f5_debug_set_op_fold_consumer(P(None) if small else P(rowf), P(c1[1]), P(c2[1])))
+        if small:
+            E.check(lib.f5_debug_set_op_fold_stats(P(stats), M, P(shift0_d), P(mean_small)))
         try:
             E.check(lib.f5_op_gemm(P(x16), P(None), P(w1_hi), P(None), P(None), P(None), P(out16), P(None), M, FF, D, D, D, FF, 1, 2, stream()),
                     "gemm gelu folded")
             sync()
+            if small:
+                assert torch.equal(mean_small, shift_d), "the rows' means left behind by the small FF1 consumer differ from fold_rows'"
             sharp = F.gelu(folded("ff1", bias1), approximate="tanh")
             exact = F.gelu(h_exact @ w64.T + bias1.double(), approximate="tanh")
             mx, _, _ = report(f"LN fold FF1 tile={tile} stress={FOLD_STRESS[stress]}: vs the folded formula in fp64", out16.float().cpu(), sharp)
@@ -1034,6 +1046,22 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
             m_fold, m_unf = max_err(out16.float().cpu(), exact), max_err(out16_unf.float().cpu(), exact)
             print(f"[ln_fold stress] tile={tile} FF1 max|err| folded {m_fold:.3e} unfolded {m_unf:.3e} ratio {m_fold / m_unf:.2f}")
             assert m_fold <= 4.0 * m_unf + 1e-6, (m_fold, m_unf)
+            # --- the STATISTICS form of the consumer (round 6): no f5_op_fold_rows in between -- the kernel merges the producer's slice
+            # statistics into its rows' factors before its K loop, in the arithmetic order of f5_fold_rows_kernel: the SAME bits, and the
+            # workgroups of column tile 0 leave the rows' means behind (what fold_rows wrote into shift_d)
+            out16_s = torch.zeros((M, FF), dtype=op_dtype(), device=DEV)
+            mean_s = torch.full((M + 8,), float("nan"), device=DEV)
+            E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(c1[1]), P(c2[1])))
+            E.check(lib.f5_debug_set_op_fold_stats(P(stats), M, P(shift0_d), P(mean_s)))
+            try:
+                E.check(lib.f5_op_gemm(P(x16), P(None), P(w1_hi), P(None), P(None), P(None), P(out16_s), P(None), M, FF, D, D, D, FF, 1, 2, stream()),
+                        "gemm gelu folded, statistics form")
+                sync()
+            finally:
+                E.check(lib.f5_debug_set_op_fold_stats(P(None), 0, P(None), P(None)))
+            assert torch.equal(out16_s, out16), "FF1: the statistics form differs from fold_rows + row factors"
+            assert torch.equal(mean_s[:M], shift_d) and bool(torch.isnan(mean_s[M:]).all()), "the rows' means left behind differ from fold_rows'"
+            E.check(lib.f5_debug_set_op_fold_consumer(P(None) if small else P(rowf), P(c1[1]), P(c2[1])))
             # --- QKV + RoPE + V^T, transposed q / k tiles, q pre-multiplied (as sample() runs it)
             npad = (Nq + 63) // 64 * 64
             cos_t, sin_t = torch.empty((Nq, 32), device=DEV), torch.empty((Nq, 32), device=DEV)
@@ -1050,10 +1078,24 @@ def test_ln_modulate_folded_into_the_gemms_around_it(lib, tile, stress):
                 E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(None), P(None)))
                 E.check(lib.f5_op_qkv_rope(P(h16), P(None), P(wq_hi), P(None), P(biasq_d), P(cos_t), P(sin_t), P(qk_unf), P(None), P(vt_unf), P(None),
                                            Bq, Nq, npad, H, D, 1, stream()), "qkv_rope unfolded")
-                E.check(lib.f5_debug_set_op_fold_consumer(P(rowf), P(c1[1]), P(c2[1])))
+                E.check(lib.f5_debug_set_op_fold_consumer(P(None) if small else P(rowf), P(c1[1]), P(c2[1])))
+                if small:
+                    E.check(lib.f5_debug_set_op_fold_stats(P(stats), M, P(shift0_d), P(mean_small)))
                 E.check(lib.f5_op_qkv_rope(P(x16), P(None), P(wq_hi), P(None), P(None), P(cos_t), P(sin_t), P(qk), P(None), P(vt), P(None),
                                            Bq, Nq, npad, H, D, 1, stream()), "qkv_rope folded")
                 sync()
+                qk_s, vt_s = torch.zeros_like(qk), torch.zeros_like(vt)            # the statistics form: q / k (transposed tiles) and V (straight)
+                mean_q = torch.full((M,), float("nan"), device=DEV)
+                E.check(lib.f5_debug_set_op_fold_consumer(P(None), P(c1[1]), P(c2[1])))
+                E.check(lib.f5_debug_set_op_fold_stats(P(stats), M, P(shift0_d), P(mean_q)))
+                try:
+                    E.check(lib.f5_op_qkv_rope(P(x16), P(None), P(wq_hi), P(None), P(None), P(cos_t), P(sin_t), P(qk_s), P(None), P(vt_s), P(None),
+                                               Bq, Nq, npad, H, D, 1, stream()), "qkv_rope folded, statistics form")
+                    sync()
+                finally:
+                    E.check(lib.f5_debug_set_op_fold_stats(P(None), 0, P(None), P(None)))
+                assert torch.equal(qk_s, qk) and torch.equal(vt_s, vt), "QKV: the statistics form differs from fold_rows + row factors"
+                assert torch.equal(mean_q, shift_d)
             finally:
                 E.check(lib.f5_debug_set_op_rope_tables_g4(P(None), P(None)))
                 E.check(lib.f5_debug_set_op_q_premul(C.c_float(0.0)))
