@@ -38,6 +38,65 @@ struct ResidPre {
     float bias[NB], gate[NB];
     uint32_t keep[MB][4];       // keep bytes of rows (rg*8 + hi*4 + 0..3) of row block mb
 };
+template <int MB, int NB>
+__device__ __forceinline__ void resid_preload(const F5GemmArgs& p, ResidPre<MB, NB>& q, int row0, int colbase, int lane) {
+    const int hi = lane >> 5, lcol = lane & 31;
+    const bool keep_words = p.rowkeep != nullptr && (reinterpret_cast<uintptr_t>(p.rowkeep) & 3) == 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int c = colbase + nb * 32 + lcol;
+        const bool ok = c < p.N;
+        q.bias[nb] = (p.bias != nullptr && ok) ? p.bias[c] : 0.0f;
+        q.gate[nb] = ok ? p.gate[c] : 0.0f;
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int rowb = row0 + mb * 32 + rg * 8 + hi * 4;
+            uint32_t kw = 0x01010101u;
+            if (p.rowkeep != nullptr) {
+                if (keep_words && rowb + 3 < p.M) {
+                    kw = *reinterpret_cast<const uint32_t*>(p.rowkeep + rowb);
+                } else {
+                    kw = 0;
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri)
+                        if (rowb + ri < p.M) kw |= (uint32_t)p.rowkeep[rowb + ri] << (8 * ri);
+                }
+            }
+            q.keep[mb][rg] = kw;
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int row = rowb + ri, c = colbase + nb * 32 + lcol;
+                    q.x[mb][rg * 4 + ri][nb] = (row < p.M && c < p.N) ? p.out_f32[(size_t)row * p.ldo + c] : 0.0f;
+                }
+        }
+}
+template <int MB, int NB>
+__device__ __forceinline__ void resid_epilogue_preloaded(const F5GemmArgs& p, f32x16 (&acc)[MB][NB], const ResidPre<MB, NB>& q, int row0,
+                                                         int colbase, int lane) {
+    const int hi = lane >> 5, lcol = lane & 31;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const int row = row0 + mb * 32 + rg * 8 + hi * 4 + ri;
+                const bool kp = ((q.keep[mb][rg] >> (8 * ri)) & 0xffu) != 0;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int c = colbase + nb * 32 + lcol;
+                    float v = acc[mb][nb][rg * 4 + ri] + q.bias[nb];
+                    if (!kp) v = 0.0f;
+                    if (row < p.M && c < p.N) p.out_f32[(size_t)row * p.ldo + c] = q.x[mb][rg * 4 + ri][nb] + q.gate[nb] * v;
+                }
+            }
+}
+
 // ---- LN-modulate fused behind the residual update (EPI_RESID_GATE of the small-tile kernels, batch-1-sized problems) ------
 // At M = 2*937 every launch is one round of workgroups and costs ~2 us of launch / drain on top of its work, and the
 // stand-alone LN-modulate kernels are 2 of the 7 launches of a DiT block (5.2 us each).  Instead, every workgroup of the
