@@ -27,8 +27,11 @@ import socket
 import sys
 import time
 
-import numpy as np
-import torch
+# hipGraph replay: no per-node packet capture (f5_tts_mlx_amd/__init__.py explains; set here too, ahead of torch's first HIP call)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
