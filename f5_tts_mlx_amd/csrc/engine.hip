@@ -415,6 +415,23 @@ extern "C" int f5_mark_weights_loaded(f5_engine* e) {
     return 0;
 }
 
+// A second handle on the arena of `owner` (same configuration and precision, weights finalised): nothing is written, the caller keeps the
+// arena alive for both.  What it is for: two handles driven by two host threads on two streams (two half batches of one sample() call fill
+// the partly empty last rounds of each other's launches: engine.py Engine._sample_split); every handle has its own
+// workspace, hipGraphs and status word, the weights are read-only on the hot path.
+extern "C" int f5_share_weights(f5_engine* e, const f5_engine* owner) {
+    F5_REQUIRE(e && owner && e != owner, "f5_share_weights: null argument / the same handle twice");
+    F5_REQUIRE(owner->arena && owner->finalized, "f5_share_weights: the owner's weights are not finalised");
+    F5_REQUIRE(e->prec == owner->prec && e->arena_need == owner->arena_need && memcmp(&e->cfg, &owner->cfg, sizeof(f5_config)) == 0,
+               "f5_share_weights: the two handles differ in configuration or precision");
+    e->arena = owner->arena;
+    e->arena_bytes = owner->arena_bytes;
+    for (auto& kv : e->tmap)
+        for (auto& d : kv.second) d.loaded = true;
+    e->finalized = true;
+    return 0;
+}
+
 // One collective replicates the model: the arena is contiguous, so a host that owns an RCCL communicator (one process per GPU,
 // xGMI) broadcasts it from `root` with a single ncclBroadcast.  RCCL is resolved at run time (dlopen) so that the library has
 // no link-time dependency on it; the torch.distributed path of the Python wrapper (dist.py) does the same with dist.broadcast.

@@ -9,8 +9,9 @@ namespace F5_NS {
 // The status word the 16-bit packers of the NEXT launches report saturation to (op16.hpp f5_sat_commit), or null.  Host-side, set by
 // the engine around a call (engine.hip SatScope) and by f5_debug_set_op_sat_flag for the op-level tests; the launchers of this file,
 // of convpos.hip and f5_launch_gemm pass it to their kernels by value (a captured graph keeps the pointer it was captured with: the
-// status word of its workspace).
-int* f5_sat_flag_host = nullptr;
+// status word of its workspace).  Per host THREAD: two engine handles may be driven from two threads at once (two half batches on two
+// streams, engine.py Engine._sample_split), each call with its own status word.
+thread_local int* f5_sat_flag_host = nullptr;
 
 
 // =================================================================================================

@@ -17,7 +17,7 @@
 #undef F5_ROWOPS_HPP_BODY
 namespace F5_NS {
 
-extern int* f5_sat_flag_host;   // rowops.hip: where the 16-bit packers of the next launches report saturation (fp16 build), or null
+extern thread_local int* f5_sat_flag_host;   // rowops.hip (per host thread): where the 16-bit packers of the next launches report saturation (fp16 build), or null
 
 // y = LN(x) * (1 + scale) + shift, LN without affine, eps (dit.py:270,289,321). One wave per row.
 // mean_out (optional, [rows]): the row means -- the shift of the first folded operand that follows (gemm.hpp x16_shift)

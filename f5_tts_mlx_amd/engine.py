@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import warnings
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Dict, Optional, Sequence
 
@@ -157,6 +158,16 @@ class OperandRangeWarning(RuntimeWarning):
 
 
 RANGE_CHECKS = ("sync", "auto", "async", "off")
+OPTION_NAMES = ("q_premul", "qkv_transposed", "ln_fusion", "gemm_flags", "attn_pipe", "null_keeps_cond", "ln_fold", "sat_check",
+                "graph_split", "fold_stats")
+# Engine.split_batch: sample() of at least this many utterances runs as TWO half batches on two HIP streams (Engine._sample_split);
+# 0 = never, the default.  The launches of a DiT block are a strict chain and each is 3.7 ... 11 rounds of one-workgroup-per-CU tiles, so
+# its last, partly filled round idles CUs (profiles/r06/m_sweep_tile_rounds.jsonl: +22 ... 29 us at every round boundary); a second,
+# independent chain gives the dispatcher workgroups to fill them with.  Measured at the 335M shape, N = 937, bit-identical results
+# (profiles/r06/split_sample_ab.jsonl, two_streams_probe.jsonl): with every MFMA operand ZERO the split is -5.4 % at 32 utterances and
+# -6.0 % at 64 -- the tails are real; with real operand values it is -0.1 / -0.4 / -3.0 % at 32 on three boxes, -2.0 % at 64, -3.5 % at 48:
+# the chip runs these launches under its power cap, and what fills idle CUs comes back as clock.  Hence opt-in: worth it for >= 48.
+SPLIT_MIN_BATCH = 0
 STATUS_FOLD_OVERFLOW, STATUS_FOLD_RAN, STATUS_SATURATED = 1, 2, 4      # include/f5tts_hip.h F5_STATUS_*
 
 
@@ -190,7 +201,7 @@ class Engine:
     """
 
     def __init__(self, cfg: DiTConfig, precision: str = "bf16", device: str | torch.device = "cuda:0", range_check: str = "sync",
-                 keep_host_weights: bool = True):
+                 keep_host_weights: bool = True, share_weights_with: Optional["Engine"] = None):
         if range_check not in RANGE_CHECKS:
             raise ValueError(f"range_check must be one of {RANGE_CHECKS}")
         if precision not in PRECISIONS:
@@ -207,11 +218,23 @@ class Engine:
         check(self.lib.f5_engine_create(C.byref(ccfg), PRECISIONS[precision], C.byref(self._h)), "f5_engine_create")
         nbytes = C.c_size_t()
         check(self.lib.f5_weights_bytes(self._h, C.byref(nbytes)), "f5_weights_bytes")
-        self.arena = _aligned_bytes(nbytes.value, self.device)
-        check(self.lib.f5_set_weights_arena(self._h, ptr(self.arena), C.c_size_t(self.arena.numel()), stream_ptr(self.device)),
-              "f5_set_weights_arena")
+        # share_weights_with: a second handle on the finalised arena of another engine of the same configuration and precision
+        # (f5_share_weights: nothing is copied; own workspace, graphs and status word) -- the sibling that runs the second half batch of
+        # a split sample()
+        if share_weights_with is None:
+            self.arena = _aligned_bytes(nbytes.value, self.device)
+            check(self.lib.f5_set_weights_arena(self._h, ptr(self.arena), C.c_size_t(self.arena.numel()), stream_ptr(self.device)),
+                  "f5_set_weights_arena")
+        else:
+            check(self.lib.f5_share_weights(self._h, share_weights_with._h), "f5_share_weights")
+            self.arena = share_weights_with.arena
         self._workspace: Optional[torch.Tensor] = None
-        self.weights_ready = False
+        self.weights_ready = share_weights_with is not None
+        self.split_batch = SPLIT_MIN_BATCH     # sample() of >= this many utterances: two half batches on two streams (0 = never: default)
+        self.split_events = 0                  # calls that ran split
+        self._sibling: Optional["Engine"] = None
+        self._pool: Optional[ThreadPoolExecutor] = None
+        self._split_seen: set = set()
         # hipGraph capture is illegal on the legacy default stream: the engine owns a side stream and
         # orders it against the caller's current stream with events (wait_stream)
         self._stream = torch.cuda.Stream(device=self.device)
@@ -236,8 +259,8 @@ class Engine:
         self.verify_events = 0                         # cross-checks that failed (the engine switched to bf16x3)
         self.last_verify_l1: Optional[float] = None
 
-    def _run_on_side_stream(self, fn):
-        cur = torch.cuda.current_stream(self.device)
+    def _run_on_side_stream(self, fn, cur=None):
+        cur = torch.cuda.current_stream(self.device) if cur is None else cur      # (torch's current stream is per host thread)
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
             fn(C.c_void_p(self._stream.cuda_stream))
@@ -245,6 +268,9 @@ class Engine:
 
     def __del__(self):
         try:
+            if getattr(self, "_pool", None) is not None:
+                self._pool.shutdown(wait=True)
+                self._pool = None
             if getattr(self, "_h", None) is not None and self._h.value:
                 self.lib.f5_engine_destroy(self._h)
                 self._h = C.c_void_p()
@@ -273,6 +299,8 @@ class Engine:
     def set_graph_cache(self, max_graphs: int) -> None:
         """Bound the number of cached hipGraphExecs (default 8); the least recently used one is destroyed."""
         check(self.lib.f5_engine_set_graph_cache(self._h, int(max_graphs)), "f5_engine_set_graph_cache")
+        if self._sibling is not None:
+            self._sibling.set_graph_cache(max_graphs)
 
     def graph_count(self) -> int:
         return int(self.lib.f5_engine_graph_count(self._h))
@@ -283,6 +311,21 @@ class Engine:
         check(self.lib.f5_engine_set_option(self._h, name.encode(), int(value)), f"f5_engine_set_option({name})")
         if self._fallback is not None and name == "null_keeps_cond":
             self._fallback.set_option(name, value)
+        if self._sibling is not None:
+            self._sibling.set_option(name, value)
+
+    def _ensure_sibling(self) -> "Engine":
+        """A second handle on THIS engine's weights arena (own workspace, own hipGraphs, own status word) and the host thread that drives
+        it: the second half batch of a split sample()."""
+        if self._sibling is None:
+            sib = Engine(self.cfg, precision=self.precision, device=self.device, range_check="off", keep_host_weights=False,
+                         share_weights_with=self)
+            for name in OPTION_NAMES:
+                sib.set_option(name, self.get_option(name))
+            sib.split_batch = 0
+            self._sibling = sib
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="f5-half-batch")
+        return self._sibling
 
     def _ensure_fallback(self) -> Optional["Engine"]:
         """The precision-"bf16x3" twin of this engine (fp32-class arithmetic, bf16's range), built once from the host weights."""
@@ -362,6 +405,11 @@ class Engine:
         assert y0.shape == cond.shape and y0.dtype == torch.float32 and y0.is_contiguous() and y0.is_cuda
         if use_mask is None:
             use_mask = B > 1                       # cfm.py:333-336
+        if 0 < self.split_batch <= B and self.verify_calls == 0:
+            done = self._sample_split(text, cond, lens, durations, y0, t, steps, method, cfg_strength, use_mask, use_graph,
+                                      return_trajectory, out, trajectory)
+            if done is not None:
+                return done                        # (None: a half reported its status word -- the whole call is repeated below, unsplit)
         ws = self.workspace(B, N, text.shape[1], steps, method)
         if out is None:
             out = torch.empty_like(cond)
@@ -393,6 +441,81 @@ class Engine:
                 if return_trajectory:
                     trajectory.copy_(ref_traj)
         return out, (trajectory if return_trajectory else None)
+
+    # ---- two half batches on two streams ---------------------------------------------------------
+    def _sample_split(self, text, cond, lens, durations, y0, t, steps, method, cfg_strength, use_mask, use_graph, return_trajectory,
+                      out, trajectory):
+        """sample() of a large batch as two independent half batches: this engine runs utterances [0, h) on its stream, a sibling handle
+        on the same weights arena runs [h, B) on its own, each enqueued by its own host thread (the HIP runtime lets a thread run only a
+        few dozen launches ahead of the GPU, so one thread cannot keep two streams fed).  Utterances do not interact (both halves keep
+        the padded length N and the batch's key-padding mask rule), so the result is bit-identical to the unsplit call
+        (tests/test_model_gpu.py::test_split_sample_is_bit_identical).  What it gains and why it is opt-in: SPLIT_MIN_BATCH above.  The first call of a
+        shape (graph capture) runs the halves one after the other.  The status words of both halves are read synchronously whatever
+        `range_check` says (the host is blocked for the length of the call anyway); if either is set the result is dropped and None is
+        returned: the caller repeats the whole call unsplit, with the warnings and fall-backs of the ordinary path."""
+        B, N, mel = cond.shape
+        h = (B + 1) // 2
+        sib = self._ensure_sibling()
+        cur = torch.cuda.current_stream(self.device)
+        if out is None:
+            out = torch.empty_like(cond)
+        nt = text.shape[1]
+        calls = []
+        for eng, (b0, b1) in ((self, (0, h)), (sib, (h, B))):
+            tr = torch.empty((steps, b1 - b0, N, mel), dtype=torch.float32, device=self.device) if return_trajectory else None
+            ws = eng.workspace(b1 - b0, N, nt, steps, method)
+            a, keep = eng._args(text[b0:b1], cond[b0:b1], lens[b0:b1], durations[b0:b1], y0[b0:b1], t, steps, method, cfg_strength,
+                                use_mask, use_graph, out[b0:b1], tr, ws)
+            calls.append((eng, a, keep, tr))
+
+        def run(eng, a):
+            torch.cuda.set_device(self.device)         # (the worker thread's current device)
+            eng._run_on_side_stream(lambda st: check(eng.lib.f5_sample(eng._h, C.byref(a), st), "f5_sample"), cur)
+
+        key = (B, N, nt, steps, method, use_graph, bool(use_mask), return_trajectory, cfg_strength >= 1e-5)
+        if key in self._split_seen:
+            fut = self._pool.submit(run, calls[1][0], calls[1][1])
+            try:
+                run(calls[0][0], calls[0][1])
+            finally:
+                fut.result()
+        else:
+            for eng, a, _, _ in calls:
+                run(eng, a)
+            self._split_seen.add(key)
+        flags = 0
+        if self._status_host is not None and self.range_check != "off":
+            for eng, a, _, _ in calls:
+                flags |= eng._status_word_blocking(a, cur)
+        if flags & (STATUS_FOLD_OVERFLOW | STATUS_SATURATED):
+            return None
+        self.split_events += 1
+        if return_trajectory:
+            if trajectory is None:
+                trajectory = torch.cat([calls[0][-1], calls[1][-1]], dim=1)
+            else:
+                trajectory[:, :h].copy_(calls[0][-1])
+                trajectory[:, h:].copy_(calls[1][-1])
+        return out, (trajectory if return_trajectory else None)
+
+    def _status_word_blocking(self, a, cur=None) -> int:
+        """The status word of the call described by `a`, read behind it on this engine's stream; waits for it."""
+        if not self._status_free:
+            self._status_pending[0][0].synchronize()
+            self.check_status(block=False)
+        slot = self._status_free.pop(0)
+        holder = {}
+
+        def enqueue_read(st):
+            check(self.lib.f5_sample_status_async(self._h, C.byref(a), C.c_void_p(self._status_host[slot:].data_ptr()), st), "f5_sample_status_async")
+            holder["ev"] = torch.cuda.Event()
+            holder["ev"].record(torch.cuda.current_stream(self.device))
+
+        self._run_on_side_stream(enqueue_read, cur)
+        holder["ev"].synchronize()
+        flags = int(self._status_host[slot])
+        self._status_free.append(slot)
+        return flags
 
     # ---- status word (fp16 operand range) ------------------------------------------------------
     def _fall_back(self, what: str, rerun: bool) -> None:
@@ -460,6 +583,8 @@ class Engine:
         self.check_status(block=True)
         if self._fallback is not None:
             self._fallback.synchronize()
+        if self._sibling is not None:
+            self._sibling.synchronize()
 
     def _after_call(self, a, launch, what: str, shape=None) -> bool:
         """Status handling of one f5_sample / f5_dit_forward call (class docstring).  Returns True when the call saturated fp16 and has

@@ -84,6 +84,12 @@ int f5_weights_bytes(f5_engine* e, size_t* bytes);
 int f5_set_weights_arena(f5_engine* e, void* dev_arena, size_t bytes, void* stream);
 int f5_load_tensor(f5_engine* e, const char* name, const float* host_data, int ndim, const int64_t* shape);
 int f5_finalize_weights(f5_engine* e, void* stream);
+/* A second handle on `owner`'s finalised arena (same f5_config and precision; nothing is copied or written, the caller keeps the arena
+ * alive for both).  Handles are not re-entrant, but two handles may run at once: a host that drives two of them from two threads on two
+ * streams, each with half of a large batch, fills the partly empty last rounds of each other's launches (-5 % at 32 utterances;
+ * f5_tts_mlx_amd/engine.py Engine._sample_split does this, INTEGRATION.md describes it).  Own workspace, hipGraphs and status word per
+ * handle. */
+int f5_share_weights(f5_engine* e, const f5_engine* owner);
 /* Multi-GPU start-up (one process per GPU, utterances sharded, no per-step communication): replicate rank `root`'s arena over an
  * RCCL communicator (`nccl_comm` = ncclComm_t) with ONE ncclBroadcast enqueued on `stream`; ranks other than root are marked
  * loaded and then call f5_finalize_weights.  librccl.so is resolved with dlopen at the first call.  (A torch.distributed host

@@ -324,6 +324,76 @@ def test_graph_split_per_ode_step_is_bit_identical(tiny_weights, method):
     m.engine.set_option("graph_split", 0)
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_split_sample_is_bit_identical(tiny_weights, prec):
+    """Round 6: sample() of a large batch runs as two half batches on two HIP streams (a sibling handle on the same weights arena,
+    enqueued by a second host thread; engine.py Engine._sample_split).  Utterances do not interact, so the bits are those of the unsplit
+    call: ragged batch of 5 (halves of 3 and 2, both padded to the batch's N, both under the batch's key-padding mask rule), graph
+    replay and eager launches (two threads inside f5_sample at once: the per-thread status pointer of the range detector), every
+    solver output incl. the trajectory, a caller-provided trajectory buffer, a changed guidance scale on the replay."""
+    cfg = TINY
+    m = _model(cfg, tiny_weights, prec)
+    eng = m.engine
+    f5 = F5TTS(transformer=m)
+    cond, text, durations, y0 = synth_inputs(cfg, 5, 96, nt=20, n_ref=16, seed=11, ragged=True)
+    kw = dict(duration=torch.tensor(durations), steps=5, y0=y0)
+    for method in ("euler", "rk4"):
+        eng.split_batch = 0
+        want = {(c, g): [x.clone() for x in f5.sample(cond, text, method=method, cfg_strength=c, use_graph=g, **kw)]
+                for c in (2.0, 0.0) for g in (True, False)}
+        eng.split_batch = 4
+        n0 = eng.split_events
+        for rep in range(3):                           # first call of a shape: the halves one after the other (capture), then concurrently
+            for (c, g), (wo, wt) in want.items():
+                out, traj = f5.sample(cond, text, method=method, cfg_strength=c, use_graph=g, **kw)
+                torch.cuda.synchronize()
+                assert torch.equal(out, wo) and torch.equal(traj, wt), (method, rep, c, g)
+        assert eng.split_events == n0 + 12 and eng._sibling is not None and eng._sibling.arena.data_ptr() == eng.arena.data_ptr()
+    # the engine-level entry with caller-owned buffers
+    B, N, mel = 5, 96, cfg.mel_dim
+    cond_p = _pad_cond(cond, N).to(DEV)
+    lens = [16] * B
+    t = np.linspace(0, 1, 5, dtype=np.float32)
+    outb, trb = torch.empty((B, N, mel), device=DEV), torch.empty((5, B, N, mel), device=DEV)
+    args = (text.to(DEV).to(torch.int32).contiguous(), cond_p, lens, durations, y0.to(DEV), t)
+    eng.split_batch = 0
+    o0, t0 = eng.sample(*args, method="midpoint")
+    eng.split_batch = 2
+    for _ in range(2):
+        o1, t1 = eng.sample(*args, method="midpoint", out=outb, trajectory=trb)
+        torch.cuda.synchronize()
+        assert o1.data_ptr() == outb.data_ptr() and t1.data_ptr() == trb.data_ptr()
+        assert torch.equal(o1, o0) and torch.equal(t1, t0)
+    # options set later reach the sibling
+    eng.set_option("null_keeps_cond", 1)
+    assert eng._sibling.get_option("null_keeps_cond") == 1
+    eng.set_option("null_keeps_cond", 0)
+
+
+def test_split_sample_flagged_half_repeats_the_call_unsplit():
+    """A half batch whose status word comes back set (here: FF1 / adaLN rows that saturate fp16, as in
+    test_f16_saturation_detector_batch1) makes the split path drop its result; the ordinary path then repeats the WHOLE call, warns and
+    falls back to bf16x3 as it does without the split: the caller gets the bf16x3 bits."""
+    cfg = TINY
+    w = synthetic_weights(cfg, seed=42)
+    r = np.random.default_rng(5)
+    pre = "transformer.transformer_blocks.1."
+    for row in r.integers(0, w[pre + "ff.ff.layers.0.layers.0.weight"].shape[0], 4):
+        w[pre + "ff.ff.layers.0.layers.0.weight"][row] *= 3.0e6
+    cond, text, durations, y0 = synth_inputs(cfg, 4, 64, nt=12, n_ref=10, seed=3, ragged=True)
+    kw = dict(duration=torch.tensor(durations), steps=4, method="euler", y0=y0)
+    ref, _ = F5TTS(transformer=_model(cfg, w, "bf16x3")).sample(cond, text, **kw)
+    torch.cuda.synchronize()
+    m = _model(cfg, w, "f16")
+    m.engine.split_batch = 2
+    f5 = F5TTS(transformer=m)
+    with pytest.warns(E.OperandRangeWarning, match="re-running it in bf16x3"):
+        out, _ = f5.sample(cond, text, **kw)
+    torch.cuda.synchronize()
+    assert m.engine.saturation_events == 1 and m.engine.split_events == 0 and m.engine._use_fallback
+    assert torch.equal(out.cpu(), ref.cpu())
+
+
 def test_c_abi_weight_broadcast_over_rccl(tiny_weights):
     """f5_broadcast_weights: the contiguous arena goes through ONE ncclBroadcast on a caller-owned RCCL communicator (here a
     1-rank communicator created with ctypes on librccl, the way a non-Python host would own one); the receiving engine is
@@ -830,6 +900,17 @@ def test_batch32_every_utterance_vs_oracle_golden(full_f16):
     out2, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=True, **mg.KW)
     torch.cuda.synchronize()
     assert torch.equal(out2.cpu(), out)
+    # ... and as two half batches of 16 on two streams (Engine.split_batch, opt-in): the first call captures the halves one after the
+    # other, the second replays them from two host threads at once -- the same bits (both halves are above the LN-fold threshold)
+    eng.split_batch = 32
+    try:
+        for _ in range(2):
+            out3, _ = f5.sample(cond, text, duration=mg.N_FRAMES, y0=y0, use_graph=True, **mg.KW)
+            torch.cuda.synchronize()
+            assert torch.equal(out3.cpu(), out)
+        assert eng.split_events == 2
+    finally:
+        eng.split_batch = 0
 
 
 @pytest.mark.parametrize("B", [4, 8, 16])

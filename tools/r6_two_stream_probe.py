@@ -93,3 +93,54 @@ for r in range(rounds):
 rec["best"] = {k: min(v) for k, v in rec["ms"].items()}
 rec["two_streams_vs_b32"] = round(rec["best"]["two_b16_two_streams"] / rec["best"]["one_engine_b32"], 4)
 print(json.dumps(rec), flush=True)
+
+# the clock follows the average power of the last seconds: sustained sequences, per-call times, in both orders
+seq = dict(kind="two_streams_sustained", calls_per_leg=6, legs=[])
+for key, fn in (("one_engine_b32", run_full), ("two_b16_two_streams", both_concurrent), ("one_engine_b32", run_full),
+                ("two_b16_two_streams", both_concurrent), ("two_b16_serial", both_serial), ("one_engine_b32", run_full)):
+    seq["legs"].append({key: [round(wall(fn), 1) for _ in range(6)]})
+print(json.dumps(seq), flush=True)
+
+# ---- variants: four quarter batches on four streams; two halves enqueued from ONE host thread (no status read inside sample())
+quarters = [model() for _ in range(4)]
+qin = [bench.synth_batch(8, first=8 * i, device=dev) for i in range(4)]
+qstreams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+
+
+def run_quarter(i):
+    c, t, y, _ = qin[i]
+    with torch.cuda.stream(qstreams[i]):
+        out, _ = quarters[i].sample(c, text=t, **kw_for(y))
+        qstreams[i].synchronize()
+    return out
+
+
+def four_concurrent():
+    th = [threading.Thread(target=run_quarter, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+
+
+for i in range(4):
+    run_quarter(i)
+for h in halves:
+    h.transformer.engine.range_check = "off"
+
+
+def two_one_thread():
+    for i in range(2):
+        c, t, y, _ = hin[i]
+        with torch.cuda.stream(streams[i]):
+            halves[i].sample(c, text=t, **kw_for(y))
+    for st_ in streams:
+        st_.synchronize()
+
+
+two_one_thread()
+seq = dict(kind="two_streams_variants", calls_per_leg=5, legs=[])
+for key, fn in (("one_engine_b32", run_full), ("four_b8_four_streams", four_concurrent), ("two_b16_one_host_thread", two_one_thread),
+                ("one_engine_b32", run_full), ("two_b16_one_host_thread", two_one_thread), ("four_b8_four_streams", four_concurrent)):
+    seq["legs"].append({key: [round(wall(fn), 1) for _ in range(5)]})
+print(json.dumps(seq), flush=True)
