@@ -701,10 +701,18 @@ def main():
                 del mb
             # (4) what a first-seen shape costs under use_graph="auto" (the Python default: almost every generate() call): the same
             # kernels launched eagerly, ~5 000 launches per sample, host-bound
+            # Measured as a PAIR: eager and graph legs in alternation, here, minutes after the headline (a headline-vs-this comparison across
+            # the sub-records in between is a comparison of clock states: profiles/r06/graph_sync_probe.jsonl)
             if B == 1 and not args.no_graph:
-                el, oe = timed_samples(f5, cond, text, dict(kw, use_graph=False), 3, 1, barrier)
-                se = summarize(el / 3 * 1e3, B)
+                legs = {"eager": [], "graph": []}
+                for _ in range(2):
+                    for name, g in (("eager", False), ("graph", True)):
+                        el, oe = timed_samples(f5, cond, text, dict(kw, use_graph=g), 3, 1, barrier)
+                        legs[name].append(el / 3 * 1e3)
+                se = summarize(min(legs["eager"]), B)
                 se["note"] = "eager launches (no hipGraph): the cost of a shape signature the first time it is seen"
+                se["paired_graph_ms_per_step"] = min(legs["graph"])
+                se["legs_ms"] = {k: [round(x, 3) for x in v] for k, v in legs.items()}
                 sub["b1_eager"] = se
             # (5) BASELINE configs[4]: MX-fp8 block GEMMs + Vocos in the timed region, 16-point midpoint, batch 32 -- a reduced-precision mode
             # OUTSIDE the parity gate by design, reported with its distance from the fp32 oracle and against the 5 PF dense fp8 peak
