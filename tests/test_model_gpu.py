@@ -370,6 +370,19 @@ def test_split_sample_is_bit_identical(tiny_weights, prec):
     eng.set_option("null_keeps_cond", 0)
 
 
+def test_split_sample_soak():
+    """tools/r6_split_soak.py: random batch sizes / lengths / solvers / graph modes / guidance scales through the split path, more shapes
+    than the graph cache holds (graphs are evicted and captured again from two host threads at once), every result bitwise equal to
+    the unsplit call."""
+    import os
+    import subprocess
+    import sys
+    from f5test import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r6_split_soak.py"), "150"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('"mismatches": []') == 2
+
+
 def test_split_sample_flagged_half_repeats_the_call_unsplit():
     """A half batch whose status word comes back set (here: FF1 / adaLN rows that saturate fp16, as in
     test_f16_saturation_detector_batch1) makes the split path drop its result; the ordinary path then repeats the WHOLE call, warns and
