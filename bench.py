@@ -161,7 +161,10 @@ def mfma_peak_measured(precision: str, dev) -> dict:
     divide by"): f5_op_mfma_peak = every wave of 1 024 workgroups streams v_mfma_f32_32x32x16 on register operands, no memory
     traffic -- once on lane-constant registers (what zero-filled benchmarks see) and once on workload-like operand registers that
     change from MFMA to MFMA (the delivered clock depends on how many operand bits toggle, MI355X_MICROARCH.md "DVFS give-back").
-    `frac` in the roofline records keeps the data-sheet 2.5 PF denominator; `frac_of_measured` divides by the workload-like figure."""
+    `frac` in the roofline records keeps the data-sheet 2.5 PF denominator; `frac_of_measured` divides by the workload-like figure.
+    Round 6: the loop now has eight INDEPENDENT accumulators (until round 5 every other MFMA waited for its predecessor and the figure
+    was that chain's rate, ~1 340 TF, not the pipe's: ~1 650 TF on the same values) and runs ~0.4 s per figure, long enough for the
+    clock to settle where the power management holds it (csrc/rowops.hip mfma_peak_kernel, profiles/r06/mfma_energy_probe.jsonl)."""
     import ctypes as C
     from f5_tts_mlx_amd import engine as E
     lib = E.load_library()
@@ -173,18 +176,18 @@ def mfma_peak_measured(precision: str, dev) -> dict:
     with E.operand_type(precision):
         for key, operands in (("constant_operands", None), ("workload_like_operands", ops)):
             fl = C.c_double()
-            run = lambda: E.check(lib.f5_op_mfma_peak(E.ptr(operands), 1024, 2000, E.ptr(sink), C.byref(fl), E.stream_ptr(dev)))   # noqa: E731
+            run = lambda: E.check(lib.f5_op_mfma_peak(E.ptr(operands), 1024, 20000, E.ptr(sink), C.byref(fl), E.stream_ptr(dev)))   # noqa: E731
             best = None
-            for _ in range(3):
+            for _ in range(2):
                 run()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(3):
+                for _ in range(6):
                     run()
                 e1.record()
                 torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / 3
+                ms = e0.elapsed_time(e1) / 6
                 best = ms if best is None else min(best, ms)
             out[key] = fl.value / (best * 1e-3) / 1e12
     return out

@@ -681,14 +681,19 @@ int f5_launch_zero_vt_pad(op16_t* vt, size_t rows, int seq_len, int npad, hipStr
 }
 
 // MFMA rate yardstick (bench.py prints the rate it measures next to the data-sheet peak it divides by): every wave
-// streams v_mfma_f32_32x32x16 on four accumulators, no memory traffic in the loop.  operands == nullptr: lane-constant operand
-// registers (what a zero / constant-filled benchmark sees); otherwise eight A and eight B fragments per lane are loaded once from
-// `operands` (>= 16 x 64 x 8 values of workload-like data) and rotated, so consecutive MFMAs see different data like a K loop does
-// -- the delivered clock depends on how many operand bits toggle (MI355X_MICROARCH.md "DVFS give-back").
+// streams v_mfma_f32_32x32x16 on EIGHT independent accumulators in the operand order of the shipped K step (consecutive pairs share
+// the B fragment), no memory traffic in the loop.  operands == nullptr: lane-constant operand registers (what a zero / constant-filled
+// benchmark sees); otherwise eight A and eight B fragments per lane are loaded once from `operands` (>= 16 x 64 x 8 values of
+// workload-like data) and rotated, so consecutive MFMAs see different data like a K loop does -- the delivered clock depends on how
+// many operand bits toggle (MI355X_MICROARCH.md "DVFS give-back").
+// Round 6 correction: until round 5 this loop had FOUR accumulators visited 0,1,1,2,2,3,3,0: every other MFMA waited for its
+// predecessor's result, and the loop measured that chain (1 336 TF at 2.0 GHz and 1 050 W -- below every limit of the chip) instead
+// of the pipe; with independent accumulators the same operand values run at 1 656 TF (1.72-1.79 GHz, 92 % pipe time, 1 240-1 270 W);
+// tools/probes/mfma_energy.hip keeps both patterns, profiles/r06/mfma_energy_probe.jsonl has the numbers.
 __global__ __launch_bounds__(512) void mfma_peak_kernel(const op16_t* __restrict__ operands, int iters, float* __restrict__ sink) {
-    f32x16 acc[4];
+    f32x16 acc[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
     op16x8 a[8], b[8];
@@ -709,13 +714,13 @@ __global__ __launch_bounds__(512) void mfma_peak_kernel(const op16_t* __restrict
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            acc[i & 3] = F5_MFMA32(a[i], b[i], acc[i & 3], 0, 0, 0);
-            acc[(i + 1) & 3] = F5_MFMA32(a[(i + 3) & 7], b[(i + 5) & 7], acc[(i + 1) & 3], 0, 0, 0);
+            acc[(2 * i) & 7] = F5_MFMA32(a[(2 * i) & 7], b[i], acc[(2 * i) & 7], 0, 0, 0);
+            acc[(2 * i + 1) & 7] = F5_MFMA32(a[(2 * i + 1) & 7], b[i], acc[(2 * i + 1) & 7], 0, 0, 0);
         }
     }
     float t = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t += acc[i][0] + acc[i][7];
+    for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][7];
     if (t == 123456.789f) sink[0] = t;                     // never true: keeps the accumulators alive
 }
 // returns the number of MFMA flops of the launch in *flops (blocks x 8 waves x iters x 16 MFMAs x 32 x 32 x 16 x 2)

@@ -1,0 +1,160 @@
+// probe (round 6): batch 32 runs at the board's power cap, so the rate the matrix pipe sustains IS its energy per flop.  Register-only
+// MFMA loops (no memory traffic), 2 waves per SIMD on every CU, workload-like operand values, a few seconds each; TF/s from HIP events,
+// clock and power from rocm-smi polled while the loop runs.  Variants: operand rotation patterns of v_mfma_f32_32x32x16_f16 (do
+// consecutive MFMAs that share an operand register cost less?), the 16x16x32 shape, bf16 operands, zero operands (the floor).
+// build: hipcc --offload-arch=gfx950 -O3 mfma_energy.hip -o bin/mfma_energy
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <string>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k(const _Float16* __restrict__ ops, int iters, float* sink) {
+    const int lane = threadIdx.x & 63;
+    h8 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = *reinterpret_cast<const h8*>(ops + ((size_t)i * 64 + lane) * 8);
+        b[i] = *reinterpret_cast<const h8*>(ops + ((size_t)(8 + i) * 64 + lane) * 8);
+        if (MODE == 5) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[i][e] = 0; b[i][e] = 0; }
+        }
+    }
+    float t = 0.0f;
+    if constexpr (MODE == 3) {              // 16x16x32: 4 x the instructions for the same flops (8 passes each... same pipe time)
+        f4v acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = f4v{0, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(i + r) & 7], b[(i * 3 + r) & 7], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += acc[i][0];
+    } else if constexpr (MODE == 4) {
+        b8 ab[8], bb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ab[i][e] = (__bf16)(float)a[i][e]; bb[i][e] = (__bf16)(float)b[i][e]; }
+        f16v acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[i], bb[i], acc[i & 3], 0, 0, 0);
+                acc[(i + 1) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[(i + 3) & 7], bb[(i + 5) & 7], acc[(i + 1) & 3], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t += acc[i][0] + acc[i][7];
+    } else {
+        f16v acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+        for (int it = 0; it < iters; ++it) {
+            if (MODE == 0 || MODE == 5) {   // the yardstick's pattern: both operands change with every instruction
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[i], acc[i & 3], 0, 0, 0);
+                    acc[(i + 1) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + 3) & 7], b[(i + 5) & 7], acc[(i + 1) & 3], 0, 0, 0);
+                }
+            } else if (MODE == 1) {         // the shipped K-step order: pairs share B (4 x 2 wave tile: for ks, nq: mb = 0, 1)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[(2 * i) & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(2 * i) & 7], b[i], acc[(2 * i) & 7], 0, 0, 0);
+                    acc[(2 * i + 1) & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(2 * i + 1) & 7], b[i], acc[(2 * i + 1) & 7], 0, 0, 0);
+                }
+            } else if (MODE == 6) {         // four consecutive MFMAs share B (a 4-row-block column of the wave tile per B fragment)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[(4 * i + m) & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(4 * i + m) & 7], b[i], acc[(4 * i + m) & 7], 0, 0, 0);
+            } else if (MODE == 2) {         // every instruction reads the same two operand registers
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc[i & 7], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][7];
+    }
+    if (t == 123456.789f) sink[0] = t;
+}
+
+static void smi(char* buf, size_t n) {
+    buf[0] = 0;
+    FILE* f = popen("rocm-smi --showclocks --showpower --json 2>/dev/null", "r");
+    if (!f) return;
+    std::string s;
+    char tmp[512];
+    while (fgets(tmp, sizeof tmp, f)) s += tmp;
+    pclose(f);
+    // crude extraction: "(1938Mhz)" after sclk, and the package power figure
+    size_t p = s.find("sclk");
+    std::string sclk = "?", pw = "?";
+    if (p != std::string::npos) { size_t q = s.find("(", p); size_t e = s.find("Mhz", q); if (q != std::string::npos && e != std::string::npos) sclk = s.substr(q + 1, e - q - 1); }
+    p = s.find("Power (W)");
+    if (p != std::string::npos) { size_t q = s.find(":", p); size_t q2 = s.find("\"", q); size_t e = s.find("\"", q2 + 1); if (q2 != std::string::npos && e != std::string::npos) pw = s.substr(q2 + 1, e - q2 - 1); }
+    snprintf(buf, n, "\"sclk_mhz\": \"%s\", \"power_w\": \"%s\"", sclk.c_str(), pw.c_str());
+}
+
+template <int MODE>
+static void run(const char* name, const _Float16* ops, float* sink, double flops_per_iter_wave) {
+    const int blocks = 1024, iters = 20000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(512), 0, 0, ops, iters, sink);
+    hipDeviceSynchronize();
+    const int launches = 24;
+    hipEventRecord(e0);
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(512), 0, 0, ops, iters, sink);
+    hipEventRecord(e1);
+    char s1[256], s2[256];
+    smi(s1, sizeof s1);                     // (the launches are queued: these two polls run while the loop does)
+    smi(s2, sizeof s2);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)launches * blocks * 8.0 * iters * flops_per_iter_wave;
+    printf("{\"probe\": \"mfma_energy\", \"variant\": \"%s\", \"seconds\": %.2f, \"tflops\": %.1f, \"smi_1\": {%s}, \"smi_2\": {%s}}\n", name, ms / 1e3, flops / ms / 1e9, s1, s2);
+    fflush(stdout);
+}
+
+int main() {
+    const size_t n = 16 * 64 * 8;
+    _Float16* h = (_Float16*)malloc(n * sizeof(_Float16));
+    srand(1);
+    for (size_t i = 0; i < n; ++i) {       // A fragments ~N(0, 1), B fragments ~N(0, 1/32) (Box-Muller)
+        const double u1 = (rand() + 1.0) / (RAND_MAX + 2.0), u2 = (rand() + 1.0) / (RAND_MAX + 2.0);
+        const double z = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        h[i] = (_Float16)(float)(i < n / 2 ? z : z * 0.03125);
+    }
+    _Float16* d; float* sink;
+    hipMalloc(&d, n * sizeof(_Float16)); hipMalloc(&sink, 64);
+    hipMemcpy(d, h, n * sizeof(_Float16), hipMemcpyHostToDevice);
+    const double F = 16.0 * 32768.0;        // 16 MFMAs of 32x32x16 per iteration and wave (or 64 of 16x16x32)
+    for (int rep = 0; rep < 2; ++rep) {
+        run<0>("f16 32x32x16, both operands change every instruction (bench yardstick)", d, sink, F);
+        run<1>("f16 32x32x16, pairs share B (the shipped K-step order)", d, sink, F);
+        run<6>("f16 32x32x16, four in a row share B", d, sink, F);
+        run<2>("f16 32x32x16, same two operand registers every instruction", d, sink, F);
+        run<3>("f16 16x16x32", d, sink, F);
+        run<4>("bf16 32x32x16, both operands change every instruction", d, sink, F);
+        run<5>("f16 32x32x16, zero operands", d, sink, F);
+    }
+    return 0;
+}
