@@ -131,6 +131,25 @@ __global__ __launch_bounds__(256, 1) void k_wave128(Args p) {
     // K tile g in slot cur_, g + 1 in nxt_, g + 3 goes to fre_ (the slot of g - 1: every wave's reads of it returned before the barrier
     // of the previous tile).  Boundary: this wave's reads of slot cur_ have returned (lgkmcnt 0), its pieces of K tile g + 1 have
     // landed (12 younger operations may be outstanding: 8 of g + 2, 4 of g + 3), barrier, then the first fragments of g + 1.
+// one 16-wide K step, interleaved BY HAND (a single wave has one issue slot: 16 MFMAs, 8 fragment reads and 4 DMA pieces must alternate,
+// and the compiler clusters them when left alone): 8 groups of (2 MFMAs on FA / FB[cur_], 1 fragment read of the NEXT step into
+// [1 - cur_], 1 DMA piece in the first four groups), each closed by a scheduling fence
+#define STEP(cur_, slotn_, ksn_, pf_, a3_, w3_, fre_)                                                                    \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                               \
+            {                                                                                                            \
+                const int t0_ = 2 * q_, t1_ = 2 * q_ + 1;                                                                \
+                acc[t0_ & 3][t0_ >> 2] = MFMA(FA[cur_][t0_ & 3], FB[cur_][t0_ >> 2], acc[t0_ & 3][t0_ >> 2], 0, 0, 0);   \
+                acc[t1_ & 3][t1_ >> 2] = MFMA(FA[cur_][t1_ & 3], FB[cur_][t1_ >> 2], acc[t1_ & 3][t1_ >> 2], 0, 0, 0);   \
+            }                                                                                                            \
+            if (ABL != 4) {                                                                                              \
+                if (q_ < 4) FA[1 - (cur_)][q_] = *reinterpret_cast<const h8*>(smem + (slotn_) + fa[ksn_] + q_ * 2048);   \
+                else FB[1 - (cur_)][q_ - 4] = *reinterpret_cast<const h8*>(smem + (slotn_) + fb[ksn_] + (q_ - 4) * 2048); \
+            }                                                                                                            \
+            if (ABL != 3 && q_ < 4) PIECE((pf_) + q_, a3_, w3_, (fre_) * SLOT);                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+        }                                                                                                                \
+    }
 #define KTILE(g_, cur_, nxt_, fre_)                                                                          \
     {                                                                                                        \
         const int g3_ = (g_) + 3 < KT ? (g_) + 3 : KT - 1;   /* past the end: re-load the last tile into a slot nobody reads */ \
@@ -138,20 +157,16 @@ __global__ __launch_bounds__(256, 1) void k_wave128(Args p) {
         const gchar* w3_ = Wb + g3_ * 64;                                                                    \
         OPAQUE(a3_);                                                                                         \
         OPAQUE(w3_);                                                                                         \
-        if (ABL != 4) FRAGS(1, (cur_) * SLOT, 1);                                                            \
-        if (ABL != 3) { _Pragma("unroll") for (int i = 0; i < 4; ++i) PIECE(i, a3_, w3_, (fre_) * SLOT); }   \
-        MMS(0);                                                                                              \
-        SCHED_STEP();                                                                                        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);      /* lgkmcnt(0): fragments (g, 0).  The BUILTIN, not asm: the compiler's own wait        \
+                                                    insertion sees it; an asm wait it does not, and with LDS-DMA pending its own wait    \
+                                                    before the first MFMA is a full lgkmcnt(0) behind a fragment read it hoisted there */ \
         FENCE();                                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
-        if (ABL != 1 && ABL != 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                          \
+        STEP(0, (cur_) * SLOT, 1, 0, a3_, w3_, fre_);                                                        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);      /* fragments (g, 1): every read of slot cur_ has returned */ \
+        if (ABL != 1 && ABL != 3) __builtin_amdgcn_s_waitcnt(0x0F7C);      /* vmcnt(12) */                    \
         if (ABL != 2) __builtin_amdgcn_s_barrier();                                                          \
         FENCE();                                                                                             \
-        if (ABL != 4) FRAGS(0, (nxt_) * SLOT, 0);                                                            \
-        if (ABL != 3) { _Pragma("unroll") for (int i = 4; i < 8; ++i) PIECE(i, a3_, w3_, (fre_) * SLOT); }   \
-        MMS(1);                                                                                              \
-        SCHED_STEP();                                                                                        \
-        FENCE();                                                                                             \
+        STEP(1, (nxt_) * SLOT, 0, 4, a3_, w3_, fre_);                                                        \
     }
     for (int g = 0; g < KT; g += 4) {
         KTILE(g, 0, 1, 3);
