@@ -241,7 +241,7 @@ static int launch128(const F5GemmArgs& a, hipStream_t stream) {
     ab.nband = (f5_gemm_nband > 0 && tiles_n > f5_gemm_nband && tiles_n % f5_gemm_nband == 0) ? f5_gemm_nband : 0;
     if (a.bias != nullptr && (reinterpret_cast<uintptr_t>(a.bias) & 15) != 0) ab.debug_flags |= 16384;
     const size_t dyn = (size_t)f5_gemm128_pad_lds;
-    if (EPI == EPI_QKV_ROPE && ab.rope_cos_tk != nullptr) {
+    if (EPI == EPI_QKV_ROPE && ab.rope_g4k != nullptr) {
         hipLaunchKernelGGL((f5_gemm128_kernel<EPI, EPI == EPI_QKV_ROPE>), dim3(ntiles), dim3(256), dyn, stream, ab, tiles_n, ntiles, tiles_m);
     } else {
         hipLaunchKernelGGL((f5_gemm128_kernel<EPI, false>), dim3(ntiles), dim3(256), dyn, stream, ab, tiles_n, ntiles, tiles_m);

@@ -452,7 +452,7 @@ static int launch_v2(const F5GemmArgs& a, hipStream_t stream) {
     if (f5_gemm_streamk && g_sk_part && ntiles >= g_sk_P) {
         hipLaunchKernelGGL((f5_gemm256_kernel<EPI, true>), dim3(g_sk_P), dim3(512), 0, stream, a, tiles_n, ntiles, g_sk_part,
                            g_sk_flag, g_sk_flag + g_sk_P, f5_gemm_streamk == 2 ? 1 : 0);
-    } else if (EPI == EPI_QKV_ROPE && ab.rope_cos_tk != nullptr) {
+    } else if (EPI == EPI_QKV_ROPE && ab.rope_g4k != nullptr) {
         hipLaunchKernelGGL((f5_gemm256_kernel<EPI, false, EPI == EPI_QKV_ROPE>), dim3(ntiles), dim3(512), 0, stream, ab, tiles_n, ntiles,
                            (float*)nullptr, (int*)nullptr, (int*)nullptr, 0);
     } else {
