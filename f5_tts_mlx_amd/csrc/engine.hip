@@ -494,7 +494,7 @@ constexpr long LN_FOLD_AUTO_ROWS = 22000;
 // (no row-factor launch), so the fold removes 44 of the 46 LN-modulate launches of a forward for a few hundred VALU instructions in the
 // residual epilogues.  LN_FOLD_SMALL_AUTO: chosen by the automatic mode (-1) where the route applies.
 constexpr long LN_FOLD_SMALL_ROWS = 2048;
-constexpr bool LN_FOLD_SMALL_AUTO = false;     // measured -0.5 ... -1.5 % at batch 1 (profiles/r06): below the 4 % bar, so opt-in (ln_fold = 1)
+constexpr bool LN_FOLD_SMALL_AUTO = false;     // measured -1.5 ... +0.7 % at batch 1 (profiles/r06): below the 4 % bar, so opt-in (ln_fold = 1)
 
 static Workspace plan_workspace(const f5_engine* e, int B, int N, int nt, int steps, int method) {
     const f5_config& c = e->cfg;
