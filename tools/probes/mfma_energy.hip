@@ -12,6 +12,36 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef int i8v __attribute__((ext_vector_type(8)));
+
+// MX-fp8 (e4m3 + E8M0 per 32): v_mfma_scale_f32_32x32x64_f8f6f4, 8 independent accumulators, pairs share B; 8 MFMAs of 131 072 flops
+// per iteration = the flops of 32 f16 MFMAs
+__global__ __launch_bounds__(512) void k_f8(const int* __restrict__ ops, int iters, float* sink) {
+    const int lane = threadIdx.x & 63;
+    i8v a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = *reinterpret_cast<const i8v*>(ops + ((size_t)i * 64 + lane) * 8);
+        b[i] = *reinterpret_cast<const i8v*>(ops + ((size_t)(4 + i) * 64 + lane) * 8);
+    }
+    f16v acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+    const int sc = 0x7f7f7f7f;      // E8M0 127 = 2^0 in every byte
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[2 * i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(2 * i) & 3], b[i], acc[2 * i], 0, 0, 0, sc, 0, sc);
+            acc[2 * i + 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(2 * i + 1) & 3], b[i], acc[2 * i + 1], 0, 0, 0, sc, 0, sc);
+        }
+    }
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][7];
+    if (t == 123456.789f) sink[0] = t;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(512) void k(const _Float16* __restrict__ ops, int iters, float* sink) {
@@ -134,6 +164,27 @@ static void run(const char* name, const _Float16* ops, float* sink, double flops
     fflush(stdout);
 }
 
+static void run_f8(const char* name, const int* ops, float* sink) {
+    const int blocks = 1024, iters = 20000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_f8, dim3(blocks), dim3(512), 0, 0, ops, iters, sink);
+    hipDeviceSynchronize();
+    const int launches = 24;
+    hipEventRecord(e0);
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_f8, dim3(blocks), dim3(512), 0, 0, ops, iters, sink);
+    hipEventRecord(e1);
+    char s1[256], s2[256];
+    smi(s1, sizeof s1);
+    smi(s2, sizeof s2);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)launches * blocks * 8.0 * iters * 8.0 * 131072.0;
+    printf("{\"probe\": \"mfma_energy\", \"variant\": \"%s\", \"seconds\": %.2f, \"tflops\": %.1f, \"smi_1\": {%s}, \"smi_2\": {%s}}\n", name, ms / 1e3, flops / ms / 1e9, s1, s2);
+    fflush(stdout);
+}
+
 int main() {
     const size_t n = 16 * 64 * 8;
     _Float16* h = (_Float16*)malloc(n * sizeof(_Float16));
@@ -146,6 +197,19 @@ int main() {
     _Float16* d; float* sink;
     hipMalloc(&d, n * sizeof(_Float16)); hipMalloc(&sink, 64);
     hipMemcpy(d, h, n * sizeof(_Float16), hipMemcpyHostToDevice);
+    // e4m3 bytes of finite, normal-looking magnitudes: random sign and mantissa, exponent field 4 ... 10
+    int* h8 = (int*)malloc(8 * 64 * 8 * sizeof(int));
+    for (int i = 0; i < 8 * 64 * 8; ++i) {
+        unsigned v = 0;
+        for (int b = 0; b < 4; ++b) {
+            const unsigned r = (unsigned)rand();
+            v |= ((((r >> 3) & 1u) << 7) | ((4u + (r >> 8) % 7u) << 3) | (r & 7u)) << (8 * b);
+        }
+        h8[i] = (int)v;
+    }
+    int* d8;
+    hipMalloc(&d8, 8 * 64 * 8 * sizeof(int));
+    hipMemcpy(d8, h8, 8 * 64 * 8 * sizeof(int), hipMemcpyHostToDevice);
     const double F = 16.0 * 32768.0;        // 16 MFMAs of 32x32x16 per iteration and wave (or 64 of 16x16x32)
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("f16 32x32x16, both operands change every instruction (bench yardstick)", d, sink, F);
@@ -155,6 +219,7 @@ int main() {
         run<3>("f16 16x16x32", d, sink, F);
         run<4>("bf16 32x32x16, both operands change every instruction", d, sink, F);
         run<5>("f16 32x32x16, zero operands", d, sink, F);
+        run_f8("MX-fp8 e4m3 32x32x64 (v_mfma_scale), 8 independent accumulators, pairs share B", d8, sink);
     }
     return 0;
 }
